@@ -1,0 +1,371 @@
+"""ctypes binding of ``libgpry_hip.so`` (C ABI declared in ``include/gpry_hip.h``).
+
+There is deliberately no CPU fallback: if the shared library is missing, or a device
+call is made on a machine without a GPU, the error is raised to the caller.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpry_hip.so")
+
+GPRY_MAX_DIM = 64
+MASK_CLASSIFIED_INF = 1
+MASK_OUTSIDE_TRUST = 2
+
+KERNEL_IDS = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
+
+
+class GpryAffine(C.Structure):
+    _fields_ = [("has_x_affine", C.c_int),
+                ("x_lo", C.c_double * GPRY_MAX_DIM),
+                ("x_span", C.c_double * GPRY_MAX_DIM),
+                ("y_mean", C.c_double), ("y_std", C.c_double),
+                ("clip_hi", C.c_double)]
+
+
+class GpryCand(C.Structure):
+    _fields_ = [("acq", C.c_double), ("y", C.c_double), ("sigma", C.c_double),
+                ("idx", C.c_int64)]
+
+
+CAND_DTYPE = np.dtype([("acq", "<f8"), ("y", "<f8"), ("sigma", "<f8"), ("idx", "<i8")])
+
+_P = C.POINTER
+_dp = _P(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/gpry_hip.h one to one
+SIGNATURES = {
+    "gpry_version": (C.c_int, []),
+    "gpry_device_count": (C.c_int, [_P(C.c_int)]),
+    "gpry_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, _P(C.c_int64), _P(C.c_int),
+                                   _P(C.c_int), C.c_char_p, C.c_int]),
+    "gpry_ctx_create": (C.c_int, [C.c_int, _P(_vp)]),
+    "gpry_ctx_destroy": (C.c_int, [_vp]),
+    "gpry_last_error": (C.c_char_p, [_vp]),
+    "gpry_ctx_sync": (C.c_int, [_vp]),
+    "gpry_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "gpry_set_train": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int]),
+    "gpry_set_theta": (C.c_int, [_vp, C.c_int, _vp]),
+    "gpry_set_affine": (C.c_int, [_vp, _P(GpryAffine)]),
+    "gpry_kernel_train": (C.c_int, [_vp, C.c_int, _vp]),
+    "gpry_kernel_cross": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "gpry_factorize": (C.c_int, [_vp, _P(C.c_int)]),
+    "gpry_get_factor": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gpry_lml": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_double), _vp, _P(C.c_int)]),
+    "gpry_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "gpry_sweep_logexp": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_double, C.c_double,
+                                    C.c_double, _vp, _vp, _vp, _P(C.c_int64)]),
+    "gpry_sweep_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _P(C.c_int64),
+                                  _P(C.c_double)]),
+    "gpry_kb_reset": (C.c_int, [_vp]),
+    "gpry_kb_register": (C.c_int, [_vp, _vp, C.c_int64, _P(C.c_int64), _vp]),
+    "gpry_kb_gram": (C.c_int, [_vp, C.c_int64, _vp, _vp, _P(C.c_int64)]),
+    "gpry_comm_unique_id": (C.c_int, [_vp]),
+    "gpry_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _P(_vp)]),
+    "gpry_comm_destroy": (C.c_int, [_vp]),
+    "gpry_comm_allgather": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "gpry_comm_allreduce_max": (C.c_int, [_vp, _vp, C.c_int64]),
+    "gpry_comm_barrier": (C.c_int, [_vp]),
+    "gpry_timing_reset": (C.c_int, [_vp]),
+    "gpry_timing_get": (C.c_int, [_vp, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
+    "gpry_microbench": (C.c_int, [_vp, C.c_int, C.c_int64, _P(C.c_double)]),
+    "gpry_debug_gemm": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 9),
+}
+
+
+class GpryHipError(RuntimeError):
+    """An API / HIP / RCCL failure reported by libgpry_hip.so."""
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load (once) and return the shared library.  Raises if it cannot be loaded."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("GPRY_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise GpryHipError(
+            f"{p} not found. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C gpry_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def device_count():
+    n = C.c_int(0)
+    lib = load_library()
+    if lib.gpry_device_count(C.byref(n)) != 0:
+        return 0
+    return n.value
+
+
+class Device:
+    """One ``gpry_ctx``: the device-resident GP state of one GPU."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.gpry_ctx_create(int(device), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.gpry_last_error(None).decode(errors="replace")
+            self._h = None
+            raise GpryHipError(f"gpry_ctx_create(device={device}) failed ({rc}): {msg}. "
+                               "The HIP path needs a GPU; there is no CPU fallback.")
+        self.device = int(device)
+        self.N = 0
+        self.d = 0
+
+    # -- plumbing -------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.gpry_last_error(self._h).decode(errors="replace")
+            raise GpryHipError(f"{what} failed ({rc}): {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                self._lib.gpry_ctx_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def sync(self):
+        self._check(self._lib.gpry_ctx_sync(self._h), "gpry_ctx_sync")
+
+    def set_option(self, key, value):
+        self._check(self._lib.gpry_ctx_set_option(self._h, key.encode(), int(value)),
+                    "gpry_ctx_set_option")
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        arch = C.create_string_buffer(256)
+        hbm, ncu, clk = C.c_int64(0), C.c_int(0), C.c_int(0)
+        self._check(self._lib.gpry_device_info(self.device, name, 256, C.byref(hbm), C.byref(ncu),
+                                               C.byref(clk), arch, 256), "gpry_device_info")
+        return {"name": name.value.decode(), "arch": arch.value.decode(),
+                "hbm_bytes": hbm.value, "n_cu": ncu.value, "clock_khz": clk.value}
+
+    # -- model state ----------------------------------------------------------------
+    def set_train(self, X_, y_, alpha):
+        X_ = _f64(X_)
+        N, d = X_.shape
+        y_ = _f64(y_, (N,))
+        alpha = _f64(np.broadcast_to(alpha, (N,)))
+        self._check(self._lib.gpry_set_train(self._h, _ptr(X_), _ptr(y_), _ptr(alpha), N, d),
+                    "gpry_set_train")
+        self.N, self.d = N, d
+
+    def set_theta(self, kernel_id, theta):
+        theta = _f64(theta, (self.d + 1,))
+        self._check(self._lib.gpry_set_theta(self._h, int(kernel_id), _ptr(theta)),
+                    "gpry_set_theta")
+
+    def set_affine(self, x_lo=None, x_span=None, y_mean=0.0, y_std=1.0, clip_hi=np.inf):
+        tf = GpryAffine()
+        tf.has_x_affine = 0 if x_lo is None else 1
+        if x_lo is not None:
+            for k in range(len(x_lo)):
+                tf.x_lo[k] = float(x_lo[k])
+                tf.x_span[k] = float(x_span[k])
+        tf.y_mean, tf.y_std = float(y_mean), float(y_std)
+        tf.clip_hi = float(clip_hi)
+        self._check(self._lib.gpry_set_affine(self._h, C.byref(tf)), "gpry_set_affine")
+
+    # -- kernels --------------------------------------------------------------------
+    def kernel_train(self, add_alpha=False):
+        K = np.empty((self.N, self.N))
+        self._check(self._lib.gpry_kernel_train(self._h, int(bool(add_alpha)), _ptr(K)),
+                    "gpry_kernel_train")
+        return K
+
+    def kernel_cross(self, Xc_):
+        Xc_ = _f64(Xc_)
+        M = Xc_.shape[0]
+        K = np.empty((M, self.N))
+        if M:
+            self._check(self._lib.gpry_kernel_cross(self._h, _ptr(Xc_), M, _ptr(K)),
+                        "gpry_kernel_cross")
+        return K
+
+    # -- factor / lml ---------------------------------------------------------------
+    def factorize(self):
+        info = C.c_int(0)
+        self._check(self._lib.gpry_factorize(self._h, C.byref(info)), "gpry_factorize")
+        return info.value
+
+    def get_factor(self, want_L=True, want_V=True, want_alpha=True):
+        N = self.N
+        L = np.empty((N, N)) if want_L else None
+        V = np.empty((N, N)) if want_V else None
+        a = np.empty(N) if want_alpha else None
+        self._check(self._lib.gpry_get_factor(self._h, _ptr(L), _ptr(V), _ptr(a)),
+                    "gpry_get_factor")
+        return L, V, a
+
+    def lml(self, theta, eval_gradient=False):
+        theta = _f64(theta, (self.d + 1,))
+        val, info = C.c_double(0.0), C.c_int(0)
+        grad = np.zeros(self.d + 1)
+        self._check(self._lib.gpry_lml(self._h, _ptr(theta), int(bool(eval_gradient)),
+                                       C.byref(val), _ptr(grad), C.byref(info)), "gpry_lml")
+        if eval_gradient:
+            return val.value, grad, info.value
+        return val.value, info.value
+
+    # -- predict / sweep ------------------------------------------------------------
+    def predict(self, X, return_std=False, mask=None):
+        X = _f64(X)
+        M = X.shape[0]
+        mean = np.empty(M)
+        std = np.empty(M) if return_std else None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        if M:
+            self._check(self._lib.gpry_predict(self._h, _ptr(X), M, _ptr(mask), _ptr(mean),
+                                               _ptr(std)), "gpry_predict")
+        return (mean, std) if return_std else mean
+
+    def sweep_logexp(self, X, zeta, baseline, sigma_n, mask=None, M=None, want=("y", "sigma", "acq")):
+        """Run the fused sweep.  ``X=None`` re-uses the candidate set resident on the device."""
+        if X is not None:
+            X = _f64(X)
+            M = X.shape[0]
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        out = {k: (np.empty(M) if k in want else None) for k in ("y", "sigma", "acq")}
+        n_nan = C.c_int64(0)
+        self._check(self._lib.gpry_sweep_logexp(
+            self._h, _ptr(X), M, _ptr(mask), float(zeta), float(baseline), float(sigma_n),
+            _ptr(out["y"]), _ptr(out["sigma"]), _ptr(out["acq"]), C.byref(n_nan)),
+            "gpry_sweep_logexp")
+        out["n_nan"] = n_nan.value
+        return out
+
+    def sweep_topk(self, Kp, exclude=None):
+        Kp = int(Kp)
+        top = np.zeros(max(Kp, 1), dtype=CAND_DTYPE)
+        n_out, bound = C.c_int64(0), C.c_double(0.0)
+        if exclude is not None and len(exclude):
+            exclude = np.ascontiguousarray(np.sort(np.asarray(exclude, dtype=np.int64)))
+            nex = len(exclude)
+        else:
+            exclude, nex = None, 0
+        self._check(self._lib.gpry_sweep_topk(self._h, Kp, _ptr(exclude), nex, _ptr(top),
+                                              C.byref(n_out), C.byref(bound)), "gpry_sweep_topk")
+        return top[:n_out.value], bound.value
+
+    # -- Kriging believer -----------------------------------------------------------
+    def kb_reset(self):
+        self._check(self._lib.gpry_kb_reset(self._h), "gpry_kb_reset")
+
+    def kb_register(self, X, want_var0=True):
+        X = _f64(X)
+        m = X.shape[0]
+        first = C.c_int64(0)
+        var0 = np.empty(m) if want_var0 else None
+        self._check(self._lib.gpry_kb_register(self._h, _ptr(X), m, C.byref(first), _ptr(var0)),
+                    "gpry_kb_register")
+        return first.value, var0
+
+    def kb_gram(self, p, n):
+        G, kv = np.empty(n), np.empty(n)
+        nn = C.c_int64(0)
+        self._check(self._lib.gpry_kb_gram(self._h, int(p), _ptr(G), _ptr(kv), C.byref(nn)),
+                    "gpry_kb_gram")
+        if nn.value != n:
+            raise GpryHipError(f"kb_gram: device holds {nn.value} candidates, host expected {n}")
+        return G, kv
+
+    # -- measurement ----------------------------------------------------------------
+    def timing_reset(self):
+        self._check(self._lib.gpry_timing_reset(self._h), "gpry_timing_reset")
+
+    def timing(self, name):
+        ms, cnt = C.c_double(0.0), C.c_int64(0)
+        self._lib.gpry_timing_get(self._h, name.encode(), C.byref(ms), C.byref(cnt))
+        return ms.value, cnt.value
+
+    def debug_gemm(self, A, B, C0, M, N, K, a_trans=False, b_trans=False, epi=0, kmode=0,
+                   lower_only=False, tile_map=0):
+        """Unit-test hook for the MFMA GEMM engine (see include/gpry_hip.h)."""
+        A, B = _f64(A), _f64(B)
+        crow = (M + 127) // 128 if epi == 3 else M
+        Cout = np.ascontiguousarray(np.zeros((crow, N)) if C0 is None else C0, dtype=np.float64).copy()
+        self._check(self._lib.gpry_debug_gemm(self._h, _ptr(A), _ptr(B), _ptr(Cout), M, N, K,
+                                              int(a_trans), int(b_trans), int(epi), int(kmode),
+                                              int(lower_only), int(tile_map)), "gpry_debug_gemm")
+        return Cout
+
+    def microbench(self, kind, nbytes=0):
+        v = C.c_double(0.0)
+        self._check(self._lib.gpry_microbench(self._h, int(kind), int(nbytes), C.byref(v)),
+                    "gpry_microbench")
+        return v.value
+
+
+class RcclComm:
+    """RCCL communicator of one rank (one process per GPU)."""
+
+    def __init__(self, dev, world, rank, unique_id):
+        self._dev = dev
+        self._lib = dev._lib
+        self.world, self.rank = int(world), int(rank)
+        self._h = C.c_void_p()
+        uid = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        dev._check(self._lib.gpry_comm_init(dev._h, self.world, self.rank, _ptr(uid),
+                                            C.byref(self._h)), "gpry_comm_init")
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = np.zeros(128, dtype=np.uint8)
+        if lib.gpry_comm_unique_id(_ptr(buf)) != 0:
+            raise GpryHipError("gpry_comm_unique_id failed: " +
+                               lib.gpry_last_error(None).decode(errors="replace"))
+        return buf.tobytes()
+
+    def allgather(self, arr):
+        arr = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + arr.shape, dtype=arr.dtype)
+        self._dev._check(self._lib.gpry_comm_allgather(self._h, _ptr(arr), arr.nbytes, _ptr(out)),
+                         "gpry_comm_allgather")
+        return out
+
+    def allreduce_max(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64).copy()
+        self._dev._check(self._lib.gpry_comm_allreduce_max(self._h, _ptr(arr), arr.size),
+                         "gpry_comm_allreduce_max")
+        return arr
+
+    def barrier(self):
+        self._dev._check(self._lib.gpry_comm_barrier(self._h), "gpry_comm_barrier")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpry_comm_destroy(self._h)
+            self._h = None

@@ -1,0 +1,694 @@
+// C-ABI entry points of the GP hot path (include/gpry_hip.h): factor, LML, predict,
+// fused NORA sweep, shortlist selection and Kriging-believer support.
+#include "common.h"
+#include <algorithm>
+
+static int require_model(gpry_ctx* ctx, bool need_factor) {
+    if (ctx->N <= 0) return gpry_fail(ctx, -1, "no training set (call gpry_set_train)");
+    if (!ctx->have_theta) return gpry_fail(ctx, -1, "no hyperparameters (call gpry_set_theta)");
+    if (need_factor && !ctx->factor_valid) return gpry_fail(ctx, -1, "model not factorised (call gpry_factorize)");
+    return 0;
+}
+
+static int ensure_part(gpry_ctx* ctx, int64_t need) {
+    if (need <= ctx->part_cap) return 0;
+    if (ctx->dpart) GPRY_TRY(dev_free(ctx, ctx->dpart));
+    ctx->dpart = nullptr; ctx->part_cap = 0;
+    GPRY_TRY(dev_alloc(ctx, &ctx->dpart, need));
+    ctx->part_cap = need;
+    return 0;
+}
+
+// copy a device matrix with leading dimension ld to a dense host rows x cols array
+static int copy_out_matrix(gpry_ctx* ctx, const double* dsrc, int64_t ld, int64_t rows, int64_t cols, double* hdst) {
+    HIP_TRY(ctx, hipMemcpy2DAsync(hdst, sizeof(double) * cols, dsrc, sizeof(double) * ld,
+                                  sizeof(double) * cols, rows, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* info_host) {
+    // A <- K + diag(alpha); A <- chol(A) (lower); V <- A^-1
+    {
+        StageScope s(ctx, "kernel_build");
+        GPRY_TRY(launch_scale_train(ctx));
+        GPRY_TRY(launch_kernel_train(ctx, A, 1));
+    }
+    if (ctx->opt_chol == 1) {
+        StageScope s(ctx, "potrf");
+        GPRY_TRY(rocsolver_potrf_trtri(ctx, A, V, ctx->Np, 1));
+    } else {
+        {
+            StageScope s(ctx, "potrf");
+            GPRY_TRY(potrf_lower(ctx, A, ctx->Np));
+        }
+        {
+            StageScope s(ctx, "trtri");
+            GPRY_TRY(trtri_lower(ctx, A, V, T, ctx->Np));
+        }
+    }
+    int info[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(info, ctx->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *info_host = info[0] != 0 ? info[0] : info[1];
+    return 0;
+}
+
+__global__ void zero_upper_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t ld, int64_t n) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    int64_t i = idx / n, j = idx - i * n;
+    dst[idx] = (j <= i) ? src[i * ld + j] : 0.0;
+}
+
+extern "C" {
+
+int gpry_kernel_train(gpry_ctx* ctx, int add_alpha, double* K_out) {
+    GPRY_TRY(require_model(ctx, false));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        StageScope s(ctx, "kernel_build");
+        GPRY_TRY(launch_scale_train(ctx));
+        GPRY_TRY(launch_kernel_train(ctx, ctx->dW, add_alpha));
+    }
+    if (K_out) GPRY_TRY(copy_out_matrix(ctx, ctx->dW, ctx->Np, ctx->N, ctx->N, K_out));
+    else HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int gpry_kernel_cross(gpry_ctx* ctx, const double* Xc_, int64_t M, double* K_out) {
+    GPRY_TRY(require_model(ctx, false));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (M <= 0) return 0;
+    int64_t mp = round_up(M, 256);
+    double *dX = nullptr, *dK = nullptr;
+    GPRY_TRY(dev_alloc(ctx, &dX, M * ctx->d));
+    GPRY_TRY(dev_alloc(ctx, &dK, ctx->Np * mp));
+    HIP_TRY(ctx, hipMemcpyAsync(dX, Xc_, sizeof(double) * M * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+    GPRY_TRY(launch_scale_train(ctx));
+    int64_t saveM = ctx->sw_M; ctx->sw_M = M;
+    int rc = launch_cross_build(ctx, dX, 0, mp, mp, dK, nullptr, 0);
+    ctx->sw_M = saveM;
+    if (rc) return rc;
+    // dK is N x mp (k-major); the caller wants M x N: transpose on the host side copy
+    std::vector<double> tmp((size_t)ctx->N * M);
+    GPRY_TRY(copy_out_matrix(ctx, dK, mp, ctx->N, M, tmp.data()));
+    for (int64_t j = 0; j < ctx->N; j++)
+        for (int64_t m = 0; m < M; m++) K_out[m * ctx->N + j] = tmp[(size_t)j * M + m];
+    GPRY_TRY(dev_free(ctx, dX)); GPRY_TRY(dev_free(ctx, dK));
+    return 0;
+}
+
+int gpry_factorize(gpry_ctx* ctx, int* info) {
+    GPRY_TRY(require_model(ctx, false));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->factor_valid = false;
+    ctx->kb_n = 0;
+    int inf = 0;
+    GPRY_TRY(build_factor(ctx, ctx->dA, ctx->dV, ctx->dW, &inf));
+    if (info) *info = inf;
+    if (inf != 0) return 0;
+    // alpha_ = V^T (V y)
+    GPRY_TRY(solve_alpha(ctx, ctx->dV, ctx->dy, ctx->dvec, ctx->dalpha_, ctx->Np));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->factor_valid = true;
+    return 0;
+}
+
+int gpry_get_factor(gpry_ctx* ctx, double* L, double* V, double* alpha_) {
+    GPRY_TRY(require_model(ctx, true));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int64_t N = ctx->N;
+    if (L) {
+        double* tmp = nullptr;
+        GPRY_TRY(dev_alloc(ctx, &tmp, N * N));
+        hipLaunchKernelGGL(zero_upper_copy_kernel, dim3((unsigned)((N * N + 255) / 256)), dim3(256), 0,
+                           ctx->stream, ctx->dA, tmp, ctx->Np, N);
+        HIP_TRY(ctx, hipMemcpyAsync(L, tmp, sizeof(double) * N * N, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        GPRY_TRY(dev_free(ctx, tmp));
+    }
+    if (V) GPRY_TRY(copy_out_matrix(ctx, ctx->dV, ctx->Np, N, N, V));
+    if (alpha_) {
+        HIP_TRY(ctx, hipMemcpyAsync(alpha_, ctx->dalpha_, sizeof(double) * N, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, double* grad, int* info) {
+    if (ctx->N <= 0) return gpry_fail(ctx, -1, "no training set (call gpry_set_train)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // evaluate at `theta` without disturbing the prediction factor (dA, dV, dalpha_)
+    double saved[1 + GPRY_MAX_DIM];
+    bool had = ctx->have_theta;
+    memcpy(saved, ctx->theta, sizeof(saved));
+    for (int k = 0; k <= ctx->d; k++) {
+        if (!isfinite(theta[k])) return gpry_fail(ctx, -1, "theta[%d] is not finite", k);
+        ctx->theta[k] = theta[k];
+    }
+    ctx->have_theta = true;
+    int inf = 0;
+    int rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, &inf);
+    double* dz = ctx->dvec;                 // z = V y
+    double* da = ctx->dvec + ctx->Np;       // alpha
+    double* dout = ctx->dvec + 2 * ctx->Np; // [logdet/2, quad, grad...]
+    if (rc == 0 && inf == 0) {
+        rc = solve_alpha(ctx, ctx->dW2, ctx->dy, dz, da, ctx->Np);
+        if (rc == 0) rc = logdet_and_quad(ctx, ctx->dW, dz, ctx->Np, dout);
+        if (rc == 0 && want_grad) {
+            {
+                StageScope s(ctx, "lauum");
+                rc = lauum_lower(ctx, ctx->dW2, ctx->dW3, ctx->Np);
+            }
+            if (rc == 0) {
+                StageScope s(ctx, "lml_traces");
+                rc = launch_lml_traces(ctx, ctx->dW3, da, dout + 2);
+            }
+        }
+    }
+    double host[2 + 1 + GPRY_MAX_DIM];
+    if (rc == 0 && inf == 0) {
+        hipError_t e = hipMemcpyAsync(host, dout, sizeof(double) * (2 + (want_grad ? ctx->d + 1 : 0)),
+                                      hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = gpry_fail(ctx, -2, "lml copy-out: %s", hipGetErrorString(e));
+    }
+    memcpy(ctx->theta, saved, sizeof(saved));
+    ctx->have_theta = had;
+    if (rc) return rc;
+    // the scaled training coordinates belong to the prediction factor: restore them
+    if (had && ctx->factor_valid) { GPRY_TRY(launch_scale_train(ctx)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+    if (info) *info = inf;
+    if (inf != 0) {   // sklearn:_gpr.py:586-589
+        *lml = -INFINITY;
+        if (want_grad && grad) for (int k = 0; k <= ctx->d; k++) grad[k] = 0.0;
+        return 0;
+    }
+    *lml = -0.5 * host[1] - host[0] - 0.5 * (double)ctx->N * log(2.0 * M_PI);
+    if (want_grad && grad) for (int k = 0; k <= ctx->d; k++) grad[k] = host[2 + k];
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
+// sweep
+struct FinishParams {
+    double C, y_mean, y_std, clip_hi, zeta, baseline, sigma_n;
+    int want_std, want_acq;
+};
+
+// per candidate: reduce the partials, apply the reference's post-processing chain
+// (gpry/gpr.py:1180-1231) and LogExp.f (gpry/acquisition_functions.py:1068-1074)
+__global__ void sweep_finish_kernel(const double* __restrict__ mean_part, const double* __restrict__ ss_part,
+                                    int nt, int64_t ldp, int64_t m0, int64_t mc, const uint8_t* __restrict__ mask,
+                                    double* __restrict__ y_all, double* __restrict__ sig_all,
+                                    double* __restrict__ acq_all, FinishParams fp) {
+    int64_t ml = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ml >= mc) return;
+    int64_t m = m0 + ml;
+    double mu_ = 0.0;
+    for (int t = 0; t < nt; t++) mu_ += mean_part[(int64_t)t * ldp + ml];
+    double y = mu_ * fp.y_std + fp.y_mean;
+    y = fmin(y, fp.clip_hi);
+    unsigned mk = mask ? mask[m] : 0u;
+    if (mk) y = -INFINITY;
+    y_all[m] = y;
+    if (!fp.want_std) return;
+    double ss = 0.0;
+    for (int t = 0; t < nt; t++) ss += ss_part[(int64_t)t * ldp + ml];
+    double var = fp.C - ss;
+    if (var < 0.0) var = 0.0;
+    double sd = sqrt(var) * fp.y_std;
+    if (mk & GPRY_MASK_CLASSIFIED_INF) sd = 0.0;
+    sig_all[m] = sd;
+    if (!fp.want_acq) return;
+    double v = sd * sd - fp.sigma_n * fp.sigma_n;
+    if (v < 0.0) v = 0.0;
+    acq_all[m] = 2.0 * fp.zeta * (y - fp.baseline) + log(sqrt(v));
+}
+
+static int ensure_sweep_buffers(gpry_ctx* ctx, int64_t M) {
+    if (M > ctx->sw_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        void* old[] = {ctx->dXc, ctx->dmask, ctx->dy_all, ctx->dsig_all, ctx->dacq_all};
+        for (void* p : old) if (p) GPRY_TRY(dev_free(ctx, p));
+        int64_t cap = round_up(M, 1024);
+        GPRY_TRY(dev_alloc(ctx, &ctx->dXc, cap * GPRY_MAX_DIM / 2));  // d <= 32
+        GPRY_TRY(dev_alloc(ctx, &ctx->dmask, cap));
+        GPRY_TRY(dev_alloc(ctx, &ctx->dy_all, cap));
+        GPRY_TRY(dev_alloc(ctx, &ctx->dsig_all, cap));
+        GPRY_TRY(dev_alloc(ctx, &ctx->dacq_all, cap));
+        ctx->sw_cap = cap;
+    }
+    return 0;
+}
+
+// runs the chunked sweep over candidates resident in ctx->dXc
+static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bool want_acq,
+                     double zeta, double baseline, double sigma_n) {
+    const int64_t Np = ctx->Np;
+    const int nt = (int)(Np / 128);
+    int64_t chunk = ctx->opt_sweep_chunk;
+    if (chunk > round_up(M, 128)) chunk = round_up(M, 128);
+    if (Np * chunk > ctx->kst_cap) {
+        if (ctx->dKst) GPRY_TRY(dev_free(ctx, ctx->dKst));
+        ctx->dKst = nullptr; ctx->kst_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dKst, Np * chunk));
+        ctx->kst_cap = Np * chunk;
+    }
+    GPRY_TRY(ensure_part(ctx, 2 * (int64_t)nt * chunk));
+    FinishParams fp;
+    fp.C = exp(ctx->theta[0]); fp.y_mean = ctx->tf.y_mean; fp.y_std = ctx->tf.y_std;
+    fp.clip_hi = ctx->tf.clip_hi; fp.zeta = zeta; fp.baseline = baseline; fp.sigma_n = sigma_n;
+    fp.want_std = want_std; fp.want_acq = want_acq;
+    ctx->sw_M = M;
+    for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+        int64_t mc = (M - m0 < chunk) ? M - m0 : chunk;
+        int64_t mcp = round_up(mc, 128);
+        double* mean_part = ctx->dpart;
+        double* ss_part = ctx->dpart + (int64_t)nt * chunk;
+        {
+            StageScope s(ctx, "cross_build");
+            GPRY_TRY(launch_cross_build(ctx, ctx->dXc, m0, mcp, mcp, ctx->dKst, mean_part, 1));
+        }
+        if (want_std) {
+            StageScope s(ctx, "sweep_gemm");
+            GemmArgs g = {};
+            g.A = ctx->dV; g.lda = Np; g.B = ctx->dKst; g.ldb = mcp; g.C = ss_part; g.ldc = mcp;
+            g.M = (int)Np; g.N = (int)mcp; g.K = (int)Np;
+            g.kmode = KM_A_LOWER; g.lower_only = 0; g.tile_map = TM_SWEEP;
+            GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_SUMSQ));
+        }
+        {
+            StageScope s(ctx, "sweep_finish");
+            hipLaunchKernelGGL(sweep_finish_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream,
+                               mean_part, ss_part, nt, mcp, m0, mc, have_mask ? ctx->dmask : nullptr,
+                               ctx->dy_all, ctx->dsig_all, ctx->dacq_all, fp);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+static int upload_candidates(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask) {
+    GPRY_TRY(ensure_sweep_buffers(ctx, M));
+    if (X) HIP_TRY(ctx, hipMemcpyAsync(ctx->dXc, X, sizeof(double) * M * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+    else if (ctx->sw_M != M) return gpry_fail(ctx, -1, "X == NULL but no resident candidate set of size %lld", (long long)M);
+    if (mask) HIP_TRY(ctx, hipMemcpyAsync(ctx->dmask, mask, (size_t)M, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+__global__ void count_nan_kernel(const double* __restrict__ a, int64_t n, unsigned long long* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (; i < n; i += stride) c += (a[i] != a[i]) ? 1ull : 0ull;
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+extern "C" {
+
+int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask, double* mean, double* std) {
+    GPRY_TRY(require_model(ctx, true));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (M <= 0) return 0;
+    if (!X) return gpry_fail(ctx, -1, "predict: X is NULL");
+    GPRY_TRY(upload_candidates(ctx, X, M, mask));
+    GPRY_TRY(run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0));
+    HIP_TRY(ctx, hipMemcpyAsync(mean, ctx->dy_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
+    if (std) HIP_TRY(ctx, hipMemcpyAsync(std, ctx->dsig_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask, double zeta,
+                      double baseline, double sigma_n, double* y_all, double* sigma_all, double* acq_all,
+                      int64_t* n_nan) {
+    GPRY_TRY(require_model(ctx, true));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (M <= 0) return gpry_fail(ctx, -1, "sweep: M must be > 0");
+    GPRY_TRY(upload_candidates(ctx, X, M, mask));
+    GPRY_TRY(run_sweep(ctx, M, mask != nullptr, true, true, zeta, baseline, sigma_n));
+    if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dsel, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(count_nan_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->dacq_all, M, ctx->dsel);
+    unsigned long long nn = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nn, ctx->dsel, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (y_all) HIP_TRY(ctx, hipMemcpyAsync(y_all, ctx->dy_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
+    if (sigma_all) HIP_TRY(ctx, hipMemcpyAsync(sigma_all, ctx->dsig_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
+    if (acq_all) HIP_TRY(ctx, hipMemcpyAsync(acq_all, ctx->dacq_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_nan) *n_nan = (int64_t)nn;
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
+// shortlist selection: exact radix select on the 96-bit composite key
+// (order-preserving image of acq, candidate index), 12 passes of 8 bits.
+struct SelState { unsigned long long hi; unsigned int lo; unsigned int pad; unsigned long long k_rem; unsigned long long count_ge; };
+
+__device__ __forceinline__ unsigned long long acq_key(double a) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(a);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ void make_keys_kernel(const double* __restrict__ acq, int64_t M, unsigned long long* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) keys[i] = acq_key(acq[i]);
+}
+__global__ void exclude_keys_kernel(unsigned long long* keys, const int64_t* excl, int64_t n, int64_t M) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && excl[i] >= 0 && excl[i] < M) keys[excl[i]] = 0ull;   // below key(-inf)
+}
+
+// digit of pass p (0 = most significant byte of the acq key ... 7; 8..11 = index bytes)
+__device__ __forceinline__ unsigned digit_of(unsigned long long key, unsigned int idx, int pass) {
+    return pass < 8 ? (unsigned)((key >> (56 - 8 * pass)) & 0xFF) : (unsigned)((idx >> (24 - 8 * (pass - 8))) & 0xFF);
+}
+__device__ __forceinline__ bool prefix_match(unsigned long long key, unsigned int idx, const SelState& s, int pass) {
+    if (pass == 0) return true;
+    if (pass <= 8) {
+        int sh = 64 - 8 * pass;
+        return sh >= 64 ? true : ((key >> sh) == (s.hi >> sh));
+    }
+    if (key != s.hi) return false;
+    int sh = 32 - 8 * (pass - 8);
+    return (idx >> sh) == (s.lo >> sh);
+}
+
+__global__ __launch_bounds__(256) void select_hist_kernel(const unsigned long long* __restrict__ keys, int64_t M,
+                                                          const SelState* __restrict__ st, int pass,
+                                                          unsigned int* __restrict__ hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    SelState s = *st;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < M; i += stride) {
+        unsigned long long k = keys[i];
+        if (k == 0ull) continue;   // excluded
+        if (prefix_match(k, (unsigned)i, s, pass)) atomicAdd(&h[digit_of(k, (unsigned)i, pass)], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void select_scan_kernel(unsigned int* hist, SelState* st, int pass) {
+    if (threadIdx.x != 0) return;
+    SelState s = *st;
+    unsigned long long k = s.k_rem, acc = 0;
+    int dsel = 0;
+    for (int dgt = 255; dgt >= 0; dgt--) {
+        unsigned long long c = hist[dgt];
+        if (acc + c >= k) { dsel = dgt; break; }
+        acc += c;
+    }
+    s.k_rem = k - acc;
+    if (pass < 8) s.hi |= ((unsigned long long)dsel) << (56 - 8 * pass);
+    else s.lo |= ((unsigned int)dsel) << (24 - 8 * (pass - 8));
+    *st = s;
+    for (int dgt = 0; dgt < 256; dgt++) hist[dgt] = 0;
+}
+// emit every candidate whose composite key >= threshold; track the best one below it
+__global__ void select_emit_kernel(const unsigned long long* __restrict__ keys, int64_t M, const SelState* __restrict__ st,
+                                   const double* __restrict__ acq, const double* __restrict__ y,
+                                   const double* __restrict__ sig, gpry_cand* __restrict__ out, int64_t cap,
+                                   unsigned long long* counters /*[0]=n_out, [1]=max key below*/) {
+    SelState s = *st;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long best_below = 0ull;
+    for (; i < M; i += stride) {
+        unsigned long long k = keys[i];
+        if (k == 0ull) continue;
+        bool ge = (k > s.hi) || (k == s.hi && (unsigned)i >= s.lo);
+        if (ge) {
+            unsigned long long pos = atomicAdd(&counters[0], 1ull);
+            if ((int64_t)pos < cap) { gpry_cand c; c.acq = acq[i]; c.y = y[i]; c.sigma = sig[i]; c.idx = i; out[pos] = c; }
+        } else if (k > best_below) best_below = k;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(best_below, off);
+        if (o > best_below) best_below = o;
+    }
+    if ((threadIdx.x & 63) == 0 && best_below) atomicMax(&counters[1], best_below);
+}
+
+static double key_to_acq(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    double a; memcpy(&a, &b, 8); return a;
+}
+
+extern "C" int gpry_sweep_topk(gpry_ctx* ctx, int64_t Kp, const int64_t* exclude, int64_t n_exclude,
+                               gpry_cand* top, int64_t* n_out, double* bound) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t M = ctx->sw_M;
+    if (M <= 0 || !ctx->dacq_all) return gpry_fail(ctx, -1, "topk: no sweep results resident");
+    if (M > 0xFFFFFFFFll) return gpry_fail(ctx, -1, "topk: M too large");
+    StageScope scope(ctx, "topk");
+    hipStream_t st = ctx->stream;
+    if (M > ctx->keys_cap) {
+        if (ctx->dkeys) GPRY_TRY(dev_free(ctx, ctx->dkeys));
+        GPRY_TRY(dev_alloc(ctx, &ctx->dkeys, round_up(M, 1024)));
+        ctx->keys_cap = round_up(M, 1024);
+    }
+    if (!ctx->dhist) { GPRY_TRY(dev_alloc(ctx, &ctx->dhist, 256)); }
+    if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64));
+    int64_t n_valid = M - (n_exclude > 0 ? n_exclude : 0);
+    if (n_valid < 0) n_valid = 0;
+    int64_t K = Kp < n_valid ? Kp : n_valid;
+    if (K > ctx->cand_cap) {
+        if (ctx->dcand) GPRY_TRY(dev_free(ctx, ctx->dcand));
+        GPRY_TRY(dev_alloc(ctx, &ctx->dcand, round_up(K, 1024)));
+        ctx->cand_cap = round_up(K, 1024);
+    }
+    unsigned nb = (unsigned)((M + 255) / 256);
+    hipLaunchKernelGGL(make_keys_kernel, dim3(nb), dim3(256), 0, st, ctx->dacq_all, M, ctx->dkeys);
+    int64_t* dex = nullptr;
+    if (n_exclude > 0) {
+        GPRY_TRY(dev_alloc(ctx, &dex, n_exclude));
+        HIP_TRY(ctx, hipMemcpyAsync(dex, exclude, sizeof(int64_t) * n_exclude, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(exclude_keys_kernel, dim3((unsigned)((n_exclude + 255) / 256)), dim3(256), 0, st,
+                           ctx->dkeys, dex, n_exclude, M);
+    }
+    *n_out = 0; *bound = -INFINITY;
+    if (K <= 0) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (dex) GPRY_TRY(dev_free(ctx, dex));
+        return 0;
+    }
+    SelState s0; memset(&s0, 0, sizeof(s0)); s0.k_rem = (unsigned long long)K;
+    SelState* dst = reinterpret_cast<SelState*>(ctx->dsel);          // 32 bytes
+    unsigned long long* dcnt = ctx->dsel + 4;                         // 2 counters after the state
+    HIP_TRY(ctx, hipMemcpyAsync(dst, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, 16, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dhist, 0, 256 * sizeof(unsigned int), st));
+    unsigned nbs = nb < 2048 ? nb : 2048;
+    for (int pass = 0; pass < 12; pass++) {
+        hipLaunchKernelGGL(select_hist_kernel, dim3(nbs), dim3(256), 0, st, ctx->dkeys, M, dst, pass, ctx->dhist);
+        hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(64), 0, st, ctx->dhist, dst, pass);
+    }
+    hipLaunchKernelGGL(select_emit_kernel, dim3(nbs), dim3(256), 0, st, ctx->dkeys, M, dst, ctx->dacq_all,
+                       ctx->dy_all, ctx->dsig_all, ctx->dcand, K, dcnt);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long cnt[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(cnt, dcnt, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (dex) GPRY_TRY(dev_free(ctx, dex));
+    if ((int64_t)cnt[0] != K)
+        return gpry_fail(ctx, -4, "topk: selected %llu candidates, expected %lld", cnt[0], (long long)K);
+    HIP_TRY(ctx, hipMemcpy(top, ctx->dcand, sizeof(gpry_cand) * K, hipMemcpyDeviceToHost));
+    // total order (acq desc, idx desc); NaN first as np.argsort(acq)[::-1] would put it
+    std::sort(top, top + K, [](const gpry_cand& a, const gpry_cand& b) {
+        unsigned long long ka, kb; double x = a.acq, y = b.acq;
+        memcpy(&ka, &x, 8); memcpy(&kb, &y, 8);
+        ka = (ka >> 63) ? ~ka : (ka | 0x8000000000000000ull);
+        kb = (kb >> 63) ? ~kb : (kb | 0x8000000000000000ull);
+        if (ka != kb) return ka > kb;
+        return a.idx > b.idx;
+    });
+    *n_out = K;
+    *bound = cnt[1] ? key_to_acq(cnt[1]) : -INFINITY;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Kriging-believer session
+__global__ void scale_rows_kernel(const double* __restrict__ X, int64_t m, int d, int dpad, int has_aff,
+                                  const double* __restrict__ lo, const double* __restrict__ span,
+                                  const double* __restrict__ ls, double* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * dpad) return;
+    int64_t i = idx / dpad; int k = (int)(idx - i * dpad);
+    double v = 0.0;
+    if (k < d) {
+        v = X[i * d + k];
+        if (has_aff) v = (v - lo[k]) / span[k];
+        v = v / ls[k];
+    }
+    out[idx] = v;
+}
+// one wave per row x: out_dot[x] = U[x].U[p] ; out_k[x] = C k(|xs_x - xs_p|)
+__device__ __forceinline__ double kb_corr(int kid, double r2) {
+    switch (kid) {
+        case GPRY_RBF: return exp(-0.5 * r2);
+        case GPRY_MATERN12: return exp(-sqrt(r2));
+        case GPRY_MATERN32: { double t = sqrt(r2) * 1.7320508075688772; return (1.0 + t) * exp(-t); }
+        default: { double t = sqrt(r2) * 2.23606797749979; return (1.0 + t + t * t / 3.0) * exp(-t); }
+    }
+}
+__global__ __launch_bounds__(256) void kb_gram_kernel(const double* __restrict__ U, int64_t ldu, int64_t n, int64_t p,
+                                                      int64_t Np, const double* __restrict__ Xkb, int dpad,
+                                                      int kid, double C, double* __restrict__ out_dot,
+                                                      double* __restrict__ out_k) {
+    const int lane = threadIdx.x & 63;
+    const int64_t x = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (x >= n) return;
+    const double* ux = U + x * ldu; const double* up = U + p * ldu;
+    double s = 0.0;
+    for (int64_t i = lane; i < Np; i += 64) s = fma(ux[i], up[i], s);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        out_dot[x] = s;
+        double r2 = 0.0;
+        for (int k = 0; k < dpad; k++) { double df = Xkb[x * dpad + k] - Xkb[p * dpad + k]; r2 = fma(df, df, r2); }
+        out_k[x] = C * kb_corr(kid, r2);
+    }
+}
+__global__ __launch_bounds__(256) void kb_var0_kernel(const double* __restrict__ U, int64_t ldu, int64_t first,
+                                                      int64_t m, int64_t Np, double C, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t x = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (x >= m) return;
+    const double* ux = U + (first + x) * ldu;
+    double s = 0.0;
+    for (int64_t i = lane; i < Np; i += 64) s = fma(ux[i], ux[i], s);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[x] = C - s;
+}
+
+extern "C" {
+
+int gpry_kb_reset(gpry_ctx* ctx) {
+    GPRY_TRY(require_model(ctx, true));
+    ctx->kb_n = 0;
+    return 0;
+}
+
+int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, double* var0) {
+    GPRY_TRY(require_model(ctx, true));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (m <= 0) { if (first) *first = ctx->kb_n; return 0; }
+    hipStream_t st = ctx->stream;
+    const int64_t Np = ctx->Np;
+    int64_t need = ctx->kb_n + round_up(m, 128);
+    if (need > ctx->kb_cap) {
+        int64_t cap = std::max<int64_t>(need, std::max<int64_t>(1024, 2 * ctx->kb_cap));
+        double *nU = nullptr, *nX = nullptr, *nO = nullptr;
+        GPRY_TRY(dev_alloc(ctx, &nU, cap * Np));
+        GPRY_TRY(dev_alloc(ctx, &nX, cap * ctx->dpad));
+        GPRY_TRY(dev_alloc(ctx, &nO, 2 * cap));
+        if (ctx->kb_n > 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(nU, ctx->dU, sizeof(double) * ctx->kb_n * Np, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(nX, ctx->dXkb, sizeof(double) * ctx->kb_n * ctx->dpad, hipMemcpyDeviceToDevice, st));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (ctx->dU) GPRY_TRY(dev_free(ctx, ctx->dU));
+        if (ctx->dXkb) GPRY_TRY(dev_free(ctx, ctx->dXkb));
+        if (ctx->dkbout) GPRY_TRY(dev_free(ctx, ctx->dkbout));
+        ctx->dU = nU; ctx->dXkb = nX; ctx->dkbout = nO; ctx->kb_cap = cap;
+    }
+    const int64_t mp = round_up(m, 128);
+    // stage the candidates, build their cross-kernel panel, then U^T = K*  V^T
+    double *dX = nullptr, *dpar = nullptr;
+    GPRY_TRY(dev_alloc(ctx, &dX, m * ctx->d));
+    GPRY_TRY(dev_alloc(ctx, &dpar, 3 * GPRY_MAX_DIM));
+    HIP_TRY(ctx, hipMemcpyAsync(dX, X, sizeof(double) * m * ctx->d, hipMemcpyHostToDevice, st));
+    double hpar[3 * GPRY_MAX_DIM];
+    for (int k = 0; k < GPRY_MAX_DIM; k++) {
+        hpar[k] = k < ctx->d ? ctx->tf.x_lo[k] : 0.0;
+        hpar[GPRY_MAX_DIM + k] = k < ctx->d ? ctx->tf.x_span[k] : 1.0;
+        hpar[2 * GPRY_MAX_DIM + k] = k < ctx->d ? exp(ctx->theta[1 + k]) : 1.0;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(dpar, hpar, sizeof(hpar), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((m * ctx->dpad + 255) / 256)), dim3(256), 0, st, dX, m,
+                       ctx->d, ctx->dpad, ctx->tf.has_x_affine, dpar, dpar + GPRY_MAX_DIM, dpar + 2 * GPRY_MAX_DIM,
+                       ctx->dXkb + ctx->kb_n * ctx->dpad);
+    if (Np * mp > ctx->kst_cap) {
+        if (ctx->dKst) GPRY_TRY(dev_free(ctx, ctx->dKst));
+        ctx->dKst = nullptr; ctx->kst_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dKst, Np * mp));
+        ctx->kst_cap = Np * mp;
+    }
+    int64_t saveM = ctx->sw_M; ctx->sw_M = m;
+    int rc = launch_cross_build(ctx, dX, 0, mp, mp, ctx->dKst, nullptr, 1);
+    ctx->sw_M = saveM;
+    if (rc) return rc;
+    GemmArgs g = {};
+    g.A = ctx->dKst; g.lda = mp;          // A(x, k) = Kst[k][x]
+    g.B = ctx->dV; g.ldb = Np;            // B(k, i) = V[i][k]
+    g.C = ctx->dU + ctx->kb_n * Np; g.ldc = Np;
+    g.M = (int)mp; g.N = (int)Np; g.K = (int)Np;
+    g.kmode = KM_B_UPPER; g.lower_only = 0; g.tile_map = TM_ROWMAJOR;
+    GPRY_TRY(gemm_f64_launch(ctx, g, true, true, EPI_STORE));
+    if (var0) {
+        hipLaunchKernelGGL(kb_var0_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, ctx->dU, Np, ctx->kb_n, m,
+                           Np, exp(ctx->theta[0]), ctx->dkbout);
+        HIP_TRY(ctx, hipMemcpyAsync(var0, ctx->dkbout, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    GPRY_TRY(dev_free(ctx, dX)); GPRY_TRY(dev_free(ctx, dpar));
+    if (first) *first = ctx->kb_n;
+    ctx->kb_n += m;
+    return 0;
+}
+
+int gpry_kb_gram(gpry_ctx* ctx, int64_t p, double* G, double* kvec, int64_t* n) {
+    GPRY_TRY(require_model(ctx, true));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (p < 0 || p >= ctx->kb_n) return gpry_fail(ctx, -1, "kb_gram: index %lld out of range [0, %lld)", (long long)p, (long long)ctx->kb_n);
+    hipStream_t st = ctx->stream;
+    int64_t nn = ctx->kb_n;
+    hipLaunchKernelGGL(kb_gram_kernel, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, st, ctx->dU, ctx->Np, nn, p,
+                       ctx->Np, ctx->dXkb, ctx->dpad, ctx->kernel_id, exp(ctx->theta[0]), ctx->dkbout,
+                       ctx->dkbout + ctx->kb_cap);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(G, ctx->dkbout, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(kvec, ctx->dkbout + ctx->kb_cap, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (n) *n = nn;
+    return 0;
+}
+
+}  // extern "C"
+
+extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, double* C, int M, int N,
+                               int K, int a_trans, int b_trans, int epi, int kmode, int lower_only,
+                               int tile_map) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (M % 64 || N % 64 || K % 64) return gpry_fail(ctx, -1, "debug_gemm: dims must be multiples of 64");
+    int64_t crow = (epi == EPI_SUMSQ) ? (M + 127) / 128 : M;
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    GPRY_TRY(dev_alloc(ctx, &dA, (int64_t)M * K));
+    GPRY_TRY(dev_alloc(ctx, &dB, (int64_t)K * N));
+    GPRY_TRY(dev_alloc(ctx, &dC, crow * N));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(dA, A, sizeof(double) * M * K, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dB, B, sizeof(double) * K * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dC, C, sizeof(double) * crow * N, hipMemcpyHostToDevice, st));
+    GemmArgs g = {};
+    g.A = dA; g.lda = a_trans ? M : K;
+    g.B = dB; g.ldb = b_trans ? K : N;
+    g.C = dC; g.ldc = N;
+    g.M = M; g.N = N; g.K = K; g.kmode = kmode; g.lower_only = lower_only; g.tile_map = tile_map;
+    GPRY_TRY(gemm_f64_launch(ctx, g, a_trans != 0, b_trans != 0, epi));
+    HIP_TRY(ctx, hipMemcpyAsync(C, dC, sizeof(double) * crow * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    GPRY_TRY(dev_free(ctx, dA)); GPRY_TRY(dev_free(ctx, dB)); GPRY_TRY(dev_free(ctx, dC));
+    return 0;
+}

@@ -1,0 +1,388 @@
+// Dense FP64 factorisation kernels for gfx950 (row-major, lower triangular):
+//   potrf_lower : A = L L^T          scipy.linalg.cholesky  at gpry/gpr.py:1456
+//   trtri_lower : V = L^-1           solve_triangular(L, I) at gpry/gpr.py:1457
+//   lauum_lower : K^-1 = V^T V       cho_solve(L, I)        at sklearn:_gpr.py:640-642
+//   solve_alpha : alpha_ = V^T (V y) cho_solve(L, y)        at gpry/gpr.py:1465
+// The O(N^3) parts run on the FP64 MFMA GEMM (gemm_f64.hip); the 64x64 diagonal work
+// runs in LDS / registers.  Matrices are padded to a multiple of 128 with an identity
+// block, so no kernel needs edge handling.
+#include "common.h"
+#include <dlfcn.h>
+
+// ------------------------------------------------------------------------------------
+// 64x64 diagonal block Cholesky in LDS (unblocked right-looking, 256 threads).
+__global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, int64_t ld,
+                                                       int64_t j0, int64_t n_real, int* info) {
+    __shared__ double S[64][65];
+    if (*info != 0) return;
+    const int t = threadIdx.x;
+    double* base = A + j0 * ld + j0;
+    for (int e = t; e < 64 * 64; e += 256) {
+        int i = e >> 6, j = e & 63;
+        S[i][j] = (j <= i) ? base[(int64_t)i * ld + j] : 0.0;
+    }
+    __syncthreads();
+    __shared__ int bad;
+    if (t == 0) bad = 0;
+    for (int j = 0; j < 64; j++) {
+        __syncthreads();
+        double djj = S[j][j];
+        // LAPACK dpotf2: fail on ajj <= 0 or NaN
+        if (!(djj > 0.0)) {
+            if (t == 0) { bad = 1; if (j0 + j < n_real) atomicCAS(info, 0, (int)(j0 + j + 1)); else atomicCAS(info, 0, (int)n_real); }
+            break;
+        }
+        double piv = sqrt(djj);
+        __syncthreads();
+        if (t == 0) S[j][j] = piv;
+        if (t > j && t < 64) S[t][j] = S[t][j] / piv;
+        __syncthreads();
+        // trailing update of the lower triangle: rows i>j, cols j<c<=i
+        const int rem = 63 - j;
+        for (int e = t; e < rem * rem; e += 256) {
+            int ii = e / rem, cc = e - ii * rem;
+            if (cc <= ii) {
+                int i = j + 1 + ii, c = j + 1 + cc;
+                S[i][c] = fma(-S[i][j], S[c][j], S[i][c]);
+            }
+        }
+    }
+    __syncthreads();
+    if (bad) return;
+    for (int e = t; e < 64 * 64; e += 256) {
+        int i = e >> 6, j = e & 63;
+        if (j <= i) base[(int64_t)i * ld + j] = S[i][j];
+    }
+}
+
+// Panel solve X * Lkk^T = A_panel, one lane per row (row kept in registers, Lkk broadcast
+// from LDS).  Same operation as BLAS dtrsm('R','L','T','N').
+__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ A, int64_t ld,
+                                                        int64_t j0, int64_t row_begin,
+                                                        int64_t n_rows, const int* info) {
+    __shared__ double Lk[64 * 64];
+    if (*info != 0) return;
+    const int t = threadIdx.x;
+    for (int e = t; e < 64 * 64; e += 64) {
+        int i = e >> 6, j = e & 63;
+        Lk[e] = A[(j0 + i) * ld + j0 + j];
+    }
+    __syncthreads();
+    int64_t r = (int64_t)blockIdx.x * 64 + t;
+    if (r >= n_rows) return;
+    double* rowp = A + (row_begin + r) * ld + j0;
+    double a[64];
+#pragma unroll
+    for (int c = 0; c < 64; c += 2) {
+        double2 v = *reinterpret_cast<const double2*>(rowp + c);
+        a[c] = v.x; a[c + 1] = v.y;
+    }
+#pragma unroll
+    for (int c = 0; c < 64; c++) {
+        double s = a[c];
+#pragma unroll
+        for (int c2 = 0; c2 < c; c2++) s = fma(-a[c2], Lk[c * 64 + c2], s);
+        a[c] = s / Lk[c * 64 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 64; c += 2) *reinterpret_cast<double2*>(rowp + c) = make_double2(a[c], a[c + 1]);
+}
+
+int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np) {
+    const int64_t NB = 256;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, sizeof(int), st));
+    for (int64_t K0 = 0; K0 < Np; K0 += NB) {
+        int64_t nbw = (Np - K0 < NB) ? Np - K0 : NB;
+        for (int64_t j0 = K0; j0 < K0 + nbw; j0 += 64) {
+            hipLaunchKernelGGL(potf2_64_kernel, dim3(1), dim3(256), 0, st, A, Np, j0, ctx->N, ctx->dinfo);
+            int64_t below = Np - (j0 + 64);
+            if (below <= 0) continue;
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)((below + 63) / 64)), dim3(64), 0, st,
+                               A, Np, j0, j0 + 64, below, ctx->dinfo);
+            int64_t w = K0 + nbw - (j0 + 64);
+            if (w > 0) {  // update the rest of the current outer panel (K = 64)
+                GemmArgs g = {};
+                g.A = A + (j0 + 64) * Np + j0; g.lda = Np;
+                g.B = A + (j0 + 64) * Np + j0; g.ldb = Np;   // B(k, j) = P[j][k]
+                g.C = A + (j0 + 64) * Np + (j0 + 64); g.ldc = Np;
+                g.M = (int)below; g.N = (int)w; g.K = 64;
+                g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
+                GPRY_TRY(gemm_f64_launch(ctx, g, false, true, EPI_SUB));
+            }
+        }
+        int64_t rest = Np - (K0 + nbw);
+        if (rest > 0) {  // trailing SYRK with K = nbw
+            GemmArgs g = {};
+            g.A = A + (K0 + nbw) * Np + K0; g.lda = Np;
+            g.B = g.A; g.ldb = Np;
+            g.C = A + (K0 + nbw) * Np + (K0 + nbw); g.ldc = Np;
+            g.M = (int)rest; g.N = (int)rest; g.K = (int)nbw;
+            g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
+            GPRY_TRY(gemm_f64_launch(ctx, g, false, true, EPI_SUB));
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Inverse of every 64x64 diagonal block: lane c solves L x = e_c by forward substitution
+// (L broadcast from LDS, x in registers).  Writes zeros above the diagonal.
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict__ L,
+                                                        double* __restrict__ V, int64_t ld,
+                                                        const int* info) {
+    __shared__ double Lk[64 * 64];
+    if (*info != 0) return;
+    const int t = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    for (int e = t; e < 64 * 64; e += 64) {
+        int i = e >> 6, j = e & 63;
+        Lk[e] = L[(b0 + i) * ld + b0 + j];
+    }
+    __syncthreads();
+    double x[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        double s = (i == t) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) s = fma(-Lk[i * 64 + k], x[k], s);
+        x[i] = (i >= t) ? s / Lk[i * 64 + i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; i++) V[(b0 + i) * ld + b0 + t] = x[i];
+}
+
+struct TriNode { int lo, mid, hi, level; };
+static int build_tree(int lo, int hi, std::vector<TriNode>& out) {
+    if (hi - lo <= 1) return 0;
+    int mid = lo + (hi - lo + 1) / 2;
+    int l1 = build_tree(lo, mid, out), l2 = build_tree(mid, hi, out);
+    int lev = (l1 > l2 ? l1 : l2) + 1;
+    out.push_back({lo, mid, hi, lev});
+    return lev;
+}
+
+// cached per-Np batch descriptors of the trtri recursion
+struct TrtriPlan {
+    int64_t Np = 0;
+    std::vector<GemmBatchItem*> d_t, d_v;   // per level
+    std::vector<int> count, maxM, maxN;
+};
+static std::map<gpry_ctx*, TrtriPlan> g_plans;
+
+void trtri_plan_free(gpry_ctx* ctx) {
+    auto it = g_plans.find(ctx);
+    if (it == g_plans.end()) return;
+    for (auto p : it->second.d_t) if (p) (void)hipFree(p);
+    for (auto p : it->second.d_v) if (p) (void)hipFree(p);
+    g_plans.erase(it);
+}
+
+static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
+    TrtriPlan& pl = g_plans[ctx];
+    if (pl.Np == Np) { *out = &pl; return 0; }
+    for (auto p : pl.d_t) if (p) (void)hipFree(p);
+    for (auto p : pl.d_v) if (p) (void)hipFree(p);
+    pl = TrtriPlan();
+    pl.Np = Np;
+    std::vector<TriNode> nodes;
+    int nlev = build_tree(0, (int)(Np / 64), nodes);
+    for (int lev = 1; lev <= nlev; lev++) {
+        std::vector<GemmBatchItem> bt, bv;
+        int mM = 0, mN = 0;
+        for (auto& nd : nodes) {
+            if (nd.level != lev) continue;
+            int64_t lo = nd.lo * 64, mid = nd.mid * 64, hi = nd.hi * 64;
+            int m = (int)(hi - mid), n = (int)(mid - lo);
+            GemmBatchItem a;  // T[mid:hi, lo:mid] = L[mid:hi, lo:mid] * V[lo:mid, lo:mid]
+            a.a_off = mid * Np + lo; a.b_off = lo * Np + lo; a.c_off = mid * Np + lo;
+            a.M = m; a.N = n; a.K = n; a.pad = 0;
+            bt.push_back(a);
+            GemmBatchItem b;  // V[mid:hi, lo:mid] = -V[mid:hi, mid:hi] * T[mid:hi, lo:mid]
+            b.a_off = mid * Np + mid; b.b_off = mid * Np + lo; b.c_off = mid * Np + lo;
+            b.M = m; b.N = n; b.K = m; b.pad = 0;
+            bv.push_back(b);
+            if (m > mM) mM = m;
+            if (n > mN) mN = n;
+        }
+        GemmBatchItem *dt = nullptr, *dv = nullptr;
+        size_t bytes = bt.size() * sizeof(GemmBatchItem);
+        HIP_TRY(ctx, hipMalloc(&dt, bytes));
+        HIP_TRY(ctx, hipMalloc(&dv, bytes));
+        HIP_TRY(ctx, hipMemcpy(dt, bt.data(), bytes, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dv, bv.data(), bytes, hipMemcpyHostToDevice));
+        pl.d_t.push_back(dt); pl.d_v.push_back(dv);
+        pl.count.push_back((int)bt.size()); pl.maxM.push_back(mM); pl.maxN.push_back(mN);
+    }
+    *out = &pl;
+    return 0;
+}
+
+// V = L^-1 by recursive doubling: [[L11,0],[L21,L22]]^-1 = [[V11,0],[-V22 L21 V11, V22]];
+// every level is two batched MFMA GEMMs.  T is an Np x Np scratch.
+int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np) {
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(V, 0, sizeof(double) * Np * Np, st));
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)(Np / 64)), dim3(64), 0, st, L, V, Np, ctx->dinfo);
+    HIP_TRY(ctx, hipGetLastError());
+    TrtriPlan* pl = nullptr;
+    GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
+    for (size_t lev = 0; lev < pl->count.size(); lev++) {
+        GemmArgs g = {};
+        g.A = L; g.lda = Np; g.B = V; g.ldb = Np; g.C = T; g.ldc = Np;
+        g.M = pl->maxM[lev]; g.N = pl->maxN[lev]; g.K = 0;
+        g.kmode = KM_B_LOWER; g.lower_only = 0; g.tile_map = TM_ROWMAJOR;
+        g.batch = pl->d_t[lev]; g.n_batch = pl->count[lev]; g.info = ctx->dinfo;
+        GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_STORE));
+        GemmArgs h = {};
+        h.A = V; h.lda = Np; h.B = T; h.ldb = Np; h.C = V; h.ldc = Np;
+        h.M = pl->maxM[lev]; h.N = pl->maxN[lev]; h.K = 0;
+        h.kmode = KM_A_LOWER; h.lower_only = 0; h.tile_map = TM_ROWMAJOR;
+        h.batch = pl->d_v[lev]; h.n_batch = pl->count[lev]; h.info = ctx->dinfo;
+        GPRY_TRY(gemm_f64_launch(ctx, h, false, false, EPI_STORE_NEG));
+    }
+    return 0;
+}
+
+// K^-1 = V^T V, lower triangle only (the traces kernel reads Kinv[max(i,j)][min(i,j)]).
+int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
+    GemmArgs g = {};
+    g.A = V; g.lda = Np; g.B = V; g.ldb = Np; g.C = Kinv; g.ldc = Np;
+    g.M = (int)Np; g.N = (int)Np; g.K = (int)Np;
+    g.kmode = KM_AT_LOWER_B_LOWER; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
+    return gemm_f64_launch(ctx, g, true, false, EPI_STORE);
+}
+
+// ------------------------------------------------------------------------------------
+// z = V y : one wave per row (row-contiguous, coalesced), fixed reduction tree.
+__global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ V, int64_t ld,
+                                                         const double* __restrict__ y,
+                                                         double* __restrict__ z, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    double s = 0.0;
+    for (int64_t k = lane; k <= row; k += 64) s = fma(V[row * ld + k], y[k], s);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) z[row] = s;
+}
+// partial column sums of V^T z over 256-row chunks: part[chunk][col]
+__global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restrict__ V, int64_t ld,
+                                                           const double* __restrict__ z,
+                                                           double* __restrict__ part, int64_t n) {
+    __shared__ double red[4][64];
+    const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * 256;
+    double s = 0.0;
+    if (r0 + 255 >= (int64_t)blockIdx.x * 64) {
+        for (int q = 0; q < 64; q++) {
+            int64_t r = r0 + rq + 4 * q;
+            if (r >= col && r < n) s = fma(V[r * ld + col], z[r], s);
+        }
+    }
+    red[rq][c] = s;
+    __syncthreads();
+    if (rq == 0) part[(int64_t)blockIdx.y * n + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+__global__ void colsum_kernel(const double* __restrict__ part, int64_t n, int nchunk, double* __restrict__ out) {
+    int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n) return;
+    double s = 0.0;
+    for (int ch = 0; ch < nchunk; ch++) s += part[(int64_t)ch * n + col];
+    out[col] = s;
+}
+
+int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha, int64_t Np) {
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, V, Np, y, z, Np);
+    int nchunk = (int)((Np + 255) / 256);
+    int64_t need = (int64_t)nchunk * Np;
+    if (need > ctx->part_cap) {
+        if (ctx->dpart) dev_free(ctx, ctx->dpart);
+        GPRY_TRY(dev_alloc(ctx, &ctx->dpart, need));
+        ctx->part_cap = need;
+    }
+    hipLaunchKernelGGL(trmv_lower_t_kernel, dim3((unsigned)(Np / 64), (unsigned)nchunk), dim3(256), 0, st,
+                       V, Np, z, ctx->dpart, Np);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, ctx->dpart, Np,
+                       nchunk, alpha);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// out[0] = sum_i log L_ii (i < n_real), out[1] = sum_i z_i^2   (single workgroup)
+__global__ __launch_bounds__(1024) void logdet_quad_kernel(const double* __restrict__ L, int64_t ld,
+                                                           const double* __restrict__ z,
+                                                           int64_t n_real, double* __restrict__ out) {
+    __shared__ double r0[1024], r1[1024];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int64_t i = t; i < n_real; i += 1024) { a += log(L[i * ld + i]); b = fma(z[i], z[i], b); }
+    r0[t] = a; r1[t] = b;
+    __syncthreads();
+    for (int s = 512; s >= 1; s >>= 1) {
+        if (t < s) { r0[t] += r0[t + s]; r1[t] += r1[t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) { out[0] = r0[0]; out[1] = r1[0]; }
+}
+
+int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np, double* out2_dev) {
+    (void)Np;
+    hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(1024), 0, ctx->stream, L, ctx->Np, z, ctx->N, out2_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// rocSOLVER comparator (option "chol"=1), loaded lazily so the default path has no
+// dependency on rocBLAS/rocSOLVER.  Row-major lower == column-major upper.
+typedef void* rb_handle;
+static struct {
+    bool tried = false, ok = false;
+    void *lib_blas = nullptr, *lib_solver = nullptr;
+    int (*create)(rb_handle*) = nullptr;
+    int (*set_stream)(rb_handle, hipStream_t) = nullptr;
+    int (*dpotrf)(rb_handle, int, int, double*, int, int*) = nullptr;
+    int (*dtrtri)(rb_handle, int, int, int, double*, int, int*) = nullptr;
+    rb_handle handle = nullptr;
+} g_rs;
+
+__global__ void zero_upper_kernel(double* A, int64_t n) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    int64_t i = idx / n, j = idx - i * n;
+    if (j > i) A[idx] = 0.0;
+}
+
+int rocsolver_potrf_trtri(gpry_ctx* ctx, double* A, double* V, int64_t Np, int want_v) {
+    if (!g_rs.tried) {
+        g_rs.tried = true;
+        g_rs.lib_blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        g_rs.lib_solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (g_rs.lib_blas && g_rs.lib_solver) {
+            g_rs.create = (int (*)(rb_handle*))dlsym(g_rs.lib_blas, "rocblas_create_handle");
+            g_rs.set_stream = (int (*)(rb_handle, hipStream_t))dlsym(g_rs.lib_blas, "rocblas_set_stream");
+            g_rs.dpotrf = (int (*)(rb_handle, int, int, double*, int, int*))dlsym(g_rs.lib_solver, "rocsolver_dpotrf");
+            g_rs.dtrtri = (int (*)(rb_handle, int, int, int, double*, int, int*))dlsym(g_rs.lib_solver, "rocsolver_dtrtri");
+            g_rs.ok = g_rs.create && g_rs.set_stream && g_rs.dpotrf && g_rs.dtrtri;
+            if (g_rs.ok && g_rs.create(&g_rs.handle) != 0) g_rs.ok = false;
+        }
+    }
+    if (!g_rs.ok) return gpry_fail(ctx, -3, "rocSOLVER comparator unavailable (dlopen/dlsym failed)");
+    g_rs.set_stream(g_rs.handle, ctx->stream);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 2 * sizeof(int), ctx->stream));
+    const int rocblas_fill_upper = 121, rocblas_diagonal_non_unit = 131;
+    if (g_rs.dpotrf(g_rs.handle, rocblas_fill_upper, (int)Np, A, (int)Np, ctx->dinfo) != 0)
+        return gpry_fail(ctx, -3, "rocsolver_dpotrf failed");
+    if (want_v) {
+        HIP_TRY(ctx, hipMemcpyAsync(V, A, sizeof(double) * Np * Np, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((Np * Np + 255) / 256)), dim3(256), 0, ctx->stream, V, Np);
+        if (g_rs.dtrtri(g_rs.handle, rocblas_fill_upper, rocblas_diagonal_non_unit, (int)Np, V, (int)Np, ctx->dinfo + 1) != 0)
+            return gpry_fail(ctx, -3, "rocsolver_dtrtri failed");
+    }
+    return 0;
+}

@@ -1,0 +1,163 @@
+// Internal definitions shared by the gfx950 kernels behind include/gpry_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/gpry_hip.h"
+
+#define GPRY_TILE 128       // GEMM workgroup tile and padding quantum of N
+#define GPRY_NB 64          // Cholesky / trtri base block
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct StageTimer {
+    double total_ms = 0.0;
+    int64_t count = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct gpry_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[1024] = {0};
+
+    // options
+    int opt_chol = 0;
+    int64_t opt_sweep_chunk = 32768;
+    int opt_timing = 1;
+
+    // training set (transformed space)
+    int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
+    int d = 0, dpad = 0;
+    int kernel_id = GPRY_RBF;
+    bool have_theta = false, factor_valid = false;
+    double theta[1 + GPRY_MAX_DIM] = {0};
+    gpry_affine tf;
+
+    double* dX = nullptr;      // N x d raw transformed training rows (row-major, ld = d)
+    double* dXs = nullptr;     // Np x dpad rows scaled by 1/l (pad rows = 0)
+    double* dy = nullptr;      // Np
+    double* dnoise = nullptr;  // Np (alpha = noise_^2; pad = 0)
+    double* dA = nullptr;      // Np x Np : K then L (factor used for prediction)
+    double* dV = nullptr;      // Np x Np : V = L^-1 (upper triangle exactly zero)
+    double* dW = nullptr;      // Np x Np : scratch (lml: K/L ; T ; K^-1)
+    double* dW2 = nullptr;     // Np x Np : scratch (lml: V)
+    double* dW3 = nullptr;     // Np x Np : scratch (lml: T, then K^-1)
+    double* dalpha_ = nullptr; // Np
+    double* dvec = nullptr;    // small vectors / reductions (8 * Np + 4096 doubles)
+    int* dinfo = nullptr;      // device status word(s)
+    double* dparams = nullptr; // device copy of [C, 1/l..., lo..., span...] etc.
+
+    // sweep state
+    int64_t sw_M = 0, sw_cap = 0;
+    double* dXc = nullptr;     // M x d candidates (raw as given)
+    uint8_t* dmask = nullptr;  // M
+    double *dy_all = nullptr, *dsig_all = nullptr, *dacq_all = nullptr;  // M each
+    double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
+    int64_t kst_cap = 0;       // doubles allocated
+    double* dpart = nullptr;   // partial sums (sumsq per i-tile, mean per j-chunk)
+    int64_t part_cap = 0;
+    // top-k scratch
+    unsigned long long* dkeys = nullptr; int64_t keys_cap = 0;
+    unsigned int* dhist = nullptr;
+    gpry_cand* dcand = nullptr; int64_t cand_cap = 0;
+    unsigned long long* dsel = nullptr;  // select state
+
+    // Kriging-believer session
+    int64_t kb_n = 0, kb_cap = 0;
+    double* dU = nullptr;      // kb_cap x Np : row x = u(x)^T   (x-major, contiguous u)
+    double* dXkb = nullptr;    // kb_cap x dpad scaled candidate rows
+    double* dkbout = nullptr;  // 2 * kb_cap
+
+    // host pinned staging
+    void* hpin = nullptr; int64_t hpin_cap = 0;
+
+    std::map<std::string, StageTimer> timers;
+};
+
+extern char g_last_error[1024];
+
+int gpry_fail(gpry_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                          \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess)                                                       \
+            return gpry_fail(ctx, -2, "%s failed: %s (%s:%d)", #expr,               \
+                             hipGetErrorString(_e), __FILE__, __LINE__);            \
+    } while (0)
+
+#define GPRY_TRY(expr)                 \
+    do {                               \
+        int _r = (expr);               \
+        if (_r != 0) return _r;        \
+    } while (0)
+
+// scoped device timing of one stage on ctx->stream
+struct StageScope {
+    gpry_ctx* ctx; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr;
+    StageScope(gpry_ctx* c, const char* n);
+    ~StageScope();
+};
+void timers_collect(gpry_ctx* ctx);
+
+template <typename T>
+int dev_alloc(gpry_ctx* ctx, T** p, int64_t count);
+int dev_free(gpry_ctx* ctx, void* p);
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ---- GEMM (gemm_f64.hip) -----------------------------------------------------------
+enum GemmKMode {
+    KM_FULL = 0,      // k in [0, K)
+    KM_A_LOWER = 1,   // A lower triangular (rows i, cols k): k < (ti+1)*TILE
+    KM_B_LOWER = 2,   // B lower triangular (rows k, cols j): k >= tj*TILE
+    KM_AT_LOWER_B_LOWER = 3, // C = A^T B with A, B lower: k >= max(ti, tj)*TILE
+    KM_B_UPPER = 4    // B upper triangular (rows k, cols j): k < (tj+1)*TILE
+};
+enum GemmEpi { EPI_STORE = 0, EPI_STORE_NEG = 1, EPI_SUB = 2, EPI_SUMSQ = 3 };
+enum GemmTileMap { TM_ROWMAJOR = 0, TM_SWEEP = 1 };
+
+struct GemmBatchItem { int64_t a_off, b_off, c_off; int M, N, K, pad; };
+
+struct GemmArgs {
+    const double* A; const double* B; double* C;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    int kmode;
+    int lower_only;        // skip output tiles with tj > ti
+    int tile_map;
+    const GemmBatchItem* batch;  // nullable; grid.z = n_batch
+    int n_batch;
+    const int* info;       // nullable: if *info != 0 the kernel exits immediately
+};
+// a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
+int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
+
+// ---- kernel_build.hip --------------------------------------------------------------
+int upload_params(gpry_ctx* ctx, const double* theta);
+int launch_scale_train(gpry_ctx* ctx);                         // dXs from dX and theta
+int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise); // full symmetric K
+int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
+                       int64_t ldk, double* Kst, double* mean_part, int raw_affine);
+int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
+                      double* grad_out_dev);
+
+// ---- chol.hip ----------------------------------------------------------------------
+int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np);             // info -> ctx->dinfo
+int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
+int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np);
+int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha,
+                int64_t Np);
+int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np,
+                    double* out2_dev);
+int rocsolver_potrf_trtri(gpry_ctx* ctx, double* A, double* V, int64_t Np, int want_v);
+
+int ensure_capacity(gpry_ctx* ctx, int64_t N, int d);
+int ensure_pinned(gpry_ctx* ctx, int64_t bytes);

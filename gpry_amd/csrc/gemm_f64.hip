@@ -1,0 +1,245 @@
+// FP64 MFMA GEMM for gfx950 (v_mfma_f64_16x16x4_f64), the contraction engine behind
+//   - the NORA sweep  M = V * K*^T   (gpry/gpr.py:1204 dtrmm + :1208 einsum, fused)
+//   - Cholesky trailing updates, V = L^-1 recursion, K^-1 = V^T V  (gpry/gpr.py:1456-1457,
+//     sklearn:_gpr.py:640-642)
+//
+// Workgroup: 256 threads = 4 waves (64 lanes) in a 2x2 arrangement, each wave owns a
+// 64x64 block of the 128x128 output tile as 4x4 MFMA tiles (16 accumulators of 4 f64).
+// K is consumed in slabs of 16 staged global -> registers -> LDS, double buffered, one
+// barrier per slab.  LDS images are padded so that every ds_read_b64 fragment read is
+// bank-conflict free (strides 18 and 144 doubles).
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define SKC 18    // row stride (doubles) of a K-contiguous tile image   [128][18]
+#define SMC 144   // row stride (doubles) of an MN-contiguous tile image [16][144]
+#define TILE_DOUBLES 2304  // 128*18 == 16*144
+
+struct TileCoord { int ti, tj, valid; };
+
+__device__ __forceinline__ TileCoord map_tile(const GemmArgs& g, int tiles_m, int tiles_n) {
+    TileCoord t;
+    int b = blockIdx.x;
+    if (g.tile_map == TM_SWEEP) {
+        // XCD-aware super-tiles: blocks b, b+8, b+16.. share an XCD (round-robin
+        // dispatch); give each XCD 64 consecutive slots = one 8x8 super-tile so that the
+        // V row-panels and K* column-panels of a super-tile are served by that XCD's L2.
+        // Super-tiles are ordered by descending row index (longest k-range first).
+        int nsi = (tiles_m + 7) >> 3, nsj = (tiles_n + 7) >> 3;
+        int xcd = b & 7, q = b >> 3;
+        int s = (q >> 6) * 8 + xcd;
+        int within = q & 63;
+        if (s >= nsi * nsj) { t.valid = 0; t.ti = t.tj = 0; return t; }
+        int si = nsi - 1 - s / nsj, sj = s % nsj;
+        t.ti = si * 8 + (within >> 3);
+        t.tj = sj * 8 + (within & 7);
+    } else {
+        t.ti = b / tiles_n;
+        t.tj = b - t.ti * tiles_n;
+    }
+    t.valid = (t.ti < tiles_m && t.tj < tiles_n);
+    if (g.lower_only && t.tj > t.ti) t.valid = 0;
+    return t;
+}
+
+// Stage loaders.  KC: operand stored with k contiguous, 128 rows x 16 k per slab.
+//                 MC: operand stored with m/n contiguous, 16 k-rows x 128 per slab.
+__device__ __forceinline__ void load_kc(const double* __restrict__ P, int64_t ld, int row0,
+                                        int rows, int k0, double (&r)[8]) {
+    int t = threadIdx.x;
+    int row = row0 + (t >> 1);
+    if (row < rows) {
+        const double2* p = reinterpret_cast<const double2*>(P + (int64_t)row * ld + k0 + (t & 1) * 8);
+        double2 a = p[0], b = p[1], c = p[2], d = p[3];
+        r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+        r[4] = c.x; r[5] = c.y; r[6] = d.x; r[7] = d.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[i] = 0.0;
+    }
+}
+__device__ __forceinline__ void store_kc(double* lds, const double (&r)[8]) {
+    int t = threadIdx.x;
+    double2* p = reinterpret_cast<double2*>(lds + (t >> 1) * SKC + (t & 1) * 8);
+    p[0] = make_double2(r[0], r[1]); p[1] = make_double2(r[2], r[3]);
+    p[2] = make_double2(r[4], r[5]); p[3] = make_double2(r[6], r[7]);
+}
+__device__ __forceinline__ void load_mc(const double* __restrict__ P, int64_t ld, int col0,
+                                        int cols, int k0, double (&r)[8]) {
+    int t = threadIdx.x;
+    int col = col0 + (t & 15) * 8;
+    if (col < cols) {
+        const double2* p = reinterpret_cast<const double2*>(P + (int64_t)(k0 + (t >> 4)) * ld + col);
+        double2 a = p[0], b = p[1], c = p[2], d = p[3];
+        r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+        r[4] = c.x; r[5] = c.y; r[6] = d.x; r[7] = d.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[i] = 0.0;
+    }
+}
+__device__ __forceinline__ void store_mc(double* lds, const double (&r)[8]) {
+    int t = threadIdx.x;
+    double2* p = reinterpret_cast<double2*>(lds + (t >> 4) * SMC + (t & 15) * 8);
+    p[0] = make_double2(r[0], r[1]); p[1] = make_double2(r[2], r[3]);
+    p[2] = make_double2(r[4], r[5]); p[3] = make_double2(r[6], r[7]);
+}
+
+template <bool AT, bool BT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double smem[4 * TILE_DOUBLES];
+    if (g.info != nullptr && *g.info != 0) return;
+
+    const double* A = g.A; const double* B = g.B; double* C = g.C;
+    int M = g.M, N = g.N, K = g.K;
+    if (g.batch != nullptr) {
+        GemmBatchItem it = g.batch[blockIdx.z];
+        A += it.a_off; B += it.b_off; C += it.c_off;
+        M = it.M; N = it.N; K = it.K;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    TileCoord tc = map_tile(g, tiles_m, tiles_n);
+    if (!tc.valid) return;
+    const int row0 = tc.ti * BM, col0 = tc.tj * BN;
+
+    int kbeg = 0, kend = K;
+    if (g.kmode == KM_A_LOWER) kend = min(K, row0 + BM);
+    else if (g.kmode == KM_B_LOWER) kbeg = min(K, col0);
+    else if (g.kmode == KM_AT_LOWER_B_LOWER) kbeg = min(K, max(row0, col0));
+    else if (g.kmode == KM_B_UPPER) kend = min(K, col0 + BN);
+    const int nslab = (kend - kbeg + BK - 1) / BK;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 15, gq = lane >> 4;
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    double ra[8], rb[8];
+    auto load_slab = [&](int s) {
+        int k0 = kbeg + s * BK;
+        if (AT) load_mc(A, g.lda, row0, M, k0, ra); else load_kc(A, g.lda, row0, M, k0, ra);
+        if (BT) load_kc(B, g.ldb, col0, N, k0, rb); else load_mc(B, g.ldb, col0, N, k0, rb);
+    };
+    auto store_slab = [&](int buf) {
+        double* As = smem + buf * 2 * TILE_DOUBLES;
+        double* Bs = As + TILE_DOUBLES;
+        if (AT) store_mc(As, ra); else store_kc(As, ra);
+        if (BT) store_kc(Bs, rb); else store_mc(Bs, rb);
+    };
+
+    if (nslab > 0) {
+        load_slab(0);
+        store_slab(0);
+    }
+    __syncthreads();
+
+    for (int s = 0; s < nslab; s++) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) load_slab(s + 1);
+        const double* As = smem + buf * 2 * TILE_DOUBLES;
+        const double* Bs = As + TILE_DOUBLES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; kk++) {
+            double a[4], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+                a[mi] = AT ? As[(kk * 4 + gq) * SMC + wr * 64 + mi * 16 + r]
+                           : As[(wr * 64 + mi * 16 + r) * SKC + kk * 4 + gq];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+                b[ni] = BT ? Bs[(wc * 64 + ni * 16 + r) * SKC + kk * 4 + gq]
+                           : Bs[(kk * 4 + gq) * SMC + wc * 64 + ni * 16 + r];
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (s + 1 < nslab) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4*reg.
+    if (EPI == EPI_SUMSQ) {
+        // column sums of squares over the 128 rows of this tile -> C[ti*ldc + col]
+        double cs[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) {
+            double s = 0.0;
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) s = fma(acc[mi][ni][q], acc[mi][ni][q], s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            cs[ni] = s;
+        }
+        double* red = smem;  // all slab reads are behind the loop's final barrier
+        if (gq == 0) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) red[wr * 128 + wc * 64 + ni * 16 + r] = cs[ni];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            int col = col0 + threadIdx.x;
+            if (col < N) C[(int64_t)tc.ti * g.ldc + col] = red[threadIdx.x] + red[128 + threadIdx.x];
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int row = row0 + wr * 64 + mi * 16 + gq + 4 * q;
+                int col = col0 + wc * 64 + ni * 16 + r;
+                if (row < M && col < N) {
+                    double* p = C + (int64_t)row * g.ldc + col;
+                    double v = acc[mi][ni][q];
+                    if (EPI == EPI_STORE) *p = v;
+                    else if (EPI == EPI_STORE_NEG) *p = -v;
+                    else *p = *p - v;
+                }
+            }
+}
+
+template <bool AT, bool BT>
+static int launch_epi(gpry_ctx* ctx, const GemmArgs& g, int epi, dim3 grid) {
+    hipStream_t st = ctx->stream;
+    switch (epi) {
+        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_STORE>), grid, dim3(256), 0, st, g); break;
+        case EPI_STORE_NEG: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_STORE_NEG>), grid, dim3(256), 0, st, g); break;
+        case EPI_SUB: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_SUB>), grid, dim3(256), 0, st, g); break;
+        case EPI_SUMSQ: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_SUMSQ>), grid, dim3(256), 0, st, g); break;
+        default: return gpry_fail(ctx, -1, "gemm: bad epilogue %d", epi);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi) {
+    int M = g.M, N = g.N;
+    if (g.batch == nullptr && (M <= 0 || N <= 0)) return 0;
+    int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    int64_t nblk;
+    if (g.tile_map == TM_SWEEP) {
+        int64_t nsi = (tiles_m + 7) / 8, nsj = (tiles_n + 7) / 8;
+        int64_t ns = (nsi * nsj + 7) / 8 * 8;
+        nblk = ns * 64;
+    } else {
+        nblk = (int64_t)tiles_m * tiles_n;
+    }
+    dim3 grid((unsigned)nblk, 1, g.batch ? (unsigned)g.n_batch : 1u);
+    if (!a_trans && !b_trans) return launch_epi<false, false>(ctx, g, epi, grid);
+    if (!a_trans && b_trans) return launch_epi<false, true>(ctx, g, epi, grid);
+    if (a_trans && !b_trans) return launch_epi<true, false>(ctx, g, epi, grid);
+    return launch_epi<true, true>(ctx, g, epi, grid);
+}

@@ -1,0 +1,375 @@
+// Covariance-matrix kernels for gfx950:
+//   * train kernel build  K = C k(r) (+ diag noise)       gpry/gpr.py:1015-1016
+//   * cross-kernel panel  K*^T (k-major) + mean partials   gpry/gpr.py:1179-1180
+//   * LML gradient traces 1/2 tr((aa^T - K^-1) dK/dtheta)  sklearn:_gpr.py:625-649
+// Kernel algebra restated from sklearn:kernels.py:1553-1580 (RBF), :1708-1768 (Matern),
+// :1239-1291 (Constant), :931-966 (Product).
+#include "common.h"
+
+struct KernParams {
+    double C;
+    int kernel_id, d, dpad, has_aff;
+    int64_t N;
+};
+struct AffParams {
+    double inv_l[GPRY_MAX_DIM];   // unused slots = 0
+    double lo[GPRY_MAX_DIM];
+    double span[GPRY_MAX_DIM];
+};
+
+__device__ __forceinline__ double corr_r2(int kid, double r2) {
+    switch (kid) {
+        case GPRY_RBF: return exp(-0.5 * r2);
+        case GPRY_MATERN12: return exp(-sqrt(r2));
+        case GPRY_MATERN32: { double t = sqrt(r2) * 1.7320508075688772; return (1.0 + t) * exp(-t); }
+        default: { double t = sqrt(r2) * 2.23606797749979; return (1.0 + t + t * t / 3.0) * exp(-t); }
+    }
+}
+// returns k(r) in *kval and h with d k / d log l_k = h * D_k   (both without the factor C)
+__device__ __forceinline__ double corr_and_h(int kid, double r2, double* kval) {
+    switch (kid) {
+        case GPRY_RBF: { double e = exp(-0.5 * r2); *kval = e; return e; }
+        case GPRY_MATERN12: {
+            double r = sqrt(r2); double e = exp(-r); *kval = e;
+            return r != 0.0 ? e / r : 0.0;
+        }
+        case GPRY_MATERN32: {
+            double t = sqrt(r2) * 1.7320508075688772; double e = exp(-t);
+            *kval = (1.0 + t) * e;
+            return 3.0 * exp(-sqrt(3.0 * r2));
+        }
+        default: {
+            double t = sqrt(r2) * 2.23606797749979; double e = exp(-t);
+            *kval = (1.0 + t + t * t / 3.0) * e;
+            double t2 = sqrt(5.0 * r2);
+            return 5.0 / 3.0 * (t2 + 1.0) * exp(-t2);
+        }
+    }
+}
+
+static KernParams make_kp(gpry_ctx* ctx) {
+    KernParams kp;
+    kp.C = exp(ctx->theta[0]);
+    kp.kernel_id = ctx->kernel_id; kp.d = ctx->d; kp.dpad = ctx->dpad;
+    kp.has_aff = ctx->tf.has_x_affine; kp.N = ctx->N;
+    return kp;
+}
+static AffParams make_ap(gpry_ctx* ctx, bool use_affine) {
+    AffParams ap;
+    for (int k = 0; k < GPRY_MAX_DIM; k++) {
+        // sklearn divides by the length scale: x / l.  Keep the division (not a
+        // reciprocal multiply) so scaled coordinates round identically.
+        ap.inv_l[k] = k < ctx->d ? exp(ctx->theta[1 + k]) : 1.0;
+        ap.lo[k] = (use_affine && k < ctx->d) ? ctx->tf.x_lo[k] : 0.0;
+        ap.span[k] = (use_affine && k < ctx->d) ? ctx->tf.x_span[k] : 1.0;
+    }
+    return ap;
+}
+
+// ------------------------------------------------------------------------------------
+__global__ void scale_train_kernel(const double* __restrict__ X, double* __restrict__ Xs,
+                                   int64_t N, int64_t Np, int d, int dpad, AffParams ap) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Np * dpad) return;
+    int64_t i = idx / dpad; int k = (int)(idx - i * dpad);
+    double v = 0.0;
+    if (i < N && k < d) v = X[i * d + k] / ap.inv_l[k];
+    Xs[idx] = v;
+}
+
+int launch_scale_train(gpry_ctx* ctx) {
+    AffParams ap = make_ap(ctx, false);
+    int64_t n = ctx->Np * ctx->dpad;
+    hipLaunchKernelGGL(scale_train_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, ctx->dX, ctx->dXs, ctx->N, ctx->Np, ctx->d, ctx->dpad, ap);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// decode linear index -> (bi >= bj) lower-triangular block pair
+__device__ __forceinline__ void tri_decode(int64_t t, int* bi, int* bj) {
+    int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(i + 1) * (i + 2) / 2 <= t) i++;
+    while ((int64_t)i * (i + 1) / 2 > t) i--;
+    *bi = i; *bj = (int)(t - (int64_t)i * (i + 1) / 2);
+}
+
+// One 64x64 tile of K per workgroup (lower block triangle); each thread owns a 4x4
+// patch.  Off-diagonal tiles are mirrored through an LDS transpose so that both the
+// (bi,bj) and (bj,bi) images are written as full 512-byte row segments.
+__global__ __launch_bounds__(256) void kernel_train_kernel(
+    const double* __restrict__ Xs, const double* __restrict__ noise, double* __restrict__ K,
+    int64_t ld, KernParams kp, int add_noise) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int dp = kp.dpad;
+    double* Xi = sm;             // [dp][64]
+    double* Xj = sm + dp * 64;   // [dp][64]
+    int bi, bj; tri_decode(blockIdx.x, &bi, &bj);
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    for (int e = t; e < 64 * dp; e += 256) {
+        int row = e / dp, k = e - row * dp;
+        Xi[k * 64 + row] = Xs[((int64_t)bi * 64 + row) * dp + k];
+        Xj[k * 64 + row] = Xs[((int64_t)bj * 64 + row) * dp + k];
+    }
+    __syncthreads();
+    double r2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) r2[a][b] = 0.0;
+    for (int k = 0; k < dp; k++) {
+        double xi[4], xj[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { xi[a] = Xi[k * 64 + ty * 4 + a]; xj[a] = Xj[k * 64 + tx * 4 + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) { double df = xi[a] - xj[b]; r2[a][b] = fma(df, df, r2[a][b]); }
+    }
+    double val[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int64_t i = (int64_t)bi * 64 + ty * 4 + a, j = (int64_t)bj * 64 + tx * 4 + b;
+            double v;
+            if (i < kp.N && j < kp.N) {
+                v = kp.C * (i == j ? 1.0 : corr_r2(kp.kernel_id, r2[a][b]));
+                if (i == j && add_noise) v += noise[i];
+            } else {
+                v = (i == j) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
+            }
+            val[a][b] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        int64_t i = (int64_t)bi * 64 + ty * 4 + a;
+        double2* p = reinterpret_cast<double2*>(K + i * ld + (int64_t)bj * 64 + tx * 4);
+        p[0] = make_double2(val[a][0], val[a][1]);
+        p[1] = make_double2(val[a][2], val[a][3]);
+    }
+    if (bi == bj) return;
+    __syncthreads();            // X tiles no longer needed: reuse LDS as a [64][65] transpose pad
+    double* T = sm;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) T[(tx * 4 + b) * 65 + ty * 4 + a] = val[a][b];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        int jr = ty * 4 + a;   // row of the mirrored tile (a column index j of K)
+        double* p = K + ((int64_t)bj * 64 + jr) * ld + (int64_t)bi * 64 + tx * 4;
+#pragma unroll
+        for (int b = 0; b < 4; b++) p[b] = T[jr * 65 + tx * 4 + b];
+    }
+}
+
+int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
+    KernParams kp = make_kp(ctx);
+    int64_t nb = ctx->Np / 64;
+    int64_t ntile = nb * (nb + 1) / 2;
+    size_t smem = sizeof(double) * (size_t)((2 * ctx->dpad * 64 > 64 * 65) ? 2 * ctx->dpad * 64 : 64 * 65);
+    hipLaunchKernelGGL(kernel_train_kernel, dim3((unsigned)ntile), dim3(256), smem, ctx->stream,
+                       ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Cross-kernel panel.  Thread <-> candidate (coalesced stores along m); a workgroup
+// covers 256 candidates x 128 training rows; scaled candidate coordinates stay in
+// registers, the training chunk sits in LDS and is read wave-uniformly (broadcast).
+// Output Kst[j*ldk + m] = C k(x*_m, x_j) (rows j >= N are zero) and the per-chunk mean
+// partial  mean_part[jc*mc + m] = sum_{j in chunk} alpha_[j] * Kst[j][m].
+template <int DP>
+__global__ __launch_bounds__(256) void cross_build_kernel(
+    const double* __restrict__ Xc, int64_t M, int64_t m0, int64_t mc,
+    const double* __restrict__ Xs, const double* __restrict__ alpha_,
+    double* __restrict__ Kst, int64_t ldk, double* __restrict__ mean_part,
+    KernParams kp, AffParams ap) {
+    __shared__ double Xl[128 * DP];
+    __shared__ double al[128];
+    const int t = threadIdx.x;
+    const int64_t ml = (int64_t)blockIdx.x * 256 + t;   // local candidate index in the chunk
+    const int64_t m = m0 + ml;
+    const int jc = blockIdx.y;
+    for (int e = t; e < 128 * DP; e += 256) {
+        int row = e / DP, k = e - row * DP;
+        Xl[e] = (k < kp.dpad) ? Xs[((int64_t)jc * 128 + row) * kp.dpad + k] : 0.0;
+    }
+    if (t < 128) al[t] = alpha_ ? alpha_[jc * 128 + t] : 0.0;
+    double xs[DP];
+#pragma unroll
+    for (int k = 0; k < DP; k++) {
+        double v = 0.0;
+        if (k < kp.d && m < M) {
+            v = Xc[m * kp.d + k];
+            if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
+            v = v / ap.inv_l[k];
+        }
+        xs[k] = v;
+    }
+    __syncthreads();
+    double macc = 0.0;
+    const bool in_chunk = ml < mc;
+    for (int j0 = 0; j0 < 128; j0 += 4) {
+        double r2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < DP; k++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                double df = xs[k] - Xl[(j0 + q) * DP + k];
+                r2[q] = fma(df, df, r2[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int64_t j = (int64_t)jc * 128 + j0 + q;
+            double v = (j < kp.N) ? kp.C * corr_r2(kp.kernel_id, r2[q]) : 0.0;
+            macc = fma(al[j0 + q], v, macc);
+            if (in_chunk) Kst[j * ldk + ml] = v;
+        }
+    }
+    if (in_chunk && mean_part) mean_part[(int64_t)jc * mc + ml] = macc;
+}
+
+int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk,
+                       double* Kst, double* mean_part, int raw_affine) {
+    KernParams kp = make_kp(ctx);
+    kp.has_aff = raw_affine && ctx->tf.has_x_affine;
+    AffParams ap = make_ap(ctx, kp.has_aff);
+    dim3 grid((unsigned)((mc + 255) / 256), (unsigned)(ctx->Np / 128));
+    int64_t M = ctx->sw_M;
+#define CB(DP) hipLaunchKernelGGL((cross_build_kernel<DP>), grid, dim3(256), 0, ctx->stream, Xc, M, m0, mc, \
+                                  ctx->dXs, ctx->dalpha_, Kst, ldk, mean_part, kp, ap)
+    if (ctx->d <= 4) CB(4);
+    else if (ctx->d <= 8) CB(8);
+    else if (ctx->d <= 16) CB(16);
+    else if (ctx->d <= 32) CB(32);
+    else return gpry_fail(ctx, -1, "d > 32 is not supported");
+#undef CB
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// LML gradient traces.  One 64x64 tile of pairs per workgroup (lower block triangle,
+// off-diagonal tiles weighted twice).  W_ij = a_i a_j - Kinv_ij is read once (Kinv holds
+// the lower triangle); distances are recomputed from the scaled coordinates, so the
+// (N,N,d) tensor of the reference never exists.  Per-tile partial sums are written to
+// part[tile][DP+1] and reduced in a fixed order by reduce_traces_kernel (deterministic).
+template <int DP>
+__global__ __launch_bounds__(256) void lml_traces_kernel(
+    const double* __restrict__ Xs, const double* __restrict__ Kinv, int64_t ld,
+    const double* __restrict__ alpha, double* __restrict__ part, KernParams kp) {
+    __shared__ double Xi[DP * 64];
+    __shared__ double Xj[DP * 64];
+    __shared__ double ai[64], aj[64];
+    __shared__ double red[4][DP + 1];
+    int bi, bj; tri_decode(blockIdx.x, &bi, &bj);
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    for (int e = t; e < 64 * DP; e += 256) {
+        int row = e / DP, k = e - row * DP;
+        double vi = 0.0, vj = 0.0;
+        if (k < kp.dpad) {
+            vi = Xs[((int64_t)bi * 64 + row) * kp.dpad + k];
+            vj = Xs[((int64_t)bj * 64 + row) * kp.dpad + k];
+        }
+        Xi[k * 64 + row] = vi; Xj[k * 64 + row] = vj;
+    }
+    if (t < 64) { ai[t] = alpha[bi * 64 + t]; aj[t] = alpha[bj * 64 + t]; }
+    __syncthreads();
+    double g[DP + 1];
+#pragma unroll
+    for (int k = 0; k <= DP; k++) g[k] = 0.0;
+#pragma unroll 1
+    for (int a = 0; a < 4; a++) {
+        const int il = ty * 4 + a;
+        const int64_t i = (int64_t)bi * 64 + il;
+        double r2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < DP; k++) {
+            double xi = Xi[k * 64 + il];
+#pragma unroll
+            for (int b = 0; b < 4; b++) { double df = xi - Xj[k * 64 + tx * 4 + b]; r2[b] = fma(df, df, r2[b]); }
+        }
+        double wh[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int jl = tx * 4 + b;
+            const int64_t j = (int64_t)bj * 64 + jl;
+            double w = 0.0, kv = 1.0, h = 0.0;
+            if (i < kp.N && j < kp.N) {
+                int64_t hi = i > j ? i : j, lo = i > j ? j : i;
+                w = ai[il] * aj[jl] - Kinv[hi * ld + lo];
+                h = corr_and_h(kp.kernel_id, r2[b], &kv);
+                if (i == j) { kv = 1.0; }
+            }
+            g[0] = fma(w, kp.C * kv, g[0]);
+            wh[b] = w * kp.C * h;
+        }
+#pragma unroll
+        for (int k = 0; k < DP; k++) {
+            double xi = Xi[k * 64 + il];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                double df = xi - Xj[k * 64 + tx * 4 + b];
+                g[1 + k] = fma(wh[b], df * df, g[1 + k]);
+            }
+        }
+    }
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int k = 0; k <= DP; k++) {
+        double v = g[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (t <= DP) {
+        double s = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        if (bi != bj) s *= 2.0;
+        part[(int64_t)blockIdx.x * (DP + 1) + t] = s;
+    }
+}
+
+__global__ void reduce_traces_kernel(const double* __restrict__ part, int64_t ntile, int stride,
+                                     int nout, double* __restrict__ out) {
+    // one thread per hyperparameter; fixed summation order over tiles
+    int k = threadIdx.x;
+    if (k >= nout) return;
+    double s = 0.0, c = 0.0;  // Kahan: thousands of tile partials of mixed sign
+    for (int64_t t = 0; t < ntile; t++) {
+        double y = part[t * stride + k] - c;
+        double u = s + y;
+        c = (u - s) - y;
+        s = u;
+    }
+    out[k] = 0.5 * s;
+}
+
+int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, double* grad_out_dev) {
+    KernParams kp = make_kp(ctx);
+    int64_t nb = ctx->Np / 64;
+    int64_t ntile = nb * (nb + 1) / 2;
+    if (ctx->d > 32) return gpry_fail(ctx, -1, "d > 32 is not supported");
+    int DPsel = ctx->d <= 4 ? 4 : ctx->d <= 8 ? 8 : ctx->d <= 16 ? 16 : 32;
+    int64_t need = ntile * (DPsel + 1);
+    if (need > ctx->part_cap) {
+        if (ctx->dpart) dev_free(ctx, ctx->dpart);
+        GPRY_TRY(dev_alloc(ctx, &ctx->dpart, need));
+        ctx->part_cap = need;
+    }
+#define LT(DP) hipLaunchKernelGGL((lml_traces_kernel<DP>), dim3((unsigned)ntile), dim3(256), 0, ctx->stream, \
+                                  ctx->dXs, Kinv, ctx->Np, alpha, ctx->dpart, kp)
+    switch (DPsel) { case 4: LT(4); break; case 8: LT(8); break; case 16: LT(16); break;
+                     default: LT(32); }
+#undef LT
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(reduce_traces_kernel, dim3(1), dim3(128), 0, ctx->stream, ctx->dpart, ntile,
+                       DPsel + 1, ctx->d + 1, grad_out_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

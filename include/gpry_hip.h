@@ -1,0 +1,182 @@
+/*
+ * gpry_hip.h -- C ABI of libgpry_hip.so: MI355X (gfx950) GP-regression + NORA sweep.
+ *
+ * This is the drop-in boundary for GPry's hot path.  GPry is pure Python; the calls
+ * below are what a ctypes binding inside gpry/gpr.py and gpry/gp_acquisition.py would
+ * bind to replace the numpy/scipy/scikit-learn arithmetic (reference file:line cited
+ * per entry point; "sklearn:" = scikit-learn 1.7.2 sklearn/gaussian_process/).
+ *
+ * Conventions
+ *  - plain C, no C++ types, no torch types; all host arrays are caller-owned,
+ *    C-contiguous float64 / int64 / uint8; every call copies in/out synchronously and
+ *    returns after the device work has completed (stream-synchronised).
+ *  - return value: 0 ok; <0 API / HIP / RCCL error (text via gpry_last_error);
+ *    numerical status (LAPACK-style "info") is returned through an out-parameter.
+ *  - one gpry_ctx per device; a ctx is not re-entrant.
+ *  - all floating point is IEEE float64.
+ */
+#ifndef GPRY_HIP_H
+#define GPRY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpry_ctx gpry_ctx;
+typedef struct gpry_comm gpry_comm;
+
+/* kernel ids: Product(ConstantKernel, RBF | Matern(nu)) -- gpry/kernels.py:213,281,601,681 */
+enum { GPRY_RBF = 0, GPRY_MATERN12 = 1, GPRY_MATERN32 = 2, GPRY_MATERN52 = 3 };
+
+#define GPRY_MAX_DIM 64
+
+/* Affine pre-/post-processing fused into the device path.
+ * x_ = (x - x_lo) / x_span       gpry/preprocessing.py:380 (Normalize_bounds.transform)
+ * y  = y_ * y_std + y_mean       gpry/preprocessing.py:620 (Normalize_y.inverse_transform)
+ * s  = s_ * y_std                gpry/preprocessing.py:630 (inverse_transform_scale)
+ * y  = min(y, clip_hi)           gpry/gpr.py:1187-1195   (pass +inf for "no clipping") */
+typedef struct {
+    int has_x_affine;                 /* 0: X is used as given */
+    double x_lo[GPRY_MAX_DIM];
+    double x_span[GPRY_MAX_DIM];
+    double y_mean, y_std;
+    double clip_hi;
+} gpry_affine;
+
+/* One shortlisted candidate of the NORA sweep (gpry/gp_acquisition.py:1328-1333 feeds
+ * candidates to RankedPool.add_one in descending acquisition order). */
+typedef struct {
+    double acq, y, sigma;
+    int64_t idx;
+} gpry_cand;
+
+/* bit flags of the per-candidate mask consumed by predict/sweep */
+enum {
+    GPRY_MASK_CLASSIFIED_INF = 1, /* gpry/gpr.py:1145,1172,1230: mean=-inf, std=0      */
+    GPRY_MASK_OUTSIDE_TRUST = 2   /* gpry/gpr.py:1107,1201:      mean=-inf, std kept   */
+};
+
+/* ---- library / device ------------------------------------------------------------ */
+int gpry_version(void);
+int gpry_device_count(int* n);
+/* name (<=name_len), HBM bytes, CU count, max clock kHz, gcn arch string (<=arch_len) */
+int gpry_device_info(int device, char* name, int name_len, int64_t* hbm_bytes,
+                     int* n_cu, int* clock_khz, char* arch, int arch_len);
+
+int gpry_ctx_create(int device, gpry_ctx** out);
+int gpry_ctx_destroy(gpry_ctx* ctx);
+const char* gpry_last_error(gpry_ctx* ctx); /* ctx may be NULL: last global error */
+int gpry_ctx_sync(gpry_ctx* ctx);
+/* option keys: "chol" = 0 hand-written MFMA Cholesky (default), 1 rocSOLVER dpotrf/dtrtri
+ *              "sweep_chunk" = candidates per sweep chunk (default 32768) */
+int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value);
+
+/* ---- model state ------------------------------------------------------------------ */
+/* X_train_, y_train_, alpha = noise_^2 in the TRANSFORMED space, as assembled by
+ * append_to_data (gpry/gpr.py:743-747).  X_ is N x d row-major. */
+int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_,
+                   const double* alpha, int64_t N, int d);
+/* kernel_.theta = [log C, log l_1..l_d] (sklearn:kernels.py:734-747) */
+int gpry_set_theta(gpry_ctx* ctx, int kernel_id, const double* theta);
+int gpry_set_affine(gpry_ctx* ctx, const gpry_affine* tf);
+
+/* ---- a1/a2/a8: kernel matrices ---------------------------------------------------- */
+/* K = kernel_(X_train_) [+ diag(alpha)] -> host N x N.  gpry/gpr.py:1015-1016,
+ * sklearn:kernels.py:931-966,1553-1560,1708-1738. */
+int gpry_kernel_train(gpry_ctx* ctx, int add_alpha, double* K_out);
+/* K* = kernel_(Xc_, X_train_) -> host M x N (gpry/gpr.py:1179).  Xc_ already
+ * transformed; meant for tests and small M (the sweep never materialises it on host). */
+int gpry_kernel_cross(gpry_ctx* ctx, const double* Xc_, int64_t M, double* K_out);
+
+/* ---- a3/a7: factor (gpry/gpr.py:996-1020, 1453-1465) ------------------------------ */
+/* builds K+diag(alpha), L = chol(K), V = L^-1, alpha_ = K^-1 y_.
+ * *info = 0 ok, k>0: leading minor of order k is not positive definite (dpotrf). */
+int gpry_factorize(gpry_ctx* ctx, int* info);
+/* copy-out for attribute parity (L_, V_, alpha_); any pointer may be NULL */
+int gpry_get_factor(gpry_ctx* ctx, double* L, double* V, double* alpha_);
+
+/* ---- a4/a5: log marginal likelihood (+ gradient) ---------------------------------- */
+/* sklearn:_gpr.py:574-652 via gpry/gpr.py:876-881.  Non-PD: returns 0 with
+ * *lml = -inf, grad = 0, *info > 0 (sklearn:_gpr.py:586-589).  Does not disturb the
+ * factor held for prediction.  grad has 1+d entries (ignored if want_grad == 0). */
+int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml,
+             double* grad, int* info);
+
+/* ---- a8-a11: posterior mean / std (gpry/gpr.py:1022-1273, 1275-1352) -------------- */
+/* X: M x d, raw if the affine map has_x_affine else already transformed.
+ * mask (nullable): per-candidate GPRY_MASK_* bits.  mean/std in untransformed units,
+ * clipped (clip_hi) and masked exactly as predict() does.  std may be NULL. */
+int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
+                 double* mean, double* std);
+
+/* ---- a8-a13: fused NORA sweep ----------------------------------------------------- */
+/* For all M candidates: mean, std (as gpry_predict), acq = LogExp.f(mean, std,
+ * baseline, sigma_n, zeta) (gpry/acquisition_functions.py:1068-1074), kept resident on
+ * the device; y_all / sigma_all / acq_all (nullable) receive host copies.
+ * n_nan receives the number of NaN acquisition values (the reference raises on those,
+ * gpry/gp_acquisition.py:1453-1455). */
+int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
+                      double zeta, double baseline, double sigma_n,
+                      double* y_all, double* sigma_all, double* acq_all,
+                      int64_t* n_nan);
+/* Shortlist of the last sweep: the Kp candidates with the largest acq in the total
+ * order (acq desc, idx desc) -- the order of np.argsort(acq)[::-1] on distinct values
+ * (gpry/gp_acquisition.py:1328-1329).  exclude (nullable, n_exclude sorted indices):
+ * rows dropped as "already proposed" (gpry/gp_acquisition.py:1037-1047).
+ * *n_out <= Kp records written, sorted; *bound = largest acq NOT returned (-inf if
+ * none): every candidate outside the shortlist has acq <= *bound. */
+int gpry_sweep_topk(gpry_ctx* ctx, int64_t Kp, const int64_t* exclude, int64_t n_exclude,
+                    gpry_cand* top, int64_t* n_out, double* bound);
+
+/* ---- a14/a15: Kriging-believer support (bordered factor instead of deepcopy+refit) - */
+/* Start a session on the current factor; drops any registered candidates. */
+int gpry_kb_reset(gpry_ctx* ctx);
+/* Register m candidates (X: m x d, raw/transformed as in gpry_predict): computes and
+ * keeps u(x) = V k*(x).  They get session indices [*first, *first + m).  var0 (nullable)
+ * receives C - |u|^2 (transformed units, unclamped). */
+int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first,
+                     double* var0);
+/* For registered candidate p: G[x] = u(p).u(x) and kvec[x] = kernel_(x_p, x) for every
+ * registered x (n = number registered so far; both arrays length n). */
+int gpry_kb_gram(gpry_ctx* ctx, int64_t p, double* G, double* kvec, int64_t* n);
+
+/* ---- a16: multi-GPU (one process per GPU, RCCL over xGMI) -------------------------- */
+/* 128-byte RCCL unique id, made on rank 0 and distributed by the caller. */
+int gpry_comm_unique_id(uint8_t id[128]);
+int gpry_comm_init(gpry_ctx* ctx, int world, int rank, const uint8_t id[128],
+                   gpry_comm** out);
+int gpry_comm_destroy(gpry_comm* comm);
+/* all-gather of `bytes` host bytes per rank (staged through device buffers, RCCL) */
+int gpry_comm_allgather(gpry_comm* comm, const void* send, int64_t bytes, void* recv);
+/* all-reduce(max) of n doubles */
+int gpry_comm_allreduce_max(gpry_comm* comm, double* inout, int64_t n);
+int gpry_comm_barrier(gpry_comm* comm);
+
+/* ---- measurement ------------------------------------------------------------------ */
+/* Device-side timing of the last call's stages in milliseconds (HIP events on the
+ * ctx stream).  Known names: "kernel_build", "potrf", "trtri", "lauum", "lml_traces",
+ * "cross_build", "sweep_gemm", "sweep_finish", "topk".  Returns <0 if unknown.
+ * *count = launches accumulated since gpry_timing_reset. */
+int gpry_timing_reset(gpry_ctx* ctx);
+int gpry_timing_get(gpry_ctx* ctx, const char* name, double* total_ms, int64_t* count);
+/* Raw micro-benchmarks used by bench.py to quote measured peaks beside the spec:
+ * kind 0: f64 MFMA 16x16x4 issue loop -> *value = TFLOP/s
+ * kind 1: HBM streaming copy of `bytes` -> *value = GB/s (read+write bytes / time) */
+int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* value);
+
+/* ---- testing hook ------------------------------------------------------------------- */
+/* Runs the FP64 MFMA GEMM engine on host matrices (unit test of the fragment layout).
+ * C(MxN) op= A(MxK) B(KxN); a_trans: A given as K x M; b_trans: B given as N x K;
+ * epi 0 store, 1 store -AB, 2 C -= AB, 3 per-128-row-tile column sums of squares
+ * (C is then ceil(M/128) x N); kmode 0 full (see csrc/common.h for the others).
+ * M, N, K must be multiples of 64. */
+int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, double* C, int M, int N,
+                    int K, int a_trans, int b_trans, int epi, int kmode, int lower_only,
+                    int tile_map);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPRY_HIP_H */
