@@ -300,6 +300,19 @@ static int upload_candidates(gpry_ctx* ctx, const double* X, int64_t M, const ui
     return 0;
 }
 
+// gpry_predict works on its own candidate set: swap it in for the duration of the call
+struct PredictSetGuard {
+    gpry_ctx* c;
+    explicit PredictSetGuard(gpry_ctx* ctx) : c(ctx) { swap(); }
+    ~PredictSetGuard() { swap(); }
+    void swap() {
+        std::swap(c->sw_M, c->pr.M); std::swap(c->sw_cap, c->pr.cap);
+        std::swap(c->dXc, c->pr.dXc); std::swap(c->dmask, c->pr.dmask);
+        std::swap(c->dy_all, c->pr.dy); std::swap(c->dsig_all, c->pr.dsig);
+        std::swap(c->dacq_all, c->pr.dacq);
+    }
+};
+
 __global__ void count_nan_kernel(const double* __restrict__ a, int64_t n, unsigned long long* out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -316,6 +329,7 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return 0;
     if (!X) return gpry_fail(ctx, -1, "predict: X is NULL");
+    PredictSetGuard guard(ctx);
     GPRY_TRY(upload_candidates(ctx, X, M, mask));
     GPRY_TRY(run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0));
     HIP_TRY(ctx, hipMemcpyAsync(mean, ctx->dy_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));

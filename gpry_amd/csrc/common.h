@@ -59,6 +59,12 @@ struct gpry_ctx {
     double* dXc = nullptr;     // M x d candidates (raw as given)
     uint8_t* dmask = nullptr;  // M
     double *dy_all = nullptr, *dsig_all = nullptr, *dacq_all = nullptr;  // M each
+    // second candidate set, used by gpry_predict so that the resident NORA pool survives
+    struct CandSet {
+        int64_t M = 0, cap = 0;
+        double* dXc = nullptr; uint8_t* dmask = nullptr;
+        double *dy = nullptr, *dsig = nullptr, *dacq = nullptr;
+    } pr;
     double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
     int64_t kst_cap = 0;       // doubles allocated
     double* dpart = nullptr;   // partial sums (sumsq per i-tile, mean per j-chunk)

@@ -152,7 +152,8 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
     void* bufs[] = {ctx->dX, ctx->dXs, ctx->dy, ctx->dnoise, ctx->dA, ctx->dV, ctx->dW, ctx->dW2, ctx->dW3,
                     ctx->dalpha_, ctx->dvec, ctx->dinfo, ctx->dparams, ctx->dXc, ctx->dmask, ctx->dy_all,
                     ctx->dsig_all, ctx->dacq_all, ctx->dKst, ctx->dpart, ctx->dkeys, ctx->dhist,
-                    ctx->dcand, ctx->dsel, ctx->dU, ctx->dXkb, ctx->dkbout};
+                    ctx->dcand, ctx->dsel, ctx->dU, ctx->dXkb, ctx->dkbout, ctx->pr.dXc, ctx->pr.dmask,
+                    ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     (void)hipStreamDestroy(ctx->stream);

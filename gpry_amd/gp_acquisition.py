@@ -1,0 +1,572 @@
+"""NORA batch acquisition on the device sweep, with GPry's interface.
+
+Host mirror of ``gpry/gp_acquisition.py``: ``GenericGPAcquisition`` (:38), ``NORA``
+(:525, ``multi_add`` :971-1108) and ``RankedPool`` (:1194-1670).  What changes is where
+the work happens:
+
+* the evaluation of (mean, std, acquisition) on the whole candidate pool -- in the
+  reference ``mpi.compute_y_parallel`` -> ``gpr.predict`` (gpry/mpi.py:182-218) and
+  ``LogExp.f`` on host arrays -- is one fused device sweep (``gpry_sweep_logexp``);
+* the descending-acquisition stream that ``RankedPool.add`` walks (:1328-1333) is
+  produced by an exact device top-k (``gpry_sweep_topk``); the walk stops at the
+  reference's own early-out (:1432), and the shortlist is extended until every
+  candidate outside it provably hits that early-out, so the pool equals the one the
+  reference computes from the full sorted stream;
+* conditioned models come from ``gpry_amd.kriging`` (bordered factor) instead of
+  ``deepcopy`` + refit;
+* with several ranks (one process per GPU) each rank sweeps a contiguous shard and the
+  per-rank shortlists are merged after one all-gather (RCCL), replacing the gathers of
+  per-rank pools (:1148-1191).
+"""
+import inspect
+import sys
+import warnings
+from collections.abc import Mapping
+from copy import deepcopy
+from functools import partial
+from time import time
+
+import numpy as np
+
+import gpry_amd.acquisition_functions as gpryacqfuncs
+from gpry_amd.tools import get_Xnumber, get_random_generator, is_in_bounds, remove_0_weight_samples
+
+try:
+    from sklearn.base import is_regressor
+except Exception:  # pragma: no cover
+    def is_regressor(obj):
+        return hasattr(obj, "predict")
+
+
+def builtin_names():
+    return [name for name, obj in inspect.getmembers(sys.modules[__name__])
+            if inspect.isclass(obj) and issubclass(obj, GenericGPAcquisition)
+            and obj is not GenericGPAcquisition]
+
+
+class NestedSamplerNotInstalledError(Exception):
+    """The requested external nested sampler is not importable."""
+
+
+class GenericGPAcquisition:
+    """Acquisition engine base: resolves the acquisition function (gp_acquisition.py:41-82)."""
+
+    def __init__(self, bounds, preprocessing_X=None, verbose=1, acq_func="LogExp"):
+        self.bounds_ = np.array(bounds).copy()
+        self.n_d = self.bounds_.shape[0]
+        self.preprocessing_X = preprocessing_X
+        self.verbose = verbose
+        if gpryacqfuncs.is_acquisition_function(acq_func):
+            self.acq_func = acq_func
+        elif isinstance(acq_func, (Mapping, str)):
+            spec = {acq_func: {}} if isinstance(acq_func, str) else dict(acq_func)
+            name = list(spec)[0]
+            args = dict(spec[name] or {})
+            args["dimension"] = self.n_d
+            try:
+                cls = getattr(gpryacqfuncs, name)
+            except AttributeError as excpt:
+                raise ValueError(f"Unknown AcquisitionFunction class {name}. Available: "
+                                 f"{gpryacqfuncs.builtin_names()}") from excpt
+            try:
+                self.acq_func = cls(**args)
+            except Exception as excpt:
+                raise ValueError("Error when initialising the AcquisitionFunction object "
+                                 f"{name} with arguments {args}: {excpt}") from excpt
+        else:
+            raise TypeError("acq_func should be an AcquisitionFunction or a str or dict "
+                            f"specification. Got {acq_func}")
+
+    def __call__(self, X, gpr, eval_gradient=False):
+        return self.acq_func(X, gpr, eval_gradient=eval_gradient)
+
+
+class NORA(GenericGPAcquisition):
+    """Nested-sampling Optimisation for Ranked Acquisition, device sweep edition.
+
+    Constructor arguments as gpry/gp_acquisition.py:584-601.  The external nested
+    samplers (PolyChord / UltraNest / nessai) only *produce* the candidate set and are not
+    part of this package: use ``sampler="uniform"``, or override ``do_MC_sample`` to
+    inject a pool ``(X, None, None, weights)``.  ``comm`` (optional) is a communicator with
+    ``world``, ``rank`` and ``allgather(ndarray)`` (``gpry_amd._lib.RcclComm``) to shard the
+    sweep over several GPUs.
+    """
+
+    def __init__(self, bounds, preprocessing_X=None, verbose=1, acq_func="LogExp", sampler=None,
+                 mc_every="1d", nlive_per_training=3, nlive_max="25d", nlive_per_dim_max=None,
+                 num_repeats="5d", num_repeats_per_dim=None, precision_criterion_target=0.01,
+                 nprior_per_nlive=10, max_ncalls=None, tmpdir=None, comm=None,
+                 shortlist_size=None):
+        super().__init__(bounds=np.asarray(bounds), preprocessing_X=preprocessing_X,
+                         verbose=verbose, acq_func=acq_func)
+        self.log_header = f"[ACQUISITION : {self.__class__.__name__}] "
+        self.mc_every = get_Xnumber(mc_every, "d", self.n_d, int, "mc_every")
+        self.mc_every_i = 0
+        self.tmpdir = tmpdir
+        self.i = 0
+        self.acq_func_y_sigma = None
+        self.sampler = sampler
+        self._init_nested_sampler()
+        self.nlive_per_training = nlive_per_training
+        self.nlive_max = (nlive_per_dim_max * self.n_d if nlive_per_dim_max is not None else
+                          get_Xnumber(nlive_max, "d", self.n_d, int, "nlive_max"))
+        self.num_repeats = (num_repeats_per_dim * self.n_d if num_repeats_per_dim is not None else
+                            get_Xnumber(num_repeats, "d", self.n_d, int, "num_repeats"))
+        self.precision_criterion_target = precision_criterion_target
+        self.nprior_per_nlive = nprior_per_nlive
+        self.max_ncalls = max_ncalls
+        self._X_mc = self._y_mc = self._sigma_y_mc = self._w_mc = None
+        self._X_mc_reweight = self._y_mc_reweight = None
+        self._sigma_y_mc_reweight = self._w_mc_reweight = None
+        self.is_last_MC_reweighted = None
+        self.pool = None
+        self.comm = comm
+        self.shortlist_size = shortlist_size
+        self._X_already_proposed = np.empty((0, self.n_d))
+        self.stats = {}
+
+    # -- bookkeeping identical in meaning to the reference --------------------------------
+    @property
+    def pool_size(self):
+        return None if self.pool is None else len(self.pool)
+
+    def _init_nested_sampler(self):
+        s = self.sampler
+        if s is None:
+            s = "uniform"   # no external sampler ships with this package
+        if s.lower() not in ("uniform",):
+            raise NestedSamplerNotInstalledError(
+                f"Nested sampler '{s}' is an external package outside this hot-path package; "
+                "pass sampler='uniform' or override do_MC_sample to inject the candidate pool.")
+        self.sampler = s
+
+    def update_NS_precision(self, gpr):
+        nlive = min(self.nlive_per_training * gpr.n, self.nlive_max)
+        return {"nlive": nlive, "num_repeats": self.num_repeats,
+                "precision_criterion": self.precision_criterion_target,
+                "nprior": int(self.nprior_per_nlive * nlive), "max_ncalls": self.max_ncalls}
+
+    def log(self, msg, level=None):
+        if level is None or level <= self.verbose:
+            print(self.log_header + msg)
+
+    def do_MC_sample(self, gpr, bounds, rng=None, sampler=None):
+        """Returns ``(X, y, sigma_y, weights)``; any of the last three may be None."""
+        sampler = sampler or self.sampler
+        if sampler.lower() == "uniform":
+            return self._do_MC_sample_uniform(gpr, bounds=bounds, rng=rng)
+        raise ValueError(f"Sampler '{sampler}' not known.")
+
+    def _do_MC_sample_uniform(self, gpr, bounds=None, rng=None):
+        """1000 d points drawn one at a time, as gp_acquisition.py:750-758 does."""
+        b = self.bounds_ if bounds is None else bounds
+        rng = get_random_generator(rng)
+        n_total = 1000 * gpr.d
+        X = np.empty((n_total, gpr.d))
+        for i in range(n_total):
+            X[i] = rng.uniform(b[:, 0], b[:, 1])
+        return X, None, None, None
+
+    # -- the sweep -----------------------------------------------------------------------------
+    def _shard(self, M):
+        if self.comm is None or self.comm.world == 1:
+            return 0, M
+        w, r = self.comm.world, self.comm.rank
+        per = -(-M // w)
+        return min(r * per, M), min((r + 1) * per, M)
+
+    def _device_sweep(self, gpr, X):
+        """Mean, std and LogExp acquisition of every row of X (this rank's shard on the
+        device; y and sigma all-gathered so that every rank holds the full arrays)."""
+        t0 = time()
+        X = np.ascontiguousarray(X, dtype=float)
+        M = len(X)
+        lo, hi = self._shard(M)
+        gpr._ensure_factor()
+        gpr._push_affine()
+        mask = gpr._masks(X[lo:hi], False, False) if hi > lo else None
+        noise = gpr.noise_level
+        if np.iterable(noise):
+            raise ValueError("NORA needs a scalar noise_level (the reference passes it raw to "
+                             "LogExp.f, gp_acquisition.py:1049-1051)")
+        # the very same array object as last time is still resident in HBM: skip the upload
+        resident = (X is getattr(self, "_sweep_X", None) and getattr(self, "_sweep_dev", None) is gpr.device
+                    and (lo, hi) == (self._sweep_lo, self._sweep_hi))
+        out = gpr.device.sweep_logexp(None if resident else X[lo:hi], self.acq_func.zeta, gpr.y_max,
+                                      noise, mask=mask, M=hi - lo, want=("y", "sigma"))
+        self._sweep_dev = gpr.device
+        gpr.n_eval += M
+        if out["n_nan"]:
+            raise ValueError("Acquisition function value not a number: nan")
+        y, s = out["y"], out["sigma"]
+        if self.comm is not None and self.comm.world > 1:
+            per = -(-M // self.comm.world)
+            buf = np.zeros((2, per))
+            buf[0, :hi - lo], buf[1, :hi - lo] = y, s
+            allb = self.comm.allgather(buf)
+            y = np.concatenate([allb[r, 0, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
+            s = np.concatenate([allb[r, 1, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
+        self._sweep_X, self._sweep_lo, self._sweep_hi = X, lo, hi
+        self.stats["sweep_s"] = time() - t0
+        self.stats["sweep_M"] = M
+        return y, s
+
+    def _shortlist(self, gpr, K, exclude_global):
+        """Global descending stream prefix: records (acq, y, sigma, idx) valid down to
+        ``bound`` (every candidate not returned has acq <= bound)."""
+        lo, hi = self._sweep_lo, self._sweep_hi
+        excl = None
+        if exclude_global is not None and len(exclude_global):
+            e = np.asarray(exclude_global, dtype=np.int64)
+            excl = e[(e >= lo) & (e < hi)] - lo
+        top, bound = gpr.device.sweep_topk(K, exclude=excl)
+        top = top.copy()
+        top["idx"] += lo
+        if self.comm is None or self.comm.world == 1:
+            return top, bound, len(top) < K
+        from gpry_amd._lib import CAND_DTYPE
+        rec = np.zeros(K + 1, dtype=CAND_DTYPE)
+        rec[:len(top)] = top
+        rec[len(top):]["idx"] = -1
+        rec[K]["acq"], rec[K]["idx"] = bound, len(top)   # trailer: this rank's bound and count
+        allr = self.comm.allgather(rec)
+        parts, gbound, exhausted = [], -np.inf, True
+        for r in range(self.comm.world):
+            n_r = int(allr[r][K]["idx"])
+            parts.append(allr[r][:n_r])
+            gbound = max(gbound, float(allr[r][K]["acq"]))
+            exhausted = exhausted and n_r < K
+        merged = np.concatenate(parts)
+        order = np.lexsort((-merged["idx"], -merged["acq"]))
+        merged = merged[order]
+        # entries at or below the largest per-rank bound may be preceded by candidates that a
+        # rank did not send: hold them back
+        valid = merged["acq"] > gbound
+        if exhausted:
+            valid[:] = True
+        return merged[valid], (gbound if not exhausted else -np.inf), exhausted
+
+    def _set_MC_sample(self, X, y, sigma_y, w, ensure_y_sigma_y=False, gpr=None):
+        """gp_acquisition.py:858-873; the (y, sigma) evaluation is the device sweep."""
+        self.is_last_MC_reweighted = False
+        self._X_mc, self._y_mc, self._sigma_y_mc, self._w_mc = X, y, sigma_y, w
+        if ensure_y_sigma_y:
+            if y is not None or sigma_y is not None:
+                raise NotImplementedError("samplers that return their own y / sigma_y are not "
+                                          "supported by the device sweep (all of the reference's "
+                                          "samplers return None for both)")
+            self._y_mc, self._sigma_y_mc = self._device_sweep(gpr, X)
+            self._dev_index = np.arange(len(X))
+
+    def _reweight_last_MC_sample(self, gpr, bounds=None, ensure_sigma_y=False):
+        """gp_acquisition.py:875-919."""
+        self.is_last_MC_reweighted = True
+        if self._X_mc is None:
+            raise ValueError("No samples yet!")
+        if self._y_mc is None:
+            raise ValueError("Original logp was not stored. Cannot reweight!")
+        Xr = np.copy(self._X_mc)
+        within = None
+        if bounds is not None:
+            within = is_in_bounds(Xr, bounds, check_shape=False)
+            Xr = Xr[within]
+        yr, sr = self._device_sweep(gpr, Xr)
+        with np.errstate(all="ignore"):
+            y_old, w_old = self._y_mc, self._w_mc
+            if within is not None:
+                y_old = y_old[within]
+                w_old = w_old[within] if w_old is not None else None
+            factor = np.exp(yr - y_old)
+            w_new = (w_old if w_old is not None else np.ones(Xr.shape[0])) * factor
+            w_new /= max(w_new)
+        keep = np.where(w_new != 0)[0]
+        self._dev_index = keep          # positions (device order) of the samples that survive
+        self._dropped = np.where(w_new == 0)[0]
+        self._w_mc_reweight, self._X_mc_reweight, self._y_mc_reweight, \
+            self._sigma_y_mc_reweight = remove_0_weight_samples(w_new, Xr, yr, sr)
+
+    def last_MC_sample(self, copy=False, warn_reweight=True):
+        if self.is_last_MC_reweighted:
+            if warn_reweight:
+                warnings.warn("This is a reweighted sample! (disable with `warn_reweight=False`)")
+            vals = (self._X_mc_reweight, self._y_mc_reweight, self._sigma_y_mc_reweight,
+                    self._w_mc_reweight)
+        else:
+            vals = (self._X_mc, self._y_mc, self._sigma_y_mc, self._w_mc)
+        if copy:
+            vals = tuple(None if v is None else np.copy(v) for v in vals)
+        return vals
+
+    @property
+    def mean(self):
+        Xs, _, _, ws = self.last_MC_sample(copy=False, warn_reweight=False)
+        return np.average(Xs.T, weights=ws, axis=-1)
+
+    @property
+    def cov(self):
+        Xs, _, _, ws = self.last_MC_sample(copy=False, warn_reweight=False)
+        return np.cov(Xs.T, aweights=ws, ddof=0)
+
+    # -- the acquisition step ------------------------------------------------------------------
+    def multi_add(self, gpr, n_points=1, bounds=None, rng=None, force_resample=False):
+        """Propose ``n_points`` locations by Kriging-believer ranking of the candidate pool
+        (gp_acquisition.py:971-1108).  Returns ``(X, y_lies, acq)`` with unconditioned acq."""
+        if not (isinstance(n_points, (int, np.integer)) and n_points > 0):
+            raise ValueError(f"n_points should be int > 0, got {n_points}")
+        n_points = int(n_points)
+        rng = get_random_generator(rng)
+        t_start = time()
+        resample = not bool(self.mc_every_i % self.mc_every) or force_resample
+        if resample:
+            self._set_MC_sample(*self.do_MC_sample(gpr, bounds=bounds, rng=rng),
+                                ensure_y_sigma_y=True, gpr=gpr)
+            self._X_already_proposed = np.empty((0, gpr.d))
+            self._dropped = np.empty(0, dtype=np.int64)
+        else:
+            self._reweight_last_MC_sample(gpr, bounds=bounds, ensure_sigma_y=True)
+        self.mc_every_i += 1
+        X_dev = self._sweep_X       # rows in device order (superset of last_MC_sample's rows)
+        # rows to ignore: weight-0 samples of a reweighted set and points proposed since the
+        # last resampling (:1037-1047; both samples assumed unique, as there)
+        exclude = list(self._dropped)
+        for row in self._X_already_proposed:
+            hit = np.flatnonzero(np.all(X_dev == row, axis=1))
+            if hit.size:
+                exclude.append(int(hit[0]))
+        exclude = np.unique(np.asarray(exclude, dtype=np.int64))
+        self.acq_func_y_sigma = partial(self.acq_func.f, baseline=gpr.y_max,
+                                        noise_level=gpr.noise_level, zeta=self.acq_func.zeta)
+        self.log(f"({(time() - t_start):.2g} sec) " +
+                 (f"Obtained new MC sample with {self.sampler}" if resample
+                  else "Re-evaluated previous MC sample"), level=2)
+        t_rank = time()
+        self.pool = RankedPool(n_points, gpr=gpr, acq_func=self.acq_func_y_sigma,
+                               verbose=self.verbose - 3)
+        K = int(self.shortlist_size or max(256, 16 * n_points))
+        fed = 0
+        with np.errstate(divide="ignore"):
+            while True:
+                top, bound, exhausted = self._shortlist(gpr, K, exclude)
+                new = top[fed:]
+                if len(new):
+                    self.pool.add(X_dev[new["idx"]], new["y"].copy(), new["sigma"].copy(),
+                                  new["acq"].copy(), method="single sort acq")
+                fed = len(top)
+                # every candidate not fed has acq <= bound: if that is at or below the pool's
+                # admission level they would all return at the early-out (:1432)
+                if exhausted or self.pool.min_acq >= bound:
+                    break
+                K *= 4
+        self.stats.update(shortlist=fed, cache_models=self.pool.cache_counter,
+                          rank_s=time() - t_rank)
+        merged = self.pool.copy(drop_empty=True)
+        X_pool, y_pool = merged.X[:n_points], merged.y[:n_points]
+        with np.errstate(divide="ignore"):
+            acq_pool = self.acq_func_y_sigma(y_pool, merged.sigma[:n_points])
+        self._X_already_proposed = np.concatenate([self._X_already_proposed, X_pool])
+        self.pool.reset_cache()
+        self.log(f"({(time() - t_rank):.2g} sec) Ranked pool of candidates.", level=2)
+        return X_pool, y_pool, acq_pool
+
+
+class RankedPool:
+    """Ranked pool of proposals under the Kriging-believer rule (gp_acquisition.py:1194).
+
+    Slot ``i`` holds the candidate whose acquisition value, evaluated with the standard
+    deviation of the GP augmented by slots ``0..i-1`` at their predicted means, is the
+    largest among the remaining ones.  ``acq_cond == -inf`` marks an empty slot; the
+    arrays carry one spare slot at the end.
+    """
+
+    def __init__(self, size, gpr, acq_func, verbose=1):
+        self._gpr = gpr
+        self._acq_func = acq_func
+        self.verbose = verbose
+        self.X = np.zeros((size + 1, gpr.d))
+        self.y = np.zeros(size + 1)
+        self.acq_cond = np.full(size + 1, -np.inf)
+        self.sigma = np.zeros(size + 1)
+        self.acq = np.zeros(size + 1)
+        self.reset_cache()
+        self.cache_counter = 0
+
+    def __len__(self):
+        return len(self.y) - 1
+
+    @property
+    def min_acq(self):
+        """Admission level: conditioned acquisition of the last real slot (-inf if not full)."""
+        return self.acq_cond[len(self) - 1]
+
+    def log(self, level=None, msg=""):
+        if level is None or level <= self.verbose:
+            print(msg)
+
+    def str_point(self, X, y, sigma, acq, sigma_cond=None, acq_cond=None):
+        s_c = f" (cond: {sigma_cond})" if sigma_cond is not None else ""
+        a_c = f" (cond: {acq_cond})" if acq_cond is not None else ""
+        return f"{X}, y = {y} +/- {sigma}{s_c}; acq = {acq}{a_c}"
+
+    def __str__(self):
+        return "\n".join(f"{i + 1} : " + self.str_point(self.X[i], self.y[i], self.sigma[i],
+                                                        self.acq[i], acq_cond=self.acq_cond[i])
+                         for i in range(len(self)))
+
+    # -- conditioned models ------------------------------------------------------------------------
+    def cache_model(self, i):
+        """Model = base GP + slots 0..i (gp_acquisition.py:1522-1555), as a bordered factor."""
+        if i < 0:
+            return self._gpr
+        self.gpr_cond[i] = self._gpr.conditioned(self.X[:i + 1], self.y[:i + 1])
+        self.cache_counter += 1
+        return self.gpr_cond[i]
+
+    def reset_cache(self):
+        self.gpr_cond = [None] * len(self.X)
+
+    # -- filling -------------------------------------------------------------------------------------
+    def add(self, X, y=None, sigma=None, acq=None, method="single sort acq"):
+        """Offer points to the pool (gp_acquisition.py:1290-1335)."""
+        X = np.atleast_2d(X)
+        y = None if y is None else np.atleast_1d(y)
+        sigma = None if sigma is None else np.atleast_1d(sigma)
+        if y is None:
+            y, sigma = self._gpr.predict(X, return_std=True, validate=False)
+        elif sigma is None:
+            sigma = self._gpr.predict_std(X, validate=False)
+        if acq is None:
+            acq = self._acq_func(y, sigma)
+        m = method.lower()
+        if m == "bulk":
+            return self.add_bulk(X, y, sigma, acq)
+        if not m.startswith("single"):
+            raise ValueError(f"Algorithm '{method}' not known.")
+        order = range(len(X))
+        by_acq = False
+        if "sort" in m:
+            key = m.split()[-1]
+            order = np.argsort({"acq": acq, "y": y}[key])[::-1]
+            by_acq = key == "acq"
+        for i in order:
+            if by_acq and acq[i] <= self.min_acq:
+                # descending acquisition: this and all later offers return at add_one's
+                # first test (:1432) without touching the pool
+                break
+            self.add_one(X[i], y[i], sigma[i], acq[i])
+
+    def add_bulk(self, X, y, sigma, acq, i_start=0):
+        """Fill slot after slot from the whole batch (gp_acquisition.py:1337-1390)."""
+        X, y, sigma, acq = np.atleast_2d(X), np.asarray(y), np.asarray(sigma), np.asarray(acq)
+        slot = i_start
+        while True:
+            if slot == 0:
+                a_cond = acq
+            else:
+                model = self.cache_model(slot - 1)
+                a_cond = self._acq_func(y, model.predict_std(X, validate=False))
+            if a_cond.size == 0:
+                return
+            best = int(np.argmax(a_cond))
+            if a_cond[best] == np.inf:
+                return
+            self.X[slot], self.y[slot] = X[best], y[best]
+            self.sigma[slot], self.acq[slot] = sigma[best], acq[best]
+            self.acq_cond[slot] = a_cond[best]
+            if slot == len(self) - 1:
+                return
+            keep = a_cond != -np.inf
+            keep[best] = False
+            X, y, sigma, acq = X[keep], y[keep], sigma[keep], acq[keep]
+            slot += 1
+
+    def _position_for(self, a_cond):
+        """First slot, scanning upwards from the bottom, whose conditioned value is >= a_cond
+        decides the provisional rank (gp_acquisition.py:1470-1474)."""
+        n = len(self)
+        for up in range(n):
+            if self.acq_cond[n - 1 - up] >= a_cond:
+                return n - up
+        return 0
+
+    def add_one(self, X, y=None, sigma=None, acq=None, acq_nan_is_null=False):
+        """Offer one point (gp_acquisition.py:1392-1520)."""
+        if acq is not None and acq <= self.min_acq:
+            return
+        X = np.atleast_2d(X)
+        if y is None:
+            y, sigma = self._gpr.predict(X, return_std=True, validate=False)
+            y, sigma = y[0], sigma[0]
+        if sigma is None:
+            sigma = self._gpr.predict_std(X, validate=False)
+        if acq is None:
+            acq = self._acq_func(y, sigma)
+        if acq <= self.min_acq:
+            return
+        if np.isnan(acq):
+            if not acq_nan_is_null:
+                raise ValueError(f"Acquisition function value not a number: {acq}")
+            acq = -np.inf
+        n = len(self)
+        a_cond = deepcopy(acq)
+        last_pos = n
+        while True:
+            pos = self._position_for(a_cond)
+            if pos in (0, last_pos, n):
+                break
+            s_cond = self.gpr_cond[pos - 1].predict_std(X, validate=False)[0]
+            a_cond = min(a_cond, self._acq_func(y, s_cond))   # conditioning cannot raise it
+            last_pos = pos
+        if pos >= n:
+            return
+        for arr, val in ((self.X, X), (self.y, y), (self.sigma, sigma), (self.acq, acq),
+                         (self.acq_cond, a_cond)):
+            arr[pos + 1:] = arr[pos:-1]
+            arr[pos] = val
+        assert self.acq_cond[pos] > -np.inf
+        self.sort(pos + 1)
+        self.acq_cond[-1] = -np.inf
+
+    def sort(self, i_start=0):
+        """Re-rank slots ``i_start..`` given that the ones above are final
+        (gp_acquisition.py:1598-1670)."""
+        slot = i_start
+        while slot < len(self):
+            upper = self.cache_model(slot - 1)
+            if self.acq_cond[slot] == -np.inf:
+                return
+            empties = np.flatnonzero(self.acq_cond == -np.inf)
+            end = int(empties[0]) if len(empties) else len(self) + 1
+            s_cond = upper.predict_std(self.X[slot:end], validate=False)
+            ceiling = np.inf if slot == 0 else self.acq_cond[slot - 1]
+            a_cond = np.clip(self._acq_func(self.y[slot:end], s_cond), None, ceiling)
+            rank = np.argsort(-a_cond)
+            if a_cond[rank[0]] == -np.inf:
+                self.acq_cond[slot:end] = -np.inf
+                return
+            src = slot + rank
+            self.X[slot:end] = self.X[src]
+            self.y[slot:end] = self.y[src]
+            self.sigma[slot:end] = self.sigma[src]
+            self.acq[slot:end] = self.acq[src]
+            self.acq_cond[slot:end] = a_cond[rank]
+            slot += 1
+
+    # -- copies ------------------------------------------------------------------------------------------
+    def __getstate__(self):
+        return deepcopy(self).__dict__
+
+    def __deepcopy__(self, memo=None):
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__ = {k: deepcopy(v) for k, v in self.__dict__.items()
+                        if k not in ("_gpr", "_acq_func", "gpr_cond")}
+        return new
+
+    def copy(self, drop_empty=False):
+        c = deepcopy(self)
+        if drop_empty:
+            empties = np.flatnonzero(c.acq_cond[:-1] == -np.inf)
+            if len(empties):
+                k = int(empties[0])
+                c.X, c.y, c.acq_cond, c.sigma, c.acq = (c.X[:k], c.y[:k], c.acq_cond[:k],
+                                                        c.sigma[:k], c.acq[:k])
+        return c

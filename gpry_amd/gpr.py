@@ -1,0 +1,720 @@
+"""Device-backed Gaussian-process regressor with GPry's incremental-data interface.
+
+Host mirror of ``gpry.gpr.GaussianProcessRegressor`` (gpry/gpr.py:27): the object model,
+bookkeeping and control flow stay in Python (``append_to_data`` :577-753,
+``fit_gpr_hyperparameters`` :883-994 with scipy's L-BFGS-B, ``_update_model`` :996-1020,
+``predict`` :1022-1273, ``predict_std`` :1275-1352, ``__deepcopy__`` :1354-1433); every
+O(N^2)...O(M N^2) array operation is a call into ``libgpry_hip.so``:
+
+    kernel build + Cholesky + L^-1 + alpha_   -> gpry_factorize
+    log marginal likelihood (+ gradient)      -> gpry_lml
+    posterior mean / std with the affine maps -> gpry_predict / gpry_sweep_logexp
+    conditioned models of the KB ranking      -> gpry_kb_*  (bordered factor)
+
+There is no CPU path: without the library or without a GPU the methods raise.
+"""
+import copy
+import os
+import warnings
+from collections.abc import Mapping
+from numbers import Number
+
+import numpy as np
+import scipy.optimize
+
+from gpry_amd import _lib
+from gpry_amd.kernels import RBF, Matern, ConstantKernel as C, clone
+from gpry_amd.preprocessing import DummyPreprocessor, Normalize_bounds, Normalize_y
+from gpry_amd.svm import SVM
+from gpry_amd.tools import (check_random_state, delta_logp_of_1d_nstd, generic_params_names,
+                            get_Xnumber, is_in_bounds, shrink_bounds)
+
+try:  # estimator tags so that sklearn.base.is_regressor() accepts the object
+    from sklearn.base import BaseEstimator as _BE, RegressorMixin as _RM
+except Exception:  # pragma: no cover
+    _BE = _RM = object
+
+
+def default_device_index():
+    """GPU of this process: ``GPRY_HIP_DEVICE`` or ``LOCAL_RANK`` (one process per GPU), else 0."""
+    for var in ("GPRY_HIP_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(var, "") != "":
+            n = _lib.device_count()
+            return int(os.environ[var]) % max(n, 1)
+    return 0
+
+
+_SCRATCH = None
+
+
+def _scratch_device():
+    """Shared context for stand-alone kernel evaluations (``kernel_(X, Y)``)."""
+    global _SCRATCH
+    if _SCRATCH is None:
+        _SCRATCH = _lib.Device(default_device_index())
+    return _SCRATCH
+
+
+class GaussianProcessRegressor(_RM, _BE):
+    """See the module docstring; constructor arguments as gpry/gpr.py:265-271."""
+
+    def __init__(self, kernel="RBF", output_scale_prior=[1e-2, 1e3],
+                 length_scale_prior=[1e-3, 1e1], noise_level=1e-2, clip_factor=1.1,
+                 optimizer="fmin_l_bfgs_b", n_restarts_optimizer=0,
+                 preprocessing_X=None, preprocessing_y=None,
+                 account_for_inf="SVM", inf_threshold="20s", keep_min_finite=None,
+                 trust_region_factor=None, trust_region_nstd=None,
+                 bounds=None, random_state=None, verbose=1):
+        self.output_scale_prior = output_scale_prior
+        self.length_scale_prior = length_scale_prior
+        self.account_for_inf = account_for_inf
+        self.n_last_appended = 0
+        self.n_last_appended_finite = 0
+        self.newly_appended_for_inv = 0
+        self.preprocessing_X = DummyPreprocessor if preprocessing_X is None else preprocessing_X
+        self.preprocessing_y = DummyPreprocessor if preprocessing_y is None else preprocessing_y
+        self.noise_level = noise_level
+        if clip_factor is not None and clip_factor < 1:
+            raise ValueError("'clip_factor' must be >= 1, or None for no clippling.")
+        self.clip_factor = clip_factor
+        self.n_eval = 0
+        self.n_eval_loglike = 0
+        self.verbose = verbose
+        self.inf_value = np.inf
+        self.minus_inf_value = -np.inf
+        self._fitted = False
+        self.bounds = None if bounds is None else np.asarray(bounds, dtype=float)
+        self.trust_bounds = None
+        self.trust_region_factor = trust_region_factor
+        self.trust_region_nstd = trust_region_nstd
+        self.inf_threshold = inf_threshold
+        self.X_train = np.empty((0, 0))
+        if keep_min_finite is None and self.bounds is None:
+            self.keep_min_finite = 2
+        else:
+            self.keep_min_finite = keep_min_finite if keep_min_finite is not None else max(2, self.d)
+        if isinstance(account_for_inf, str) and account_for_inf.lower() == "svm":
+            self.infinities_classifier = SVM(random_state=random_state)
+        elif account_for_inf is False:
+            self.infinities_classifier = None
+        else:
+            self.infinities_classifier = account_for_inf
+        if self.infinities_classifier is not None:
+            if not getattr(self.preprocessing_y, "is_linear", False):
+                warnings.warn("If using a standard classifier for infinities, the y-preprocessor "
+                              "needs to be linear (declare an attr ``is_linear=True``). This may "
+                              "lead to errors further in the pipeline.")
+            if self.inf_threshold is None:
+                raise ValueError("Specify 'inf_threshold' if using infinities classifier.")
+            value, in_sigma, power = get_Xnumber(self.inf_threshold, "s", None, dtype=float,
+                                                 varname="inf_threshold")
+            if power is not None:
+                raise ValueError("Power for sigma not supported.")
+            self._diff_threshold = (self.compute_threshold_given_sigma(value, self.d)
+                                    if in_sigma else value)
+        if isinstance(kernel, str):
+            kernel = {kernel: {}}
+        if isinstance(kernel, Mapping):
+            if len(kernel) != 1:
+                raise ValueError("'kernel' must be a single-key dict.")
+            name = list(kernel)[0]
+            kargs = kernel[name] or {}
+            if self.bounds is None:
+                raise ValueError(f"You selected used the automatically constructed '{name}' kernel "
+                                 "without specifying prior bounds.")
+            self.bounds_ = self.preprocessing_X.transform_bounds(self.bounds)
+            try:
+                cls = {"rbf": RBF, "matern": Matern}[name.lower()]
+            except KeyError as excpt:
+                raise ValueError("Currently only 'RBF' and 'Matern' are supported as standard "
+                                 f"kernels. Got '{name}'.") from excpt
+            scale0 = np.sqrt(output_scale_prior[0] * output_scale_prior[1])
+            length0 = np.sqrt(length_scale_prior[0] * length_scale_prior[1])
+            kernel = (C(scale0 ** 2, [output_scale_prior[0] ** 2, output_scale_prior[1] ** 2]) *
+                      cls([length0] * self.d, length_scale_prior, prior_bounds=self.bounds_, **kargs))
+        self.kernel = kernel
+        self.alpha = noise_level ** 2. if isinstance(noise_level, Number) else None
+        self.optimizer = optimizer
+        self.n_restarts_optimizer = n_restarts_optimizer
+        self.random_state = random_state
+        self.X_train, self.y_train = np.empty((0, self.d)), np.empty((0,))
+        self.X_train_, self.y_train_ = None, None
+        self.X_train_all, self.y_train_all = np.empty((0, self.d)), np.empty((0,))
+        self.X_train_all_, self.y_train_all_ = None, None
+        self.noise_level_ = None
+        self.kernel_ = None
+        self.log_marginal_likelihood_value_ = None
+        self._init_device_state()
+
+    # ---- device state ---------------------------------------------------------------
+    def _init_device_state(self):
+        self._dev = None
+        self._dev_train_ok = False     # device holds X_train_, y_train_, alpha
+        self._dev_factor_ok = False    # device factor matches kernel_.theta + training set
+        self._host_factor = {}         # lazily fetched copies of L_, V_, alpha_
+        self._kb = None                # Kriging-believer session on the current factor
+
+    @property
+    def device(self):
+        if self._dev is None:
+            self._dev = _lib.Device(default_device_index())
+        return self._dev
+
+    def _invalidate(self, train=False):
+        if train:
+            self._dev_train_ok = False
+        self._dev_factor_ok = False
+        self._host_factor = {}
+        self._kb = None
+
+    def _upload_train(self):
+        if not self._dev_train_ok:
+            self.device.set_train(self.X_train_, self.y_train_, self.alpha)
+            kern = self.kernel_ if self.kernel_ is not None else self.kernel
+            self.device.set_theta(*kern.device_spec(self.d))   # fixes the kernel family too
+            self._dev_train_ok = True
+            self._dev_factor_ok = False
+
+    def _x_affine(self):
+        px = self.preprocessing_X
+        if px is None or px is DummyPreprocessor or isinstance(px, DummyPreprocessor):
+            return None, None
+        if isinstance(px, Normalize_bounds) or (hasattr(px, "bounds_min") and hasattr(px, "bounds_max")):
+            return np.asarray(px.bounds_min, float), np.asarray(px.bounds_max - px.bounds_min, float)
+        raise NotImplementedError(f"X-preprocessor {type(px).__name__} has no device form (only "
+                                  "Normalize_bounds / none are on the hot path; SURVEY.md section 2)")
+
+    def _y_affine(self):
+        py = self.preprocessing_y
+        if py is None or py is DummyPreprocessor or isinstance(py, DummyPreprocessor):
+            return 0.0, 1.0
+        if isinstance(py, Normalize_y) or (hasattr(py, "mean_") and hasattr(py, "std_")):
+            return float(py.mean_), float(py.std_)
+        raise NotImplementedError(f"y-preprocessor {type(py).__name__} has no device form (only "
+                                  "Normalize_y / none are on the hot path; SURVEY.md section 2)")
+
+    def _clip_hi(self):
+        if self.clip_factor is None:
+            return np.inf
+        return self.clip_factor * max(self.y_train) - (self.clip_factor - 1) * min(self.y_train)
+
+    def _push_affine(self):
+        lo, span = self._x_affine()
+        mean_y, std_y = self._y_affine()
+        self.device.set_affine(lo, span, mean_y, std_y, self._clip_hi())
+
+    def _device_theta(self, kernel=None):
+        return (kernel or self.kernel_).device_spec(self.d)
+
+    def _ensure_factor(self):
+        """Bring the device factor up to date with (kernel_, training set)."""
+        if self._dev_factor_ok:
+            return
+        self._upload_train()
+        kid, theta = self._device_theta()
+        self.device.set_theta(kid, theta)
+        info = self.device.factorize()
+        if info != 0:
+            raise np.linalg.LinAlgError(
+                "The kernel, %s, is not returning a positive definite matrix. Try gradually "
+                "increasing the 'noise_level' parameter of your GaussianProcessRegressor "
+                "estimator." % self.kernel_,
+                f"{info}-th leading minor of the array is not positive definite")
+        self._dev_factor_ok = True
+        self._host_factor = {}
+        self._kb = None
+
+    def _fetch_factor(self, which):
+        if which not in self._host_factor:
+            self._ensure_factor()
+            L, V, a = self.device.get_factor(want_L=(which == "L_"), want_V=(which == "V_"),
+                                             want_alpha=(which == "alpha_"))
+            self._host_factor[which] = {"L_": L, "V_": V, "alpha_": a}[which]
+        return self._host_factor[which]
+
+    # L_, V_, alpha_ live on the device; host copies are made on attribute access only
+    @property
+    def L_(self):
+        return self._fetch_factor("L_")
+
+    @property
+    def V_(self):
+        return self._fetch_factor("V_")
+
+    @property
+    def alpha_(self):
+        return self._fetch_factor("alpha_")
+
+    # ---- simple properties (gpry/gpr.py:391-540) ------------------------------------------
+    @property
+    def d(self):
+        return self.X_train.shape[1] if self.bounds is None else self.bounds.shape[0]
+
+    @property
+    def y_max(self):
+        return np.max(getattr(self, "y_train", [self.minus_inf_value]))
+
+    @property
+    def n(self):
+        return len(getattr(self, "y_train", []))
+
+    @property
+    def n_finite(self):
+        return self.n
+
+    @property
+    def n_total(self):
+        if self.infinities_classifier:
+            return self.infinities_classifier.n or self.n
+        return self.n
+
+    @property
+    def X_train_infinite(self):
+        if self.infinities_classifier is None:
+            return np.empty(shape=(0, self.d))
+        return self.X_train_all[~self.infinities_classifier.y_finite]
+
+    @property
+    def y_train_infinite(self):
+        if self.infinities_classifier is None:
+            return np.empty(shape=(0,))
+        return self.y_train_all[~self.infinities_classifier.y_finite]
+
+    @property
+    def fitted(self):
+        return self._fitted
+
+    @property
+    def last_appended(self):
+        if self.infinities_classifier is None:
+            return self.last_appended_finite
+        return (np.copy(self.X_train_all[-self.n_last_appended:]),
+                np.copy(self.y_train_all[-self.n_last_appended:]))
+
+    @property
+    def last_appended_finite(self):
+        return (np.copy(self.X_train[-self.n_last_appended_finite:]),
+                np.copy(self.y_train[-self.n_last_appended_finite:]))
+
+    @property
+    def scales(self):
+        return (self.preprocessing_y.inverse_transform_scale(np.sqrt(self.kernel_.k1.constant_value)),
+                tuple(self.preprocessing_X.inverse_transform_scale(
+                    np.atleast_1d(self.kernel_.k2.length_scale))))
+
+    def training_set_as_df(self):
+        import pandas as pd
+        data = dict(zip(generic_params_names(self.d), self.X_train_all.copy().T))
+        data["y"] = self.y_train_all.copy()
+        data["is_finite"] = self.is_finite(data["y"])
+        return pd.DataFrame(data)
+
+    @property
+    def abs_finite_threshold(self):
+        thr = self.infinities_classifier.abs_threshold
+        return self.preprocessing_y.inverse_transform_scale(thr)
+
+    def is_finite(self, y):
+        if self.infinities_classifier is None:
+            return np.full(shape=len(y), fill_value=True)
+        return self.infinities_classifier.is_finite(self.preprocessing_y.transform(y))
+
+    def predict_is_finite(self, X, validate=True):
+        if self.infinities_classifier is None:
+            return np.full(shape=(len(self.y_train_all),), fill_value=True)
+        return self.infinities_classifier.predict(
+            np.ascontiguousarray(self.preprocessing_X.transform(X)), validate=validate)
+
+    def set_random_state(self, random_state):
+        self.random_state = random_state
+        if self.infinities_classifier:
+            self.infinities_classifier.random_state = check_random_state(
+                random_state, convert_to_random_state=True)
+
+    def update_trust_region(self):
+        """gpry/gpr.py:554-575."""
+        if self.trust_region_factor is None:
+            return
+        if self.trust_region_nstd is None:
+            use_X = self.X_train
+        else:
+            nstd = self.trust_region_nstd
+            use_X = np.empty(shape=(0, self.X_train.shape[1]))
+            while len(use_X) < min(self.d, self.n):
+                use_X = self.X_train[np.where(max(self.y_train) - self.y_train <
+                                              delta_logp_of_1d_nstd(nstd, self.d))]
+                nstd = nstd + 0.1
+        self.trust_bounds = shrink_bounds(self.bounds, use_X, factor=self.trust_region_factor)
+
+    # ---- data ---------------------------------------------------------------------------
+    def append_to_data(self, X, y, noise_level=None, fit_gpr=True, fit_classifier=True):
+        """Append points and update the model (gpry/gpr.py:577-753).
+
+        ``fit_gpr``: True (restarts), 'simple' (one run from the current optimum), a dict of
+        ``fit_gpr_hyperparameters`` arguments, or False (fixed theta: refactorise only).
+        """
+        fit_kwargs = None
+        if fit_gpr is True:
+            fit_kwargs = {}
+        elif str(fit_gpr) == "simple":
+            fit_kwargs = {"simple": True}
+        elif isinstance(fit_gpr, Mapping):
+            fit_kwargs = copy.deepcopy(dict(fit_gpr))
+        elif fit_gpr is not False:
+            raise ValueError("`fit_gpr` needs to be bool, 'simple', or a dict of args for the "
+                             f"`fit_gpr_hyperparameters` method. Got {fit_gpr}.")
+        do_fit = fit_kwargs is not None
+        if do_fit:
+            fit_classifier = True
+        fit_preprocessors = bool(fit_classifier)
+        force_fit = False
+        if X is None and y is None:
+            X, y = np.empty((0, self.d)), np.empty((0,))
+            force_fit = do_fit
+            if noise_level is not None:
+                raise ValueError("Cannot give a noise level if X and y are not given.")
+        elif X is None or y is None:
+            raise ValueError("If passing X, y needs to be passed too, and viceversa.")
+        X = np.asarray(X, dtype=float).reshape(-1, self.d) if np.size(X) else np.empty((0, self.d))
+        y = np.atleast_1d(np.asarray(y, dtype=float))
+        noise_valid = self._validate_noise_level(noise_level, len(y))
+        self.n_last_appended = len(y)
+        self.X_train_all = np.append(self.X_train_all, X, axis=0)
+        self.y_train_all = np.append(self.y_train_all, y)
+        self._update_noise_level(noise_valid)
+        clf = self.infinities_classifier
+        if clf is None:
+            is_finite_all = np.full(len(self.y_train_all), True)
+            X_fin, y_fin = np.copy(self.X_train_all), np.copy(self.y_train_all)
+        else:
+            thr_keep = self._diff_threshold_if_keep_n_finite(
+                self.y_train_all, self.keep_min_finite, self._diff_threshold)
+            is_finite_all = clf._is_finite_raw(self.y_train_all, thr_keep)
+            X_fin = np.copy(self.X_train_all[is_finite_all])
+            y_fin = np.copy(self.y_train_all[is_finite_all])
+        if fit_preprocessors:
+            self.preprocessing_X.fit(X_fin, y_fin)
+            self.preprocessing_y.fit(X_fin, y_fin)
+        self.X_train_all_ = self.preprocessing_X.transform(self.X_train_all)
+        self.y_train_all_ = self.preprocessing_y.transform(self.y_train_all)
+        noise_arr = (np.full(len(self.y_train_all_), self.noise_level)
+                     if isinstance(self.noise_level, Number) else self.noise_level)
+        self.noise_level_ = self.preprocessing_y.transform_scale(noise_arr)
+        if clf is None:
+            last_finite = np.full(self.n_last_appended, True)
+        else:
+            if fit_classifier:
+                thr_ = self.preprocessing_y.transform_scale(thr_keep)
+                pred = clf.fit(self.X_train_all_, self.y_train_all_, thr_)
+                assert np.array_equal(is_finite_all, pred), \
+                    "Infinities classifier miss-classified at least 1 point."
+            last_finite = is_finite_all[len(is_finite_all) - self.n_last_appended:]
+        self.n_last_appended_finite = int(sum(last_finite))
+        if not self.n_last_appended_finite and not force_fit:
+            return self
+        self.X_train, self.y_train = X_fin, y_fin
+        self.X_train_ = np.ascontiguousarray(self.preprocessing_X.transform(self.X_train))
+        self.y_train_ = np.ascontiguousarray(self.preprocessing_y.transform(self.y_train))
+        self.alpha = np.asarray(self.noise_level_)[is_finite_all] ** 2
+        self.newly_appended_for_inv = self.n_last_appended_finite
+        self._invalidate(train=True)
+        if do_fit:
+            self.fit_gpr_hyperparameters(**fit_kwargs)
+        else:
+            self._update_model()
+        self.update_trust_region()
+        return self
+
+    def fit(self, X, y):
+        """Thin alias (the reference never calls sklearn's ``fit``; SURVEY.md preamble)."""
+        return self.append_to_data(X, y, fit_gpr=True)
+
+    def _validate_noise_level(self, noise_level, n_train):
+        """gpry/gpr.py:755-785."""
+        if n_train == 0 and noise_level is not None:
+            raise ValueError("noise_level must be None if not fitting to new points.")
+        if np.iterable(noise_level):
+            noise_level = np.atleast_1d(noise_level)
+            if noise_level.shape[0] != n_train:
+                raise ValueError("noise_level must be an array with same number of entries as y, "
+                                 f"but len(n)={noise_level.shape[0]} != len(y)={n_train})")
+        elif isinstance(noise_level, Number):
+            if np.iterable(self.noise_level):
+                noise_level = np.full(fill_value=noise_level, shape=(n_train,))
+        elif noise_level is None:
+            if np.iterable(self.noise_level):
+                raise ValueError("Need to pass non-null noise_level (scalar or array) because "
+                                 "concrete values were given earlier for the training points.")
+        else:
+            raise ValueError("noise_level needs to be an iterable, number or None. "
+                             f"Got type(noise_level)={type(noise_level)}")
+        return noise_level
+
+    def _update_noise_level(self, noise_level):
+        """gpry/gpr.py:787-817."""
+        if np.iterable(noise_level):
+            if not np.iterable(self.noise_level):
+                if self.verbose > 1:
+                    warnings.warn("A new noise level has been assigned to the updated training set "
+                                  "while the old training set has a single scalar noise level: "
+                                  f"{self.noise_level}. Converting to individual levels!")
+                n_old = len(self.y_train_all) - len(noise_level)
+                self.noise_level = np.full(fill_value=self.noise_level, shape=(n_old,))
+            self.noise_level = np.append(self.noise_level, noise_level, axis=0)
+        elif isinstance(noise_level, Number):
+            assert not np.iterable(self.noise_level)
+            if not np.isclose(noise_level, self.noise_level):
+                if self.verbose > 1:
+                    warnings.warn("Overwriting the noise level with a scalar. Make sure that "
+                                  "kernel's hyperparamters are refitted.")
+                self.noise_level = noise_level
+
+    def remove_from_data(self, position, fit=True):
+        raise NotImplementedError("This function is outdated and needs review.")
+
+    # ---- marginal likelihood and fit ------------------------------------------------------
+    def log_marginal_likelihood(self, theta=None, eval_gradient=False, clone_kernel=True):
+        """Device evaluation of sklearn:_gpr.py:574-652 (counted as gpry/gpr.py:876-881)."""
+        self.n_eval_loglike += 1
+        if theta is None:
+            if eval_gradient:
+                raise ValueError("Gradient can only be evaluated for theta!=None")
+            return self.log_marginal_likelihood_value_
+        theta = np.asarray(theta, dtype=float)
+        kernel = self.kernel_ if self.kernel_ is not None else clone(self.kernel)
+        if clone_kernel:
+            kernel = kernel.clone_with_theta(theta)
+        else:
+            if self.kernel_ is None:
+                self.kernel_ = kernel
+            kernel.theta = theta          # same side effect as the reference
+            self._dev_factor_ok = False
+            self._host_factor = {}
+            self._kb = None
+        self._upload_train()
+        kid, theta_full = kernel.device_spec(self.d)
+        if self.device.N != len(self.y_train_):
+            raise RuntimeError("device training set out of sync")
+        if eval_gradient:
+            lml, grad_full, _ = self.device.lml(theta_full, True)
+            if not np.isfinite(lml):
+                return -np.inf, np.zeros_like(theta)
+            return lml, kernel.grad_from_full(grad_full, self.d)
+        lml, _ = self.device.lml(theta_full, False)
+        return lml if np.isfinite(lml) else -np.inf
+
+    def fit_gpr_hyperparameters(self, simple=False, start_from_current=True, n_restarts=None,
+                                hyperparameter_bounds=None):
+        """Maximise the marginal likelihood over theta (gpry/gpr.py:883-994): same restart
+        schedule, RNG order (:969-978) and optimiser (scipy L-BFGS-B with jac) as the
+        reference; the objective and its gradient are evaluated on the device."""
+        if simple:
+            start_from_current, n_restarts = True, 1
+        if not self._fitted:
+            start_from_current = False
+        if n_restarts is None:
+            n_restarts = self.n_restarts_optimizer
+        if self.kernel_ is None:
+            self.kernel_ = clone(self.kernel)
+        reasons = []
+        if self.optimizer is None:
+            reasons.append("no optimizer has been specified")
+        if self.kernel.n_dims == 0:
+            reasons.append("the kernel has no hyperparamenters")
+        if n_restarts <= 0:
+            reasons.append("the number of optimizer restarts requested is 0.")
+        if reasons:
+            warnings.warn(f"Hyper-parameters not (re)fit. Reason(s): {'; '.join(reasons)}.")
+            self.log_marginal_likelihood_value_ = self.log_marginal_likelihood(
+                self.kernel_.theta, clone_kernel=False)
+            self._update_model()
+            return self
+
+        def obj_func(theta, eval_gradient=True):
+            if eval_gradient:
+                lml, grad = self.log_marginal_likelihood(theta, eval_gradient=True,
+                                                         clone_kernel=False)
+                return -lml, -grad
+            return -self.log_marginal_likelihood(theta, clone_kernel=False)
+
+        if hyperparameter_bounds is None:
+            hyperparameter_bounds = self.kernel_.bounds
+        if n_restarts - int(start_from_current):
+            if not np.isfinite(hyperparameter_bounds).all():
+                raise ValueError(
+                    "There is at least one optimizer run the requires sampling from the "
+                    "hyperparameters' prior, but it has not finite density, because not all "
+                    "bounds are finite. You can pass some finite bounds manually using "
+                    "``hyperparameter_bounds``.")
+        optima = []
+        self._rng = check_random_state(self.random_state)
+        for iteration in range(n_restarts):
+            if iteration == 0 and start_from_current:
+                theta0 = self.kernel_.theta
+            else:
+                theta0 = self._rng.uniform(hyperparameter_bounds[:, 0], hyperparameter_bounds[:, 1])
+            optima.append(self._constrained_optimization(obj_func, theta0, hyperparameter_bounds))
+        values = [o[1] for o in optima]
+        self.log_marginal_likelihood_value_ = -np.min(values)
+        self.kernel_.theta = optima[int(np.argmin(values))][0]
+        self._invalidate()
+        self._update_model()
+        self._fitted = True
+        return self
+
+    def _constrained_optimization(self, obj_func, initial_theta, bounds):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if self.optimizer == "fmin_l_bfgs_b":
+                res = scipy.optimize.minimize(obj_func, initial_theta, method="L-BFGS-B", jac=True,
+                                              bounds=bounds)
+                return res.x, res.fun
+            if callable(self.optimizer):
+                return self.optimizer(obj_func, initial_theta, bounds=bounds)
+            raise ValueError("Unknown optimizer %s." % self.optimizer)
+
+    def _update_model(self):
+        """Refactorise at fixed theta (gpry/gpr.py:996-1020)."""
+        if self.newly_appended_for_inv < 1:
+            warnings.warn("No new points have been appended to the model.")
+            return self
+        if self.kernel_ is None:
+            self.kernel_ = clone(self.kernel)
+        self._invalidate()
+        self._ensure_factor()
+        self.newly_appended_for_inv = 0
+        return self
+
+    # ---- prediction -----------------------------------------------------------------------
+    def _masks(self, X, validate, ignore_trust_region):
+        """Host-side gates turned into the device's per-candidate mask bits."""
+        mask = None
+        if self.trust_bounds is not None and not ignore_trust_region:
+            outside = np.logical_not(is_in_bounds(X, self.trust_bounds, check_shape=False))
+            mask = outside.astype(np.uint8) * _lib.MASK_OUTSIDE_TRUST
+        if self.infinities_classifier is not None:
+            X_ = self.preprocessing_X.transform(X)
+            finite = self.infinities_classifier.predict(np.ascontiguousarray(X_), validate=validate)
+            bits = np.logical_not(finite).astype(np.uint8) * _lib.MASK_CLASSIFIED_INF
+            mask = bits if mask is None else (mask | bits)
+        return mask
+
+    def _validate_X(self, X, validate):
+        if validate:
+            X = np.asarray(X, dtype=float)
+            if X.ndim != 2:
+                raise ValueError(f"Expected 2D array, got array with shape {X.shape}")
+            if not np.all(np.isfinite(X)):
+                raise ValueError("Input X contains NaN or infinity.")
+        return X
+
+    def predict(self, X, return_std=False, return_cov=False, return_mean_grad=False,
+                return_std_grad=False, validate=True, ignore_trust_region=False):
+        """Posterior mean (and std) at ``X`` in untransformed units (gpry/gpr.py:1022-1273).
+
+        Clipping, classifier and trust-region gates behave as in the reference.  The
+        x-gradient outputs are not on the device path yet.
+        """
+        self.n_eval += len(X)
+        if return_std_grad and not (return_std and return_mean_grad):
+            raise ValueError("Not returning std_gradient without returning the std and the mean grad.")
+        if X.shape[0] != 1 and (return_mean_grad or return_std_grad):
+            raise ValueError("Mean grad and std grad not implemented for n_samples > 1")
+        if return_mean_grad or return_std_grad:
+            raise NotImplementedError("predict(..., return_mean_grad/return_std_grad) has no device "
+                                      "implementation yet (SURVEY.md section 8f, item 3)")
+        X = self._validate_X(X, validate)
+        if self.X_train_ is None:  # not fit: GP prior
+            y_mean = np.zeros(X.shape[0])
+            if self.trust_bounds is not None and not ignore_trust_region:
+                y_mean[~is_in_bounds(X, self.trust_bounds)] = self.minus_inf_value
+            if return_std:
+                return y_mean, np.sqrt(self.kernel.diag(X))
+            return y_mean
+        self._ensure_factor()
+        self._push_affine()
+        mask = self._masks(X, validate, ignore_trust_region)
+        out = self.device.predict(X, return_std=return_std, mask=mask)
+        y_mean = out[0] if return_std else out
+        if self.minus_inf_value != -np.inf:
+            y_mean[np.isneginf(y_mean)] = self.minus_inf_value
+        return (y_mean, out[1]) if return_std else y_mean
+
+    def predict_std(self, X, validate=True):
+        """gpry/gpr.py:1275-1352 (no trust-region gate, classifier-masked rows give 0)."""
+        self.n_eval += len(X)
+        X = self._validate_X(X, validate)
+        if self.X_train_ is None:
+            return np.sqrt(self.kernel.diag(X))
+        self._ensure_factor()
+        self._push_affine()
+        mask = None
+        if self.infinities_classifier is not None:
+            X_ = self.preprocessing_X.transform(X)
+            finite = self.infinities_classifier.predict(np.ascontiguousarray(X_), validate=validate)
+            mask = np.logical_not(finite).astype(np.uint8) * _lib.MASK_CLASSIFIED_INF
+        return self.device.predict(X, return_std=True, mask=mask)[1]
+
+    # ---- Kriging-believer conditioning (used by RankedPool.cache_model) ---------------------
+    def kb_session(self):
+        from gpry_amd.kriging import KBSession
+        self._ensure_factor()
+        if self._kb is None:
+            self._kb = KBSession(self)
+        return self._kb
+
+    def conditioned(self, X, y):
+        """Model augmented by ``(X, y)`` at fixed theta and frozen pre-processors -- what
+        ``deepcopy(gpr).append_to_data(X, y, fit_gpr=False, fit_classifier=False)`` yields in
+        the reference (gpry/gp_acquisition.py:1550-1553) -- as a bordered factor."""
+        return self.kb_session().conditioned(np.atleast_2d(X), np.atleast_1d(y))
+
+    # ---- copies and pickles ------------------------------------------------------------------
+    def __deepcopy__(self, memo):
+        """Same field semantics as gpry/gpr.py:1354-1433 (a fresh object from the constructor
+        arguments that the reference forwards, then the data fields); device state is not
+        shared: the copy rebuilds its factor on first use."""
+        c = GaussianProcessRegressor(
+            kernel=copy.deepcopy(self.kernel), noise_level=copy.deepcopy(self.noise_level),
+            optimizer=self.optimizer, n_restarts_optimizer=self.n_restarts_optimizer,
+            preprocessing_X=self.preprocessing_X, preprocessing_y=self.preprocessing_y,
+            bounds=self.bounds, random_state=self.random_state, account_for_inf=None)
+        for name in ("n_eval", "n_eval_loglike", "noise_level_", "alpha", "n_last_appended",
+                     "n_last_appended_finite", "newly_appended_for_inv", "_fitted",
+                     "log_marginal_likelihood_value_"):
+            if hasattr(self, name):
+                setattr(c, name, getattr(self, name))
+        for name in ("X_train", "y_train", "X_train_", "y_train_", "X_train_all", "y_train_all",
+                     "X_train_all_", "y_train_all_"):
+            v = getattr(self, name, None)
+            setattr(c, name, None if v is None else np.copy(v))
+        for name in ("kernel_", "infinities_classifier", "_diff_threshold", "keep_min_finite",
+                     "trust_region_factor", "trust_region_nstd", "inf_value", "minus_inf_value"):
+            if hasattr(self, name):
+                setattr(c, name, copy.deepcopy(getattr(self, name)))
+        return c
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in ("_dev", "_kb", "_host_factor"):
+            state.pop(k, None)
+        state["_dev_train_ok"] = False
+        state["_dev_factor_ok"] = False
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._init_device_state()
+
+    # ---- helpers shared with the reference ------------------------------------------------------
+    @staticmethod
+    def compute_threshold_given_sigma(n_sigma, n_dimensions):
+        return delta_logp_of_1d_nstd(n_sigma, n_dimensions)
+
+    @staticmethod
+    def _diff_threshold_if_keep_n_finite(y, n, reference_diff_threshold, epsilon=1e-6):
+        """gpry/gpr.py:1476-1488."""
+        if n is None or n <= 1:
+            return reference_diff_threshold
+        ys = np.sort(y)
+        return max(reference_diff_threshold, ys[-1] - ys[-min(n, len(ys))] + epsilon)

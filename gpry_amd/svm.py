@@ -1,0 +1,80 @@
+"""Finite / infinite classifier that gates GP predictions (host side, off the hot path).
+
+Same role and interface as ``gpry/svm.py`` (``fit`` :227, ``_is_finite_raw`` :273-295,
+``is_finite`` :297, ``predict`` :308-347): an RBF support-vector classifier trained on
+"y above (max - threshold)" labels.  The device sweep consumes its verdict as a per-
+candidate mask; the classifier itself stays on the host (libsvm through scikit-learn).
+"""
+import warnings
+
+import numpy as np
+
+from gpry_amd.tools import check_random_state
+
+
+class SVM:
+    def __init__(self, C=1e7, kernel="rbf", gamma="scale", tol=1e-3, random_state=None, **svc_kwargs):
+        self._svc_args = dict(C=C, kernel=kernel, gamma=gamma, tol=tol, **svc_kwargs)
+        self.random_state = check_random_state(random_state, convert_to_random_state=True)
+        self._svc = None
+        self.X_train = None
+        self.y_train = None
+        self.y_finite = None
+        self.at_least_one_finite = False
+        self.all_finite = False
+        self.diff_threshold = None
+        self._max_y = None
+
+    @property
+    def d(self):
+        if self.X_train is None:
+            raise ValueError("You need to add some data before determining its dimension.")
+        return self.X_train.shape[1]
+
+    @property
+    def n(self):
+        return 0 if self.y_train is None else len(self.y_train)
+
+    @property
+    def abs_threshold(self):
+        return self._max_y - self.diff_threshold
+
+    @staticmethod
+    def _is_finite_raw(y, diff_threshold, max_y=None):
+        if max_y is None:
+            max_y = np.max(y)
+        return np.greater_equal(y, max_y - diff_threshold) & np.isfinite(y)
+
+    def is_finite(self, y):
+        if self.y_train is None:
+            raise ValueError("Cannot do anything: the SVM has not been trained yet!")
+        return self._is_finite_raw(y, self.diff_threshold, self._max_y)
+
+    def fit(self, X, y, diff_threshold):
+        from sklearn.svm import SVC
+        self.X_train, self.y_train = np.copy(X), np.copy(y)
+        if np.all(self.y_train == -np.inf):
+            self.at_least_one_finite = False
+            self.y_finite = np.full(len(X), False)
+            return self.y_finite
+        self.at_least_one_finite = True
+        self.diff_threshold = diff_threshold
+        self._max_y = max(self.y_train)
+        self.y_finite = self._is_finite_raw(self.y_train, diff_threshold, max_y=self._max_y)
+        self.all_finite = bool(np.all(self.y_finite))
+        if not self.all_finite:
+            self._svc = SVC(random_state=self.random_state, **self._svc_args)
+            self._svc.fit(self.X_train, self.y_finite)
+        return self.y_finite
+
+    def predict(self, X, validate=True):
+        if self.y_train is None:
+            raise ValueError("The SVM has not been trained yet.")
+        X = np.atleast_2d(X)
+        if self.all_finite:
+            return np.full(len(X), True)
+        if not self.at_least_one_finite:
+            warnings.warn("Only -inf points added to the classifier so far. "
+                          "Returning False unconditionally.")
+            return np.full(len(X), False)
+        return self._svc.predict(X).astype(bool)

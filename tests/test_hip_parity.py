@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP path (through the C ABI / the host mirror) against
+(a) golden vectors captured from the real reference and (b) the pinned CPU oracle.
+
+Tolerances (BASELINE.json north_star: posterior mean/variance within 1e-6 rel,
+acquisition argmax identical): mean rel <= 1e-8, |d var| <= 1e-9 * C (variance compared
+relative to the prior variance C), LML rel <= 1e-10, gradient
+rel <= 1e-7 of its largest entry, kernel values rel <= 1e-13.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import gpry_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from gpry_amd import _lib
+    d = _lib.Device(0)
+    yield d
+    d.close()
+
+
+def relmax(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / (np.max(np.abs(b)) + 1e-300))
+
+
+# ---------------------------------------------------------------------------- MFMA engine
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_mfma_gemm_layout_asymmetric(dev, at, bt):
+    """A = I with an asymmetric B catches a transposed C/D fragment map."""
+    n = 128
+    B = np.arange(n * n, dtype=float).reshape(n, n) / 7.0
+    A = np.eye(n)
+    Ain = np.ascontiguousarray(A.T) if at else A
+    Bin = np.ascontiguousarray(B.T) if bt else B
+    np.testing.assert_array_equal(dev.debug_gemm(Ain, Bin, None, n, n, n, at, bt), B)
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((192, 320))
+    B = rng.standard_normal((320, 256))
+    Ain = np.ascontiguousarray(A.T) if at else A
+    Bin = np.ascontiguousarray(B.T) if bt else B
+    assert relmax(dev.debug_gemm(Ain, Bin, None, 192, 256, 320, at, bt), A @ B) < 1e-14
+
+
+def test_mfma_gemm_triangular_modes_and_sumsq(dev):
+    rng = np.random.default_rng(2)
+    n = 512
+    L = np.tril(rng.standard_normal((n, n)))
+    B = rng.standard_normal((n, 640))
+    ref = L @ B
+    ss = np.stack([np.sum(ref[t * 128:(t + 1) * 128] ** 2, axis=0) for t in range(n // 128)])
+    for tile_map in (0, 1):
+        got = dev.debug_gemm(L, B, None, n, 640, n, kmode=1, epi=3, tile_map=tile_map)
+        assert relmax(got, ss) < 1e-14
+    C0 = rng.standard_normal((n, n))
+    got = dev.debug_gemm(L, L, C0, n, n, n, b_trans=1, epi=2)   # C -= L L^T
+    assert relmax(got, C0 - L @ L.T) < 1e-13
+
+
+# ---------------------------------------------------------------------------- F1 kernels
+@pytest.mark.parametrize("kid", [0, 1, 2, 3])
+@pytest.mark.parametrize("d", [1, 2, 5])
+def test_f1_kernel_matrices_vs_reference(dev, kid, d):
+    g = load_golden("kernels")
+    p = f"f1_k{kid}_d{d}_"
+    X, Y, theta = g[p + "X"], g[p + "Y"], g[p + "theta"]
+    dev.set_train(X, np.zeros(len(X)), np.zeros(len(X)))
+    dev.set_theta(kid, theta)
+    K = dev.kernel_train(add_alpha=False)
+    np.testing.assert_allclose(K, g[p + "K"], rtol=1e-13, atol=0)
+    assert np.array_equal(K, K.T)
+    np.testing.assert_allclose(dev.kernel_cross(Y), g[p + "Kx"], rtol=1e-13, atol=0)
+    Ka = dev.kernel_train(add_alpha=True)
+    np.testing.assert_array_equal(Ka, K)  # alpha = 0 here
+
+
+# ---------------------------------------------------------------------------- F2 / F3
+@pytest.mark.parametrize("kid", [0, 1, 2, 3])
+def test_f2_factor_and_f3_lml_vs_reference(dev, kid):
+    g = load_golden("factor_lml")
+    p = f"f2_k{kid}_"
+    dev.set_train(g[p + "X_"], g[p + "y_"], g[p + "alpha"])
+    dev.set_theta(kid, g[p + "theta"])
+    assert dev.factorize() == 0
+    L, V, a = dev.get_factor()
+    assert not np.triu(L, 1).any() and not np.triu(V, 1).any()
+    np.testing.assert_allclose(L, g[p + "L"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(V, g[p + "V"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(a, g[p + "alpha_"], rtol=1e-8, atol=1e-9)
+    th = g[f"f3_k{kid}_theta"]
+    lml, grad, info = dev.lml(th, True)
+    assert info == 0
+    assert abs(lml - g[f"f3_k{kid}_lml"]) <= 1e-10 * abs(g[f"f3_k{kid}_lml"])
+    assert relmax(grad, g[f"f3_k{kid}_grad"]) < 1e-7
+    lml2, _ = dev.lml(th, False)
+    assert lml2 == lml
+    # the prediction factor is untouched by lml()
+    L2, _, _ = dev.get_factor(want_V=False, want_alpha=False)
+    np.testing.assert_array_equal(L, L2)
+
+
+def test_f3_non_positive_definite_convention(dev):
+    g = load_golden("factor_lml")
+    X_, y_, th = g["f3_nonpd_X_"], g["f3_nonpd_y_"], g["f3_nonpd_theta"]
+    dev.set_train(X_, y_, np.zeros(len(y_)))
+    lml, grad, info = dev.lml(th, True)
+    assert lml == -np.inf and not grad.any() and info > 0   # sklearn:_gpr.py:586-589
+    dev.set_theta(0, th)
+    assert dev.factorize() > 0
+
+
+# ---------------------------------------------------------------------------- F4 / F5 / F8
+def _oracle_model(g, p, kid, **kw):
+    m = orc.OracleGPR(g[p + "bounds"], kernel_id=kid, **kw)
+    m.theta = np.array(g[p + "theta"])
+    m.fitted = True
+    return m
+
+
+def _load_model(dev, m):
+    dev.set_train(m.X_train_, m.y_train_, m.alpha)
+    dev.set_theta(m.kernel_id, m.theta)
+    dev.set_affine(m.pre_X.lo, m.pre_X.hi - m.pre_X.lo, m.pre_y.mean_, m.pre_y.std_, m.clip_hi())
+    assert dev.factorize() == 0
+
+
+@pytest.mark.parametrize("kid", [0, 3])
+def test_f4_predict_clip_trust_vs_reference(dev, kid):
+    from gpry_amd import _lib
+    g = load_golden("predict")
+    p = f"f4_k{kid}_"
+    m = _oracle_model(g, p, kid, clip_factor=1.0)
+    m.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    Xc = g[p + "Xc"]
+    mean, std = dev.predict(Xc, return_std=True)
+    assert (mean == g[p + "clip_hi"]).sum() == (g[p + "mean"] == g[p + "clip_hi"]).sum() >= 1
+    np.testing.assert_allclose(mean, g[p + "mean"], rtol=1e-8, atol=1e-9)
+    C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
+    assert np.max(np.abs(std ** 2 - g[p + "std"] ** 2)) <= 1e-9 * C
+    np.testing.assert_allclose(dev.predict(Xc), mean, rtol=0, atol=0)
+    outside = ~orc.is_in_bounds(Xc, g[p + "trust_bounds"])
+    mask = outside.astype(np.uint8) * _lib.MASK_OUTSIDE_TRUST
+    mean_tr, std_tr = dev.predict(Xc, return_std=True, mask=mask)
+    assert np.array_equal(np.isneginf(mean_tr), np.isneginf(g[p + "mean_tr"]))
+    fin = np.isfinite(mean_tr)
+    np.testing.assert_allclose(mean_tr[fin], g[p + "mean_tr"][fin], rtol=1e-8, atol=1e-9)
+    assert np.max(np.abs(std_tr ** 2 - g[p + "std_tr"] ** 2)) <= 1e-9 * C
+
+
+def test_f4_classifier_mask_vs_reference(dev):
+    from gpry_amd import _lib
+    g = load_golden("predict")
+    p = "f4_svm_"
+    m = _oracle_model(g, p, 3)
+    m.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    mask = (~g[p + "finite"]).astype(np.uint8) * _lib.MASK_CLASSIFIED_INF
+    mean, std = dev.predict(g[p + "Xc"], return_std=True, mask=mask)
+    assert np.array_equal(np.isneginf(mean), np.isneginf(g[p + "mean"]))
+    fin = g[p + "finite"]
+    np.testing.assert_allclose(mean[fin], g[p + "mean"][fin], rtol=1e-8, atol=1e-9)
+    assert not std[~fin].any()
+    np.testing.assert_allclose(std, g[p + "std"], rtol=1e-6, atol=1e-9)
+
+
+def test_f5_logexp_through_the_sweep(dev):
+    """Drive the fused epilogue with a model whose (mean, std) are known, then compare the
+    acquisition with LogExp.f of the reference on those very values."""
+    g = load_golden("predict")
+    p = "f4_k3_"
+    m = _oracle_model(g, p, 3, clip_factor=1.0)
+    m.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    zeta, base, noise = float(g["f5_zeta"]), float(g["f5_baseline"]), float(g["f5_noise"])
+    out = dev.sweep_logexp(g[p + "Xc"], zeta, base, noise)
+    ref = orc.logexp_f(out["y"], out["sigma"], base, noise, zeta)
+    assert out["n_nan"] == 0
+    assert np.array_equal(np.isneginf(out["acq"]), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(out["acq"][fin], ref[fin], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["y"], g[p + "mean"], rtol=1e-8, atol=1e-9)
+
+
+def test_f8_append_rows_fixed_theta_vs_reference(dev):
+    g = load_golden("predict")
+    m = _oracle_model(g, "f8_", 2)
+    X, y, Xc = g["f8_X"], g["f8_y"], g["f8_Xc"]
+    m.append_to_data(X[:32], y[:32], fit_gpr=False, fit_preprocessors=True)
+    m.append_to_data(X[32:], y[32:], fit_gpr=False, fit_preprocessors=False)
+    _load_model(dev, m)
+    L, V, a = dev.get_factor()
+    np.testing.assert_allclose(L, g["f8_L"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(V, g["f8_V"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(a, g["f8_alpha_"], rtol=1e-8, atol=1e-9)
+    mean, std = dev.predict(Xc, return_std=True)
+    np.testing.assert_allclose(mean, g["f8_mean_after"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(std, g["f8_std_after"], rtol=1e-6, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------- oracle at size
+@pytest.mark.parametrize("N,d,kid,M", [(1, 1, 0, 1), (2, 3, 3, 5), (127, 4, 1, 129), (129, 2, 2, 127),
+                                       (1024, 8, 0, 2000), (1500, 32, 3, 300)])
+def test_pipeline_vs_oracle_ragged_sizes(dev, N, d, kid, M):
+    bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M, seed=N + d)
+    m = orc.OracleGPR(bounds, kernel_id=kid, normalize_y=(N > 1))
+    m.theta = np.log(np.array([4.0] + [0.3 + 0.01 * k for k in range(d)]))
+    m.fitted = True
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    rm, rs = m.predict(Xc, return_std=True)
+    mean, std = dev.predict(Xc, return_std=True)
+    C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
+    np.testing.assert_allclose(mean, rm, rtol=1e-8, atol=1e-8)
+    assert np.max(np.abs(std ** 2 - rs ** 2)) <= 1e-9 * C
+    th = m.theta + 0.05
+    lml, grad, info = dev.lml(th, True)
+    rl, rg = orc.log_marginal_likelihood(m.X_train_, m.y_train_, m.alpha, th, kid, True)
+    assert info == 0 and abs(lml - rl) <= 1e-10 * max(1.0, abs(rl))
+    assert np.max(np.abs(grad - rg)) <= 1e-7 * max(1.0, np.max(np.abs(rg)))
+    zeta = orc.auto_zeta(d)
+    out = dev.sweep_logexp(Xc, zeta, m.y_max, m.noise_level)
+    racq = orc.logexp_f(rm, rs, m.y_max, m.noise_level, zeta)
+    if np.isfinite(racq).any():
+        assert int(np.argmax(out["acq"])) == int(np.argmax(racq))   # acquisition argmax identical
+    K = min(M, 50)
+    top, bound = dev.sweep_topk(K)
+    order = np.lexsort((-np.arange(M), -out["acq"]))
+    np.testing.assert_array_equal(top["idx"], order[:K])
+    np.testing.assert_array_equal(top["acq"], out["acq"][order[:K]])
+    assert bound == (out["acq"][order[K]] if K < M else -np.inf)
+
+
+def test_topk_ties_exclusions_and_exhaustion(dev):
+    bounds, X, y, Xc = orc.synthetic_like_goldens(64, 2, 1000, seed=5)
+    Xc[100:110] = Xc[5]          # duplicated candidates -> tied acquisition values
+    m = orc.OracleGPR(bounds, kernel_id=0)
+    m.theta = np.log(np.array([4.0, 0.3, 0.3]))
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    out = dev.sweep_logexp(Xc, 0.5, m.y_max, m.noise_level)
+    acq = out["acq"]
+    assert len(np.unique(acq[100:110])) == 1
+    order = np.lexsort((-np.arange(1000), -acq))   # (acq desc, idx desc)
+    for K in (1, 7, 400, 1000, 5000):
+        top, bound = dev.sweep_topk(K)
+        k = min(K, 1000)
+        np.testing.assert_array_equal(top["idx"], order[:k])
+    excl = order[:13]
+    top, bound = dev.sweep_topk(20, exclude=excl)
+    np.testing.assert_array_equal(top["idx"], order[13:33])
+    assert bound == acq[order[33]]
+    # re-using the resident candidate set (X=None) gives the same sweep
+    out2 = dev.sweep_logexp(None, 0.5, m.y_max, m.noise_level, M=1000)
+    np.testing.assert_array_equal(out2["acq"], acq)
+
+
+def test_full_size_properties_config3(dev):
+    """BASELINE configs[2] sizes (N=4096, d=16, Matern-5/2): size-independent properties."""
+    N, d, M = 4096, 16, 20000
+    bounds, X, y, Xc = orc.synthetic_problem(N, d, M)
+    pre = orc.NormalizeBounds(bounds)
+    X_ = pre.transform(X)
+    ym, ys = y.mean(), y.std()
+    alpha = np.full(N, (1e-2 / ys) ** 2)
+    theta = np.log(np.array([4.0] + [0.3] * d))
+    dev.set_train(X_, (y - ym) / ys, alpha)
+    dev.set_theta(3, theta)
+    dev.set_affine(pre.lo, pre.hi - pre.lo, ym, ys, np.inf)
+    assert dev.factorize() == 0
+    L, V, a = dev.get_factor()
+    K = dev.kernel_train(add_alpha=True)
+    assert np.array_equal(K, K.T)
+    assert relmax(L @ L.T, K) < 1e-13                      # factor reproduces K + alpha I
+    assert np.max(np.abs(V @ L - np.eye(N))) < 1e-9         # V is the inverse factor
+    assert relmax(K @ a, (y - ym) / ys) < 1e-8              # alpha_ solves the system
+    # interpolation: at the training points the posterior mean is y up to the noise
+    mean, std = dev.predict(X[:512], return_std=True)
+    assert np.max(np.abs(mean - y[:512])) < 0.1
+    assert np.all(std < 0.1 * np.sqrt(np.exp(theta[0])) * ys)
+    # variance identity on a sample: var = C - |V k*|^2 with the exported V
+    Kx = dev.kernel_cross(pre.transform(Xc[:256]))
+    var_ref = np.exp(theta[0]) - np.sum((V @ Kx.T) ** 2, axis=0)
+    _, s = dev.predict(Xc[:256], return_std=True)
+    assert np.max(np.abs((s / ys) ** 2 - np.clip(var_ref, 0, None))) < 1e-10 * np.exp(theta[0])
+    # LML gradient against central finite differences of the device LML itself
+    lml, grad, info = dev.lml(theta, True)
+    for k in (0, 1, d):
+        e = np.zeros(d + 1)
+        e[k] = 1e-5
+        fd = (dev.lml(theta + e, False)[0] - dev.lml(theta - e, False)[0]) / 2e-5
+        assert abs(fd - grad[k]) <= 1e-5 * max(1.0, abs(grad[k]))

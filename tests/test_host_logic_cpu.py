@@ -1,0 +1,252 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, the
+product refuses to run without a device, and the host-side logic (kernel parameter
+algebra, pre-processors, LogExp, RankedPool control flow, shortlist merge across ranks)
+is checked with the oracle standing in for the device."""
+import os
+import re
+from functools import partial
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import gpry_oracle as orc
+
+
+def test_library_exports_every_declared_symbol():
+    from gpry_amd import _lib
+    header = open(os.path.join(ROOT, "include", "gpry_hip.h")).read()
+    declared = set(re.findall(r"\b(gpry_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    lib = _lib.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/gpry_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    assert lib.gpry_version() >= 100
+
+
+def test_product_fails_loudly_without_gpu():
+    from gpry_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.GpryHipError, match="no CPU fallback"):
+        _lib.Device(0)
+    from gpry_amd.gpr import GaussianProcessRegressor
+    b = np.array([[0.0, 1.0]] * 2)
+    gpr = GaussianProcessRegressor(kernel="RBF", bounds=b, account_for_inf=None)
+    with pytest.raises(_lib.GpryHipError):
+        gpr.append_to_data(np.random.rand(5, 2), np.random.rand(5), fit_gpr=False)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "gpry_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("test oracle", ""), f"{fn} mentions the oracle"
+
+
+@pytest.mark.parametrize("kid,name", [(0, "RBF"), (3, {"Matern": {"nu": 2.5}})])
+def test_kernel_parameter_algebra(kid, name):
+    from gpry_amd.gpr import GaussianProcessRegressor
+    from gpry_amd.preprocessing import Normalize_bounds, Normalize_y
+    g = load_golden("fit")
+    p = f"f6_k{kid}_"
+    b = g[p + "bounds"]
+    gpr = GaussianProcessRegressor(kernel=name, bounds=b, preprocessing_X=Normalize_bounds(b),
+                                   preprocessing_y=Normalize_y(), account_for_inf=None)
+    k = gpr.kernel
+    np.testing.assert_allclose(k.bounds, g[p + "theta_bounds"], rtol=1e-15)
+    d = len(b)
+    np.testing.assert_allclose(k.theta, np.log([10.0] + [0.1] * d), rtol=1e-14)
+    th = np.log(np.array([3.0] + [0.2 + 0.1 * i for i in range(d)]))
+    k2 = k.clone_with_theta(th)
+    np.testing.assert_allclose(k2.theta, th)
+    np.testing.assert_allclose(k.theta, np.log([10.0] + [0.1] * d))   # original untouched
+    assert k2.k1.constant_value == pytest.approx(3.0)
+    np.testing.assert_allclose(k2.k2.length_scale, np.exp(th[1:]))
+    kid_dev, th_full = k2.device_spec(d)
+    assert kid_dev == kid
+    np.testing.assert_allclose(th_full, th)
+    np.testing.assert_allclose(k2.grad_from_full(np.arange(d + 1.0), d), np.arange(d + 1.0))
+    np.testing.assert_allclose(k2.diag(np.zeros((4, d))), 3.0)
+    assert k2.n_dims == d + 1 and len(k2.hyperparameters) == 2
+
+
+def test_isotropic_and_fixed_hyperparameters_map_to_device_theta():
+    from gpry_amd.kernels import ConstantKernel, RBF
+    k = ConstantKernel(2.0, "fixed") * RBF(0.5, (1e-3, 10.0))
+    assert k.n_dims == 1
+    kid, full = k.device_spec(3)
+    np.testing.assert_allclose(full, np.log([2.0, 0.5, 0.5, 0.5]))
+    np.testing.assert_allclose(k.grad_from_full(np.array([9.0, 1.0, 2.0, 3.0]), 3), [6.0])
+    np.testing.assert_allclose(k.theta_to_full(np.log([0.25]), 3), np.log([2.0, 0.25, 0.25, 0.25]))
+
+
+def test_preprocessors_and_tools():
+    from gpry_amd.preprocessing import Normalize_bounds, Normalize_y, DummyPreprocessor
+    from gpry_amd.tools import get_Xnumber, is_in_bounds, shrink_bounds
+    b = np.array([[-5.0, 5.0], [0.0, 2.0]])
+    nb = Normalize_bounds(b)
+    X = np.array([[0.0, 1.0], [-5.0, 2.0]])
+    np.testing.assert_allclose(nb.transform(X), [[0.5, 0.5], [0.0, 1.0]])
+    np.testing.assert_allclose(nb.inverse_transform(nb.transform(X)), X)
+    np.testing.assert_allclose(nb.transform_bounds(b), [[0, 1], [0, 1]])
+    ny = Normalize_y()
+    with pytest.raises(TypeError):
+        ny.transform(np.ones(3))
+    y = np.array([1.0, 2.0, 4.0, -np.inf])
+    ny.fit(None, y)
+    assert ny.mean_ == pytest.approx(7 / 3) and ny.std_ == pytest.approx(np.std([1, 2, 4]))
+    np.testing.assert_allclose(ny.inverse_transform(ny.transform(y[:3])), y[:3])
+    assert DummyPreprocessor.transform(3) == 3
+    assert get_Xnumber("5d", "d", 4, int) == 20 and get_Xnumber("30d1.5", "d", 4, int) == 240
+    assert get_Xnumber("20s", "s", None, dtype=float) == (20.0, True, None)
+    assert list(is_in_bounds(X, b)) == [True, True] and not is_in_bounds([[6, 1]], b)[0]
+    got = shrink_bounds(b, np.array([[0.0, 0.5], [2.0, 1.5]]), factor=2)
+    np.testing.assert_allclose(got, orc.shrink_bounds(b, np.array([[0.0, 0.5], [2.0, 1.5]]), 2))
+
+
+def test_logexp_value_path_vs_reference_vectors():
+    from gpry_amd.acquisition_functions import LogExp
+    g = load_golden("predict")
+    af = LogExp(dimension=7)
+    assert af.zeta == float(g["f5_zeta"])
+    acq = LogExp.f(g["f5_mu"], g["f5_std"], float(g["f5_baseline"]), float(g["f5_noise"]), af.zeta)
+    assert np.array_equal(np.isneginf(acq), np.isneginf(g["f5_acq"]))
+    fin = np.isfinite(acq)
+    np.testing.assert_array_equal(acq[fin], g["f5_acq"][fin])
+
+
+# ---- RankedPool / NORA control flow with the oracle standing in for the device --------------
+class FakeDevice:
+    """Test double of gpry_amd._lib.Device for the sweep/top-k calls (numpy via the oracle)."""
+
+    def __init__(self, model):
+        self.m = model
+
+    def sweep_logexp(self, X, zeta, baseline, sigma_n, mask=None, M=None, want=()):
+        X = self._lastX if X is None else X     # X=None: candidate set still resident
+        self._lastX = X
+        y, s =self.m.predict(X, return_std=True) if len(X) else (np.empty(0), np.empty(0))
+        self.acq = orc.logexp_f(y, s, baseline, sigma_n, zeta)
+        self.y, self.s = y, s
+        return {"y": y, "sigma": s, "acq": self.acq, "n_nan": int(np.isnan(self.acq).sum())}
+
+    def sweep_topk(self, K, exclude=None):
+        from gpry_amd._lib import CAND_DTYPE
+        M = len(self.acq)
+        ok = np.ones(M, bool)
+        if exclude is not None:
+            ok[np.asarray(exclude, dtype=int)] = False
+        order = np.lexsort((-np.arange(M), -self.acq))
+        order = order[ok[order]]
+        top = np.zeros(min(K, len(order)), dtype=CAND_DTYPE)
+        sel = order[:K]
+        top["acq"], top["y"], top["sigma"], top["idx"] = self.acq[sel], self.y[sel], self.s[sel], sel
+        bound = self.acq[order[K]] if len(order) > K else -np.inf
+        return top, bound
+
+
+class FakeGPR:
+    """Quacks like gpry_amd.gpr.GaussianProcessRegressor where NORA / RankedPool touch it."""
+
+    def __init__(self, model):
+        self.m = model
+        self.device = FakeDevice(model)
+        self.d, self.n_eval, self.noise_level = model.d, 0, model.noise_level
+        self.infinities_classifier = None
+
+    y_max = property(lambda self: self.m.y_max)
+    n = property(lambda self: self.m.n)
+
+    def _ensure_factor(self):
+        pass
+
+    _push_affine = _ensure_factor
+
+    def _masks(self, X, validate, ignore):
+        return None
+
+    def predict(self, X, return_std=False, validate=True):
+        return self.m.predict(X, return_std=return_std)
+
+    def predict_std(self, X, validate=True):
+        return self.m.predict_std(X)
+
+    def conditioned(self, X, y):
+        c = FakeGPR(self.m.conditioned_copy(X, y))
+        return c
+
+    def append_to_data(self, X, y, **kw):
+        self.m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+
+
+def _golden_model(tag):
+    g = load_golden("multi_add")
+    p = f"f7{tag}_"
+    N, d = g[p + "X"].shape
+    bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, int(g[p + "M"]), int(g[p + "seed"]))
+    m = orc.OracleGPR(bounds, kernel_id=int(g[p + "kid"]))
+    m.theta = np.array(g[p + "theta"])
+    m.fitted = True
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    return g, p, bounds, Xc, m
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("shortlist", [4, 64, 100000])
+def test_nora_shortlist_stream_reproduces_reference_pool(tag, shortlist):
+    """The streamed shortlist (any initial size, incl. too small ones that must be
+    extended) gives exactly the reference's proposals, twice in a row."""
+    from gpry_amd.gp_acquisition import NORA
+    g, p, bounds, Xc, m = _golden_model(tag)
+    gpr = FakeGPR(m)
+    npts = len(g[p + "acq_cond"]) - 1
+    acq = NORA(bounds, sampler="uniform", mc_every=2, verbose=0, shortlist_size=shortlist)
+    acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+    Xp, yp, ap = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
+    np.testing.assert_array_equal(Xp, g[p + "X_pool"])
+    np.testing.assert_allclose(yp, g[p + "y_pool"], rtol=1e-9)
+    np.testing.assert_allclose(ap, g[p + "acq_pool"], rtol=1e-8)
+    np.testing.assert_allclose(acq.pool.acq_cond, g[p + "acq_cond"], rtol=1e-6)
+    assert acq.pool.cache_counter == int(g[p + "cache_counter"])
+    gpr.append_to_data(Xp, g[p + "y_new"])
+    Xp2, yp2, ap2 = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
+    np.testing.assert_array_equal(Xp2, g[p + "X_pool2"])
+    np.testing.assert_allclose(ap2, g[p + "acq_pool2"], rtol=1e-7)
+    assert len(acq.last_MC_sample(warn_reweight=False)[1]) == int(g[p + "n_rw"])
+
+
+def test_ranked_pool_mirror_equals_oracle_restatement():
+    from gpry_amd.gp_acquisition import RankedPool
+    g, p, bounds, Xc, m = _golden_model("a")
+    gpr = FakeGPR(m)
+    y, s = m.predict(Xc, return_std=True)
+    f = partial(orc.logexp_f, baseline=m.y_max, noise_level=m.noise_level, zeta=orc.auto_zeta(m.d))
+    a = f(y, s)
+    for method in ("single sort acq", "single sort y", "single", "bulk"):
+        sub = slice(0, 600)
+        mine = RankedPool(3, gpr=gpr, acq_func=f, verbose=0)
+        mine.add(Xc[sub], y[sub], s[sub], a[sub], method=method)
+        ref = orc.OracleRankedPool(3, m, f)
+        ref.add(Xc[sub], y[sub], s[sub], a[sub], method=method)
+        np.testing.assert_array_equal(mine.X, ref.X)
+        np.testing.assert_allclose(mine.acq_cond, ref.acq_cond, rtol=1e-12)
+    c = mine.copy(drop_empty=True)
+    assert len(c.X) <= 4 and not hasattr(c, "_gpr")
+    with pytest.raises(ValueError):
+        mine.add(Xc[:2], y[:2], s[:2], np.array([np.nan, 1.0]))
+
+
+def test_nora_argument_checks():
+    from gpry_amd.gp_acquisition import NORA, NestedSamplerNotInstalledError, builtin_names
+    b = np.array([[0.0, 1.0]] * 3)
+    with pytest.raises(NestedSamplerNotInstalledError):
+        NORA(b, sampler="polychord")
+    acq = NORA(b, sampler="uniform", verbose=0)
+    assert acq.mc_every == 3 and acq.nlive_max == 75 and acq.num_repeats == 15
+    assert acq.acq_func.zeta == 3 ** -0.85
+    with pytest.raises(ValueError):
+        acq.multi_add(None, n_points=0)
+    assert "NORA" in builtin_names()

@@ -1,0 +1,172 @@
+"""GPU tests of the drop-in classes (GaussianProcessRegressor / NORA / RankedPool mirrors)
+against golden vectors from the reference and against the oracle."""
+import copy
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import gpry_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KERNEL_SPEC = {0: "RBF", 1: {"Matern": {"nu": 0.5}}, 2: {"Matern": {"nu": 1.5}},
+               3: {"Matern": {"nu": 2.5}}}
+
+
+def make_gpr(bounds, kid, theta=None, **kw):
+    from gpry_amd.gpr import GaussianProcessRegressor
+    from gpry_amd.preprocessing import Normalize_bounds, Normalize_y
+    from gpry_amd.kernels import clone
+    kw.setdefault("account_for_inf", None)
+    gpr = GaussianProcessRegressor(kernel=KERNEL_SPEC[kid], bounds=bounds,
+                                   preprocessing_X=Normalize_bounds(bounds),
+                                   preprocessing_y=Normalize_y(), **kw)
+    if theta is not None:
+        k = clone(gpr.kernel)
+        k.theta = theta
+        gpr.kernel_ = k
+        gpr._fitted = True
+    return gpr
+
+
+@pytest.mark.parametrize("kid,N", [(0, 48), (3, 60)])
+def test_f6_fit_full_and_simple_vs_reference(kid, N):
+    g = load_golden("fit")
+    p = f"f6_k{kid}_"
+    gpr = make_gpr(g[p + "bounds"], kid, n_restarts_optimizer=4, random_state=3)
+    np.testing.assert_allclose(gpr.kernel.bounds, g[p + "theta_bounds"], rtol=1e-15)
+    X, y, Xc = g[p + "X"], g[p + "y"], g[p + "Xc"]
+    gpr.append_to_data(X[:N], y[:N], fit_gpr=True)
+    assert gpr.fitted and gpr.n == N
+    assert abs(gpr.log_marginal_likelihood_value_ - g[p + "lml_full"]) < 1e-5
+    np.testing.assert_allclose(gpr.kernel_.theta, g[p + "theta_full"], rtol=1e-3, atol=1e-3)
+    m, s = gpr.predict(Xc, return_std=True)
+    np.testing.assert_allclose(m, g[p + "mean_full"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(s, g[p + "std_full"], rtol=1e-4, atol=1e-5)
+    gpr.append_to_data(X[N:], y[N:], fit_gpr="simple")
+    assert abs(gpr.log_marginal_likelihood_value_ - g[p + "lml_simple"]) < 1e-4
+    m, s = gpr.predict(Xc, return_std=True)
+    np.testing.assert_allclose(m, g[p + "mean_simple"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(s, g[p + "std_simple"], rtol=1e-3, atol=1e-4)
+    assert gpr.n_eval == 2 * len(Xc) and gpr.n_eval_loglike > 10
+
+
+def test_f9_config1_curved_degeneracy():
+    g = load_golden("fit")
+    gpr = make_gpr(g["f9_bounds"], 0, n_restarts_optimizer=3, random_state=3)
+    gpr.append_to_data(g["f9_X"], g["f9_y"], fit_gpr=True)
+    assert abs(gpr.log_marginal_likelihood_value_ - g["f9_lml"]) < 1e-5
+    m, s = gpr.predict(g["f9_Xc"], return_std=True)
+    np.testing.assert_allclose(m, g["f9_mean"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(s, g["f9_std"], rtol=1e-4, atol=1e-6)
+
+
+def test_gpr_attributes_copy_pickle_and_errors():
+    g = load_golden("predict")
+    X, y, Xc = g["f8_X"], g["f8_y"], g["f8_Xc"]
+    gpr = make_gpr(g["f8_bounds"], 2, theta=g["f8_theta"])
+    gpr.append_to_data(X[:32], y[:32], fit_gpr=False)
+    np.testing.assert_allclose(gpr.predict_std(Xc), g["f8_std_before"], rtol=1e-6)
+    gpr.append_to_data(X[32:], y[32:], fit_gpr=False, fit_classifier=False)
+    np.testing.assert_allclose(gpr.X_train_, g["f8_X_train_"], rtol=1e-15)
+    np.testing.assert_allclose(gpr.y_train_, g["f8_y_train_"], rtol=1e-13)
+    np.testing.assert_allclose(gpr.L_, g["f8_L"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gpr.V_, g["f8_V"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(gpr.alpha_, g["f8_alpha_"], rtol=1e-8, atol=1e-9)
+    m, s = gpr.predict(Xc, return_std=True)
+    np.testing.assert_allclose(m, g["f8_mean_after"], rtol=1e-8, atol=1e-9)
+    assert gpr.n == 35 and gpr.d == 3 and gpr.y_max == y.max() and gpr.n_last_appended == 3
+    from sklearn.base import is_regressor
+    assert is_regressor(gpr)
+    for clone_ in (copy.deepcopy(gpr), pickle.loads(pickle.dumps(gpr))):
+        m2, s2 = clone_.predict(Xc, return_std=True)
+        np.testing.assert_allclose(m2, m, rtol=1e-12)
+        np.testing.assert_allclose(s2, s, rtol=1e-9, atol=1e-12)
+    # duplicated points + zero noise -> not positive definite -> LinAlgError with the hint
+    bad = make_gpr(g["f8_bounds"], 0, theta=np.log(np.array([1.0, 10.0, 10.0, 10.0])), noise_level=0.0)
+    Xd = np.vstack([X[:8], X[:8]])
+    with pytest.raises(np.linalg.LinAlgError, match="not returning a positive definite"):
+        bad.append_to_data(Xd, np.append(y[:8], y[:8]), fit_gpr=False)
+    with pytest.raises(NotImplementedError):
+        gpr.predict(Xc[:1], return_mean_grad=True)
+
+
+def test_conditioned_models_match_refactorised_oracle():
+    """Bordered factor == deepcopy + append_to_data(fit_gpr=False) of the reference path."""
+    bounds, X, y, Xc = orc.synthetic_like_goldens(200, 4, 300, seed=77)
+    theta = np.log(np.array([4.0, 0.3, 0.25, 0.4, 0.35]))
+    ref = orc.OracleGPR(bounds, kernel_id=3)
+    ref.theta = theta.copy()
+    ref.fitted = True
+    ref.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    gpr = make_gpr(bounds, 3, theta=theta)
+    gpr.append_to_data(X, y, fit_gpr=False)
+    pts = Xc[:5]
+    lies = ref.predict(pts)
+    C = np.exp(theta[0]) * ref.pre_y.std_ ** 2
+    for k in (1, 3, 5):
+        cm = gpr.conditioned(pts[:k], lies[:k])
+        rc = ref.conditioned_copy(pts[:k], lies[:k])
+        got, want = cm.predict_std(Xc), rc.predict_std(Xc)
+        assert np.max(np.abs(got ** 2 - want ** 2)) <= 1e-9 * C
+        # conditioning on a point collapses the variance there to about the noise level
+        assert np.all(got[:k] < 2 * ref.noise_level)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_f7_nora_multi_add_vs_reference(tag):
+    from gpry_amd.gp_acquisition import NORA
+    g = load_golden("multi_add")
+    p = f"f7{tag}_"
+    kid, M = int(g[p + "kid"]), int(g[p + "M"])
+    N, d = g[p + "X"].shape
+    bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M, int(g[p + "seed"]))
+    gpr = make_gpr(bounds, kid, theta=g[p + "theta"])
+    gpr.append_to_data(X, y, fit_gpr=False)
+    npts = len(g[p + "acq_cond"]) - 1
+    acq = NORA(bounds, sampler="uniform", mc_every=2, verbose=0, shortlist_size=32)
+    acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+    Xp, yp, ap = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
+    Xmc, ymc, smc, _ = acq.last_MC_sample(warn_reweight=False)
+    np.testing.assert_allclose(ymc, g[p + "y_mc"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(smc, g[p + "sigma_mc"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal(Xp, g[p + "X_pool"])       # same proposals, same order
+    np.testing.assert_allclose(yp, g[p + "y_pool"], rtol=1e-8)
+    np.testing.assert_allclose(ap, g[p + "acq_pool"], rtol=1e-7)
+    np.testing.assert_allclose(acq.pool.acq_cond, g[p + "acq_cond"], rtol=1e-5)
+    # second call: re-used sample, reweighting, already-proposed rows excluded
+    gpr.append_to_data(Xp, g[p + "y_new"], fit_gpr=False)
+    Xp2, yp2, ap2 = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
+    np.testing.assert_array_equal(Xp2, g[p + "X_pool2"])
+    np.testing.assert_allclose(yp2, g[p + "y_pool2"], rtol=1e-7)
+    np.testing.assert_allclose(ap2, g[p + "acq_pool2"], rtol=1e-6)
+    Xr, yr, sr, wr = acq.last_MC_sample(warn_reweight=False)
+    assert len(yr) == int(g[p + "n_rw"])
+    assert abs(wr.sum() - g[p + "w_rw_sum"]) <= 1e-7 * g[p + "w_rw_sum"]
+
+
+def test_ranked_pool_methods_agree_with_oracle():
+    """RankedPool 'bulk' and 'single sort acq' on the device vs the oracle restatement."""
+    from functools import partial
+    from gpry_amd.gp_acquisition import RankedPool
+    from gpry_amd.acquisition_functions import LogExp
+    bounds, X, y, Xc = orc.synthetic_like_goldens(160, 8, 3000, seed=42)
+    theta = np.log(np.array([4.0] + [0.3] * 8))
+    ref = orc.OracleGPR(bounds, kernel_id=0)
+    ref.theta = theta.copy()
+    ref.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    gpr = make_gpr(bounds, 0, theta=theta)
+    gpr.append_to_data(X, y, fit_gpr=False)
+    ym, sm = gpr.predict(Xc, return_std=True)
+    zeta = orc.auto_zeta(8)
+    f = partial(LogExp.f, baseline=gpr.y_max, noise_level=gpr.noise_level, zeta=zeta)
+    a = f(ym, sm)
+    for method in ("single sort acq", "bulk"):
+        pool = RankedPool(8, gpr=gpr, acq_func=f, verbose=0)
+        pool.add(Xc, ym, sm, a, method=method)
+        rp = orc.OracleRankedPool(8, ref, f)
+        rp.add(Xc, ym, sm, a, method=method)
+        np.testing.assert_array_equal(pool.X, rp.X)
+        np.testing.assert_allclose(pool.acq_cond[:8], rp.acq_cond[:8], rtol=1e-6)
