@@ -3,68 +3,76 @@
 //   * cross-kernel panel  K*^T (k-major) + mean partials   gpry/gpr.py:1179-1180
 //   * LML gradient traces 1/2 tr((aa^T - K^-1) dK/dtheta)  sklearn:_gpr.py:625-649
 // Kernel algebra restated from sklearn:kernels.py:1553-1580 (RBF), :1708-1768 (Matern),
-// :1239-1291 (Constant), :931-966 (Product).
+// :1239-1291 (Constant), :931-966 (Product).  All kernels are templated on the kernel
+// family so that the per-pair code has no branches.
 #include "common.h"
 
 struct KernParams {
     double C;
-    int kernel_id, d, dpad, has_aff;
+    int d, dpad, has_aff;
     int64_t N;
 };
 struct AffParams {
-    double inv_l[GPRY_MAX_DIM];   // unused slots = 0
+    double ls[GPRY_MAX_DIM];     // length scales (unused slots = 1)
     double lo[GPRY_MAX_DIM];
     double span[GPRY_MAX_DIM];
 };
 
-__device__ __forceinline__ double corr_r2(int kid, double r2) {
-    switch (kid) {
-        case GPRY_RBF: return exp(-0.5 * r2);
-        case GPRY_MATERN12: return exp(-sqrt(r2));
-        case GPRY_MATERN32: { double t = sqrt(r2) * 1.7320508075688772; return (1.0 + t) * exp(-t); }
-        default: { double t = sqrt(r2) * 2.23606797749979; return (1.0 + t + t * t / 3.0) * exp(-t); }
-    }
+#define SQRT3 1.7320508075688772
+#define SQRT5 2.23606797749979
+
+template <int KID>
+__device__ __forceinline__ double corr_r2(double r2) {
+    if (KID == GPRY_RBF) return exp(-0.5 * r2);
+    if (KID == GPRY_MATERN12) return exp(-sqrt(r2));
+    if (KID == GPRY_MATERN32) { double t = sqrt(r2) * SQRT3; return (1.0 + t) * exp(-t); }
+    double t = sqrt(r2) * SQRT5;
+    return (1.0 + t + t * t * (1.0 / 3.0)) * exp(-t);
 }
 // returns k(r) in *kval and h with d k / d log l_k = h * D_k   (both without the factor C)
-__device__ __forceinline__ double corr_and_h(int kid, double r2, double* kval) {
-    switch (kid) {
-        case GPRY_RBF: { double e = exp(-0.5 * r2); *kval = e; return e; }
-        case GPRY_MATERN12: {
-            double r = sqrt(r2); double e = exp(-r); *kval = e;
-            return r != 0.0 ? e / r : 0.0;
-        }
-        case GPRY_MATERN32: {
-            double t = sqrt(r2) * 1.7320508075688772; double e = exp(-t);
-            *kval = (1.0 + t) * e;
-            return 3.0 * exp(-sqrt(3.0 * r2));
-        }
-        default: {
-            double t = sqrt(r2) * 2.23606797749979; double e = exp(-t);
-            *kval = (1.0 + t + t * t / 3.0) * e;
-            double t2 = sqrt(5.0 * r2);
-            return 5.0 / 3.0 * (t2 + 1.0) * exp(-t2);
-        }
+template <int KID>
+__device__ __forceinline__ double corr_and_h(double r2, double* kval) {
+    if (KID == GPRY_RBF) { double e = exp(-0.5 * r2); *kval = e; return e; }
+    if (KID == GPRY_MATERN12) {
+        double r = sqrt(r2); double e = exp(-r); *kval = e;
+        return r != 0.0 ? e / r : 0.0;
     }
+    if (KID == GPRY_MATERN32) {
+        double t = sqrt(r2) * SQRT3; double e = exp(-t);
+        *kval = (1.0 + t) * e;
+        return 3.0 * e;
+    }
+    double t = sqrt(r2) * SQRT5; double e = exp(-t);
+    *kval = (1.0 + t + t * t * (1.0 / 3.0)) * e;
+    return (5.0 / 3.0) * (t + 1.0) * e;
 }
 
 static KernParams make_kp(gpry_ctx* ctx) {
     KernParams kp;
     kp.C = exp(ctx->theta[0]);
-    kp.kernel_id = ctx->kernel_id; kp.d = ctx->d; kp.dpad = ctx->dpad;
+    kp.d = ctx->d; kp.dpad = ctx->dpad;
     kp.has_aff = ctx->tf.has_x_affine; kp.N = ctx->N;
     return kp;
 }
 static AffParams make_ap(gpry_ctx* ctx, bool use_affine) {
     AffParams ap;
     for (int k = 0; k < GPRY_MAX_DIM; k++) {
-        // sklearn divides by the length scale: x / l.  Keep the division (not a
-        // reciprocal multiply) so scaled coordinates round identically.
-        ap.inv_l[k] = k < ctx->d ? exp(ctx->theta[1 + k]) : 1.0;
+        // sklearn divides by the length scale (x / l); we keep the division, not a reciprocal
+        // multiply, so that scaled coordinates round identically.
+        ap.ls[k] = k < ctx->d ? exp(ctx->theta[1 + k]) : 1.0;
         ap.lo[k] = (use_affine && k < ctx->d) ? ctx->tf.x_lo[k] : 0.0;
         ap.span[k] = (use_affine && k < ctx->d) ? ctx->tf.x_span[k] : 1.0;
     }
     return ap;
 }
+
+#define DISPATCH_KID(kid, CALL)                         \
+    switch (kid) {                                      \
+        case GPRY_RBF: { CALL(GPRY_RBF); break; }       \
+        case GPRY_MATERN12: { CALL(GPRY_MATERN12); break; } \
+        case GPRY_MATERN32: { CALL(GPRY_MATERN32); break; } \
+        default: { CALL(GPRY_MATERN52); break; }        \
+    }
 
 // ------------------------------------------------------------------------------------
 __global__ void scale_train_kernel(const double* __restrict__ X, double* __restrict__ Xs,
@@ -73,7 +81,7 @@ __global__ void scale_train_kernel(const double* __restrict__ X, double* __restr
     if (idx >= Np * dpad) return;
     int64_t i = idx / dpad; int k = (int)(idx - i * dpad);
     double v = 0.0;
-    if (i < N && k < d) v = X[i * d + k] / ap.inv_l[k];
+    if (i < N && k < d) v = X[i * d + k] / ap.ls[k];
     Xs[idx] = v;
 }
 
@@ -96,7 +104,9 @@ __device__ __forceinline__ void tri_decode(int64_t t, int* bi, int* bj) {
 
 // One 64x64 tile of K per workgroup (lower block triangle); each thread owns a 4x4
 // patch.  Off-diagonal tiles are mirrored through an LDS transpose so that both the
-// (bi,bj) and (bj,bi) images are written as full 512-byte row segments.
+// (bi,bj) and (bj,bi) images are written as full 512-byte row segments with 16-byte
+// stores.  Algorithmic traffic: read X once (8 N d), write K once (8 N^2).
+template <int KID>
 __global__ __launch_bounds__(256) void kernel_train_kernel(
     const double* __restrict__ Xs, const double* __restrict__ noise, double* __restrict__ K,
     int64_t ld, KernParams kp, int add_noise) {
@@ -118,9 +128,10 @@ __global__ __launch_bounds__(256) void kernel_train_kernel(
 #pragma unroll
         for (int b = 0; b < 4; b++) r2[a][b] = 0.0;
     for (int k = 0; k < dp; k++) {
-        double xi[4], xj[4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) { xi[a] = Xi[k * 64 + ty * 4 + a]; xj[a] = Xj[k * 64 + tx * 4 + a]; }
+        const double2* pi = reinterpret_cast<const double2*>(Xi + k * 64 + ty * 4);
+        const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + tx * 4);
+        double2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
+        double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -132,13 +143,9 @@ __global__ __launch_bounds__(256) void kernel_train_kernel(
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             int64_t i = (int64_t)bi * 64 + ty * 4 + a, j = (int64_t)bj * 64 + tx * 4 + b;
-            double v;
-            if (i < kp.N && j < kp.N) {
-                v = kp.C * (i == j ? 1.0 : corr_r2(kp.kernel_id, r2[a][b]));
-                if (i == j && add_noise) v += noise[i];
-            } else {
-                v = (i == j) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
-            }
+            double v = kp.C * corr_r2<KID>(r2[a][b]);
+            if (i == j) v = kp.C + (add_noise ? noise[i < kp.N ? i : 0] : 0.0);
+            if (i >= kp.N || j >= kp.N) v = (i == j) ? 1.0 : 0.0;   // identity padding
             val[a][b] = v;
         }
 #pragma unroll
@@ -149,19 +156,19 @@ __global__ __launch_bounds__(256) void kernel_train_kernel(
         p[1] = make_double2(val[a][2], val[a][3]);
     }
     if (bi == bj) return;
-    __syncthreads();            // X tiles no longer needed: reuse LDS as a [64][65] transpose pad
+    __syncthreads();            // X tiles no longer needed: reuse LDS as a [64][66] transpose pad
     double* T = sm;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) T[(tx * 4 + b) * 65 + ty * 4 + a] = val[a][b];
+        for (int b = 0; b < 4; b++) T[(tx * 4 + b) * 66 + ty * 4 + a] = val[a][b];
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         int jr = ty * 4 + a;   // row of the mirrored tile (a column index j of K)
-        double* p = K + ((int64_t)bj * 64 + jr) * ld + (int64_t)bi * 64 + tx * 4;
-#pragma unroll
-        for (int b = 0; b < 4; b++) p[b] = T[jr * 65 + tx * 4 + b];
+        double2* p = reinterpret_cast<double2*>(K + ((int64_t)bj * 64 + jr) * ld + (int64_t)bi * 64 + tx * 4);
+        const double2* q = reinterpret_cast<const double2*>(T + jr * 66 + tx * 4);
+        p[0] = q[0]; p[1] = q[1];
     }
 }
 
@@ -169,9 +176,11 @@ int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
     KernParams kp = make_kp(ctx);
     int64_t nb = ctx->Np / 64;
     int64_t ntile = nb * (nb + 1) / 2;
-    size_t smem = sizeof(double) * (size_t)((2 * ctx->dpad * 64 > 64 * 65) ? 2 * ctx->dpad * 64 : 64 * 65);
-    hipLaunchKernelGGL(kernel_train_kernel, dim3((unsigned)ntile), dim3(256), smem, ctx->stream,
-                       ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise);
+    size_t smem = sizeof(double) * (size_t)((2 * ctx->dpad * 64 > 64 * 66) ? 2 * ctx->dpad * 64 : 64 * 66);
+#define KT(KID) hipLaunchKernelGGL((kernel_train_kernel<KID>), dim3((unsigned)ntile), dim3(256), smem, \
+                                   ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise)
+    DISPATCH_KID(ctx->kernel_id, KT)
+#undef KT
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -182,7 +191,7 @@ int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
 // registers, the training chunk sits in LDS and is read wave-uniformly (broadcast).
 // Output Kst[j*ldk + m] = C k(x*_m, x_j) (rows j >= N are zero) and the per-chunk mean
 // partial  mean_part[jc*mc + m] = sum_{j in chunk} alpha_[j] * Kst[j][m].
-template <int DP>
+template <int DP, int KID>
 __global__ __launch_bounds__(256) void cross_build_kernel(
     const double* __restrict__ Xc, int64_t M, int64_t m0, int64_t mc,
     const double* __restrict__ Xs, const double* __restrict__ alpha_,
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
         if (k < kp.d && m < M) {
             v = Xc[m * kp.d + k];
             if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
-            v = v / ap.inv_l[k];
+            v = v / ap.ls[k];
         }
         xs[k] = v;
     }
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             int64_t j = (int64_t)jc * 128 + j0 + q;
-            double v = (j < kp.N) ? kp.C * corr_r2(kp.kernel_id, r2[q]) : 0.0;
+            double v = (j < kp.N) ? kp.C * corr_r2<KID>(r2[q]) : 0.0;
             macc = fma(al[j0 + q], v, macc);
             if (in_chunk) Kst[j * ldk + ml] = v;
         }
@@ -241,14 +250,14 @@ int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, 
     AffParams ap = make_ap(ctx, kp.has_aff);
     dim3 grid((unsigned)((mc + 255) / 256), (unsigned)(ctx->Np / 128));
     int64_t M = ctx->sw_M;
-#define CB(DP) hipLaunchKernelGGL((cross_build_kernel<DP>), grid, dim3(256), 0, ctx->stream, Xc, M, m0, mc, \
-                                  ctx->dXs, ctx->dalpha_, Kst, ldk, mean_part, kp, ap)
-    if (ctx->d <= 4) CB(4);
-    else if (ctx->d <= 8) CB(8);
-    else if (ctx->d <= 16) CB(16);
-    else if (ctx->d <= 32) CB(32);
-    else return gpry_fail(ctx, -1, "d > 32 is not supported");
-#undef CB
+    if (ctx->d > 32) return gpry_fail(ctx, -1, "d > 32 is not supported");
+#define CB2(DP, KID) hipLaunchKernelGGL((cross_build_kernel<DP, KID>), grid, dim3(256), 0, ctx->stream, Xc, M, \
+                                        m0, mc, ctx->dXs, ctx->dalpha_, Kst, ldk, mean_part, kp, ap)
+#define CB4(KID) { if (ctx->d <= 4) CB2(4, KID); else if (ctx->d <= 8) CB2(8, KID); \
+                   else if (ctx->d <= 16) CB2(16, KID); else CB2(32, KID); }
+    DISPATCH_KID(ctx->kernel_id, CB4)
+#undef CB4
+#undef CB2
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -257,14 +266,14 @@ int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, 
 // LML gradient traces.  One 64x64 tile of pairs per workgroup (lower block triangle,
 // off-diagonal tiles weighted twice).  W_ij = a_i a_j - Kinv_ij is read once (Kinv holds
 // the lower triangle); distances are recomputed from the scaled coordinates, so the
-// (N,N,d) tensor of the reference never exists.  Per-tile partial sums are written to
-// part[tile][DP+1] and reduced in a fixed order by reduce_traces_kernel (deterministic).
-template <int DP>
+// (N,N,d) tensor of the reference never exists.  Per-tile partial sums go to
+// part[tile][DP+1]; reduce_traces_kernel sums them in a fixed order (deterministic).
+template <int DP, int KID>
 __global__ __launch_bounds__(256) void lml_traces_kernel(
     const double* __restrict__ Xs, const double* __restrict__ Kinv, int64_t ld,
     const double* __restrict__ alpha, double* __restrict__ part, KernParams kp) {
-    __shared__ double Xi[DP * 64];
-    __shared__ double Xj[DP * 64];
+    __shared__ __attribute__((aligned(16))) double Xi[DP * 64];
+    __shared__ __attribute__((aligned(16))) double Xj[DP * 64];
     __shared__ double ai[64], aj[64];
     __shared__ double red[4][DP + 1];
     int bi, bj; tri_decode(blockIdx.x, &bi, &bj);
@@ -291,8 +300,11 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
 #pragma unroll
         for (int k = 0; k < DP; k++) {
             double xi = Xi[k * 64 + il];
+            const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + tx * 4);
+            double2 j0 = pj[0], j1 = pj[1];
+            double xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
-            for (int b = 0; b < 4; b++) { double df = xi - Xj[k * 64 + tx * 4 + b]; r2[b] = fma(df, df, r2[b]); }
+            for (int b = 0; b < 4; b++) { double df = xi - xj[b]; r2[b] = fma(df, df, r2[b]); }
         }
         double wh[4];
 #pragma unroll
@@ -303,8 +315,8 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
             if (i < kp.N && j < kp.N) {
                 int64_t hi = i > j ? i : j, lo = i > j ? j : i;
                 w = ai[il] * aj[jl] - Kinv[hi * ld + lo];
-                h = corr_and_h(kp.kernel_id, r2[b], &kv);
-                if (i == j) { kv = 1.0; }
+                h = corr_and_h<KID>(r2[b], &kv);
+                if (i == j) kv = 1.0;
             }
             g[0] = fma(w, kp.C * kv, g[0]);
             wh[b] = w * kp.C * h;
@@ -312,9 +324,12 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
 #pragma unroll
         for (int k = 0; k < DP; k++) {
             double xi = Xi[k * 64 + il];
+            const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + tx * 4);
+            double2 j0 = pj[0], j1 = pj[1];
+            double xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                double df = xi - Xj[k * 64 + tx * 4 + b];
+                double df = xi - xj[b];
                 g[1 + k] = fma(wh[b], df * df, g[1 + k]);
             }
         }
@@ -335,19 +350,20 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
     }
 }
 
-__global__ void reduce_traces_kernel(const double* __restrict__ part, int64_t ntile, int stride,
-                                     int nout, double* __restrict__ out) {
-    // one thread per hyperparameter; fixed summation order over tiles
-    int k = threadIdx.x;
-    if (k >= nout) return;
-    double s = 0.0, c = 0.0;  // Kahan: thousands of tile partials of mixed sign
-    for (int64_t t = 0; t < ntile; t++) {
-        double y = part[t * stride + k] - c;
-        double u = s + y;
-        c = (u - s) - y;
-        s = u;
+// one workgroup per hyperparameter: strided partial sums then a fixed LDS tree
+__global__ __launch_bounds__(256) void reduce_traces_kernel(const double* __restrict__ part, int64_t ntile,
+                                                            int stride, double* __restrict__ out) {
+    __shared__ double red[256];
+    const int k = blockIdx.x, t = threadIdx.x;
+    double s = 0.0;
+    for (int64_t i = t; i < ntile; i += 256) s += part[i * stride + k];
+    red[t] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
     }
-    out[k] = 0.5 * s;
+    if (t == 0) out[k] = 0.5 * red[0];
 }
 
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, double* grad_out_dev) {
@@ -362,14 +378,16 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, do
         GPRY_TRY(dev_alloc(ctx, &ctx->dpart, need));
         ctx->part_cap = need;
     }
-#define LT(DP) hipLaunchKernelGGL((lml_traces_kernel<DP>), dim3((unsigned)ntile), dim3(256), 0, ctx->stream, \
-                                  ctx->dXs, Kinv, ctx->Np, alpha, ctx->dpart, kp)
-    switch (DPsel) { case 4: LT(4); break; case 8: LT(8); break; case 16: LT(16); break;
-                     default: LT(32); }
-#undef LT
+#define LT2(DP, KID) hipLaunchKernelGGL((lml_traces_kernel<DP, KID>), dim3((unsigned)ntile), dim3(256), 0, \
+                                        ctx->stream, ctx->dXs, Kinv, ctx->Np, alpha, ctx->dpart, kp)
+#define LT4(KID) { if (DPsel == 4) LT2(4, KID); else if (DPsel == 8) LT2(8, KID); \
+                   else if (DPsel == 16) LT2(16, KID); else LT2(32, KID); }
+    DISPATCH_KID(ctx->kernel_id, LT4)
+#undef LT4
+#undef LT2
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(reduce_traces_kernel, dim3(1), dim3(128), 0, ctx->stream, ctx->dpart, ntile,
-                       DPsel + 1, ctx->d + 1, grad_out_dev);
+    hipLaunchKernelGGL(reduce_traces_kernel, dim3((unsigned)(ctx->d + 1)), dim3(256), 0, ctx->stream,
+                       ctx->dpart, ntile, DPsel + 1, grad_out_dev);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

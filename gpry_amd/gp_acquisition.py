@@ -437,6 +437,10 @@ class RankedPool:
         if acq is None:
             acq = self._acq_func(y, sigma)
         m = method.lower()
+        if hasattr(self._gpr, "kb_session") and 0 < len(X) <= 16384:
+            # one device pass computes u(x) = V k*(x) for the whole offer; conditioned
+            # standard deviations are then look-ups (gpry_amd/kriging.py)
+            self._gpr.kb_session().register(X)
         if m == "bulk":
             return self.add_bulk(X, y, sigma, acq)
         if not m.startswith("single"):
