@@ -40,7 +40,7 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
     } else {
         {
             StageScope s(ctx, "potrf");
-            GPRY_TRY(potrf_lower(ctx, A, ctx->Np));
+            GPRY_TRY(ctx->opt_chol == 2 ? potrf_lower(ctx, A, ctx->Np) : potrf_lower_fused(ctx, A, ctx->Np));
         }
         {
             StageScope s(ctx, "trtri");

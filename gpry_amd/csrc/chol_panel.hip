@@ -1,0 +1,226 @@
+// Fused Cholesky panel step for gfx950: ONE launch per 64 columns does, for every 64-row
+// block of the panel (workgroup = block, 4 waves):
+//     B   <- A[rows, j0:j0+64] - A[rows, K0:j0] * A[j0:j0+64, K0:j0]^T     (left-looking update)
+//     Lkk <- chol(D)   with D the same update of the diagonal block (every workgroup
+//                       recomputes it: 64x64, cheaper than a second launch + dependency)
+//     X   <- B * Lkk^-T                                                     (dtrsm R,L,T,N)
+// Inside the workgroup everything is blocked by 16: the 16x16 diagonal factors run in a
+// single wave (shuffles), the 16-wide triangular solves are lane-per-row substitutions
+// (same operation order as LAPACK dpotf2/dtrsm: scale by the reciprocal pivot), and all
+// rank-16 updates are v_mfma_f64_16x16x4_f64.  LDS images use a row stride of 66 doubles:
+// MFMA fragment reads (16 rows x {k, k+1}) then hit 32 distinct bank pairs.
+#include "common.h"
+
+#define PLD 66
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// acc += sign * A[16 x K] * B[16 x K]^T ; A, B point at row 0 of their 16-row blocks in LDS
+template <bool NEG>
+__device__ __forceinline__ v4d mfma_nt16(v4d acc, const double* A, const double* B, int K, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        double a = A[r * PLD + k0 + g];
+        double b = B[r * PLD + k0 + g];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -a : a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// C/D fragment (row = g + 4q, col = r) <-> LDS tile at T (row 0, col 0 of the tile)
+__device__ __forceinline__ v4d tile_load(const double* T, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    v4d v;
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = T[(g + 4 * q) * PLD + r];
+    return v;
+}
+__device__ __forceinline__ void tile_store(double* T, v4d v, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; q++) T[(g + 4 * q) * PLD + r] = v[q];
+}
+
+// Cholesky of the 16x16 block at S (LDS, stride PLD) by one full wave: lane (i, cq) keeps
+// S[i][4cq .. 4cq+3] in registers; column j is finished with three shuffles per lane.
+// Writes L (lower, zeros above).  Returns the first failing column + 1 (0 if ok).
+__device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
+    const int i = lane & 15, cq = lane >> 4;
+    double x[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) x[c] = S[i * PLD + cq * 4 + c];
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int jq = j >> 2, jj = j & 3;
+        double sij = __shfl(x[jj], i + 16 * jq);      // S[i][j]
+        double djj = __shfl(x[jj], j + 16 * jq);      // S[j][j]
+        if (!(djj > 0.0) && bad == 0) bad = j + 1;    // dpotf2: ajj <= 0 or NaN
+        // reciprocal pivot first (one rsqrt instead of sqrt + divide on the critical path);
+        // dpotf2 likewise scales the column by 1/ajj
+        double rinv = rsqrt(djj);
+        double piv = djj * rinv;
+        double lij = sij * rinv;
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            const int c = cq * 4 + cc;
+            double lcj = __shfl(x[jj], c + 16 * jq) * rinv;   // L[c][j]
+            if (c > j) x[cc] = fma(-lij, lcj, x[cc]);
+        }
+        if (cq == jq) x[jj] = (i == j) ? piv : (i > j ? lij : 0.0);
+        if (cq == jq && i == j) rd[j] = rinv;          // reciprocal pivots for the solves
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) S[i * PLD + cq * 4 + c] = x[c];
+    return bad;
+}
+
+// x <- x * L^-T for the 16 rows at Xr against the 16x16 lower factor at L (both LDS):
+// lanes 0..15 take one row each (forward substitution, reciprocal-pivot scaling)
+__device__ __forceinline__ void trsm16_rows(double* Xr, const double* L, const double* rd, int lane) {
+    const int i = lane & 15;
+    double x[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = Xr[i * PLD + c];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        // axpy form: the 15-c updates of a step are independent (short dependency chain)
+        x[c] = x[c] * rd[c];
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; c2++) x[c2] = fma(-x[c], L[c2 * PLD + c], x[c2]);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) Xr[i * PLD + c] = x[c];
+    }
+}
+
+__device__ __forceinline__ void load_block(const double* __restrict__ G, int64_t ld, double* S, int t) {
+    for (int e = t; e < 64 * 32; e += 256) {
+        int row = e >> 5, c2 = (e & 31) * 2;
+        double2 v = *reinterpret_cast<const double2*>(G + (int64_t)row * ld + c2);
+        *reinterpret_cast<double2*>(S + row * PLD + c2) = v;
+    }
+}
+__device__ __forceinline__ void store_block(double* __restrict__ G, int64_t ld, const double* S, int t,
+                                            bool lower_only) {
+    for (int e = t; e < 64 * 32; e += 256) {
+        int row = e >> 5, c2 = (e & 31) * 2;
+        double2 v = *reinterpret_cast<const double2*>(S + row * PLD + c2);
+        double* p = G + (int64_t)row * ld + c2;
+        if (!lower_only || c2 + 1 <= row) *reinterpret_cast<double2*>(p) = v;
+        else if (c2 <= row) p[0] = v.x;
+    }
+}
+
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int64_t ld, int64_t j0,
+                                                         int64_t K0, int64_t n_real, int* info) {
+    __shared__ __attribute__((aligned(16))) double sD[64 * PLD];
+    __shared__ __attribute__((aligned(16))) double sB[64 * PLD];
+    __shared__ __attribute__((aligned(16))) double sPt[64 * PLD];
+    __shared__ __attribute__((aligned(16))) double sPo[64 * PLD];
+    __shared__ double sRd[64];
+    __shared__ int s_bad;
+    if (*info != 0) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const bool is_diag = blockIdx.x == 0;
+    const int64_t R = j0 + 64 * (int64_t)blockIdx.x;
+    const int kprev = (int)(j0 - K0);          // 0 or 64
+    if (t == 0) s_bad = 0;
+    load_block(A + j0 * ld + j0, ld, sD, t);
+    if (!is_diag) load_block(A + R * ld + j0, ld, sB, t);
+    if (kprev) {
+        load_block(A + j0 * ld + K0, ld, sPt, t);
+        if (!is_diag) load_block(A + R * ld + K0, ld, sPo, t);
+    }
+    __syncthreads();
+    // ---- left-looking update with the previous 64 columns of the outer panel
+    if (kprev) {
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            double* T = sD + (w * 16) * PLD + n * 16;
+            v4d acc = tile_load(T, lane);
+            acc = mfma_nt16<true>(acc, sPt + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+            tile_store(T, acc, lane);
+            if (!is_diag) {
+                double* U = sB + (w * 16) * PLD + n * 16;
+                v4d acb = tile_load(U, lane);
+                acb = mfma_nt16<true>(acb, sPo + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+                tile_store(U, acb, lane);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- Cholesky of the 64x64 diagonal block, blocked by 16 (wave w owns row strip w)
+    for (int cb = 0; cb < 4; cb++) {
+        if (w == cb) {
+            int bad = chol16_wave(sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
+            if (bad && lane == 0) s_bad = cb * 16 + bad;
+        }
+        __syncthreads();
+        if (s_bad) break;
+        if (w > cb) trsm16_rows(sD + (w * 16) * PLD + cb * 16, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
+        __syncthreads();
+        if (w > cb) {
+            for (int cc = cb + 1; cc <= w; cc++) {
+                double* T = sD + (w * 16) * PLD + cc * 16;
+                v4d acc = tile_load(T, lane);
+                acc = mfma_nt16<true>(acc, sD + (w * 16) * PLD + cb * 16, sD + (cc * 16) * PLD + cb * 16, 16, lane);
+                tile_store(T, acc, lane);
+            }
+            wave_fence();
+        }
+    }
+    if (s_bad) {
+        if (is_diag && t == 0) {
+            int64_t col = j0 + s_bad;                       // 1-based failing column
+            atomicCAS(info, 0, (int)(col <= n_real ? col : n_real));
+        }
+        return;
+    }
+    if (is_diag) {
+        store_block(A + j0 * ld + j0, ld, sD, t, true);
+        return;
+    }
+    // ---- X = B Lkk^-T, wave w solves its own 16-row strip (no workgroup barriers needed)
+    for (int cb = 0; cb < 4; cb++) {
+        double* T = sB + (w * 16) * PLD + cb * 16;
+        if (cb) {
+            v4d acc = tile_load(T, lane);
+            acc = mfma_nt16<true>(acc, sB + (w * 16) * PLD, sD + (cb * 16) * PLD, cb * 16, lane);
+            tile_store(T, acc, lane);
+            wave_fence();
+        }
+        trsm16_rows(T, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
+        wave_fence();
+    }
+    __syncthreads();
+    store_block(A + R * ld + j0, ld, sB, t, false);
+}
+
+// A = L L^T in place (lower; the strict upper triangle is left untouched).  Outer blocks of
+// 128 columns: two fused panel steps, then one MFMA SYRK (K = 128) on the trailing matrix.
+int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 2 * sizeof(int), st));
+    for (int64_t K0 = 0; K0 < Np; K0 += 128) {
+        for (int64_t j0 = K0; j0 < K0 + 128; j0 += 64) {
+            unsigned nblk = (unsigned)((Np - j0) / 64);
+            hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), 0, st, A, Np, j0, K0, ctx->N, ctx->dinfo);
+        }
+        int64_t rest = Np - (K0 + 128);
+        if (rest > 0) {
+            GemmArgs g = {};
+            g.A = A + (K0 + 128) * Np + K0; g.lda = Np;
+            g.B = g.A; g.ldb = Np;
+            g.C = A + (K0 + 128) * Np + (K0 + 128); g.ldc = Np;
+            g.M = (int)rest; g.N = (int)rest; g.K = 128;
+            g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
+            GPRY_TRY(gemm_f64_launch(ctx, g, false, true, EPI_SUB));
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

@@ -156,7 +156,8 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
                       double* grad_out_dev);
 
 // ---- chol.hip ----------------------------------------------------------------------
-int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np);             // info -> ctx->dinfo
+int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np);             // info -> ctx->dinfo (unfused v1)
+int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // fused panel steps (default)
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
 int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np);
 int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha,

@@ -264,7 +264,9 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
     if (kind == 0) {
         double* out = nullptr;
         HIP_TRY(ctx, hipMalloc((void**)&out, 64));
-        const int iters = 2000, nblk = 256 * 8;   // 8 workgroups of 4 waves per CU
+        // `bytes` selects the number of 4-wave workgroups per CU (waves per SIMD), default 1
+        const int wps = (bytes >= 1 && bytes <= 8) ? (int)bytes : 1;
+        const int iters = 40000 / wps, nblk = 256 * wps;
         hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(nblk), dim3(256), 0, ctx->stream, out, 10);
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(nblk), dim3(256), 0, ctx->stream, out, iters);
