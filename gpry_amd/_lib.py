@@ -74,6 +74,7 @@ SIGNATURES = {
     "gpry_timing_get": (C.c_int, [_vp, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
     "gpry_microbench": (C.c_int, [_vp, C.c_int, C.c_int64, _P(C.c_double)]),
     "gpry_debug_gemm": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 9),
+    "gpry_debug_read_diag": (C.c_int, [_vp, _vp, C.c_int]),
 }
 
 
@@ -320,6 +321,11 @@ class Device:
                                               int(a_trans), int(b_trans), int(epi), int(kmode),
                                               int(lower_only), int(tile_map)), "gpry_debug_gemm")
         return Cout
+
+    def read_diag(self, reset=True):
+        out = np.zeros(6, dtype=np.uint64)
+        self._check(self._lib.gpry_debug_read_diag(self._h, _ptr(out), int(reset)), "gpry_debug_read_diag")
+        return out
 
     def microbench(self, kind, nbytes=0):
         v = C.c_double(0.0)

@@ -278,7 +278,8 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
             GemmArgs g = {};
             g.A = ctx->dV; g.lda = Np; g.B = ctx->dKst; g.ldb = mcp; g.C = ss_part; g.ldc = mcp;
             g.M = (int)Np; g.N = (int)mcp; g.K = (int)Np;
-            g.kmode = KM_A_LOWER; g.lower_only = 0; g.tile_map = TM_SWEEP;
+            g.kmode = KM_A_LOWER; g.lower_only = 0; g.tile_map = TM_SWEEP | (ctx->opt_sweep_tilemap << 4); g.stagger = ctx->opt_sweep_stagger; g.extra_lds = ctx->opt_sweep_extra_lds; g.kskew = ctx->opt_sweep_kskew;
+            if (ctx->opt_sweep_diag) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); g.diag = ctx->dsel + 16; }
             GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_SUMSQ));
         }
         {
@@ -704,5 +705,14 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
     HIP_TRY(ctx, hipMemcpyAsync(C, dC, sizeof(double) * crow * N, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     GPRY_TRY(dev_free(ctx, dA)); GPRY_TRY(dev_free(ctx, dB)); GPRY_TRY(dev_free(ctx, dC));
+    return 0;
+}
+
+extern "C" int gpry_debug_read_diag(gpry_ctx* ctx, uint64_t out[6], int reset) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->dsel + 16, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(ctx, hipMemset(ctx->dsel + 16, 0, 6 * sizeof(uint64_t)));
     return 0;
 }

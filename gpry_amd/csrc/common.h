@@ -31,6 +31,11 @@ struct gpry_ctx {
     int opt_chol = 0;
     int64_t opt_sweep_chunk = 32768;
     int opt_timing = 1;
+    int opt_sweep_tilemap = 3;   // log2 of V row-tiles per 64-tile super-tile
+    int opt_sweep_stagger = 0;
+    int opt_sweep_extra_lds = 0;
+    int opt_sweep_diag = 0;
+    int opt_sweep_kskew = 0;
 
     // training set (transformed space)
     int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
@@ -142,6 +147,10 @@ struct GemmArgs {
     const GemmBatchItem* batch;  // nullable; grid.z = n_batch
     int n_batch;
     const int* info;       // nullable: if *info != 0 the kernel exits immediately
+    int stagger;           // >0: odd wave-slot workgroups sleep stagger*32*64 cycles first
+    int extra_lds;         // bytes of unused dynamic LDS (occupancy experiments)
+    int kskew;             // >0: rotate the slab order of tile (ti,tj) by ((ti+tj)&7)*kskew slabs
+    unsigned long long* diag;  // non-null: run the stamped diagnostic build, sums land here
 };
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);

@@ -175,6 +175,14 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
         ctx->opt_sweep_chunk = round_up(value, 1024); return 0;
     }
     if (!strcmp(key, "timing")) { ctx->opt_timing = (int)value; return 0; }
+    if (!strcmp(key, "sweep_kskew")) { ctx->opt_sweep_kskew = (int)value; return 0; }
+    if (!strcmp(key, "sweep_diag")) { ctx->opt_sweep_diag = (int)value; return 0; }
+    if (!strcmp(key, "sweep_extra_lds")) { ctx->opt_sweep_extra_lds = (int)value; return 0; }
+    if (!strcmp(key, "sweep_stagger")) { ctx->opt_sweep_stagger = (int)value; return 0; }
+    if (!strcmp(key, "sweep_tilemap")) {
+        if (value < 0 || value > 6) return gpry_fail(ctx, -1, "sweep_tilemap must be in 0..6");
+        ctx->opt_sweep_tilemap = (int)value; return 0;
+    }
     return gpry_fail(ctx, -1, "unknown option '%s'", key);
 }
 
@@ -249,6 +257,22 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
     for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) out[0] = s;   // keep the chain live without a store in practice
 }
+// same loop with the accumulators pinned to architectural VGPRs (as the GEMM kernels use them)
+__global__ __launch_bounds__(256) void mfma_f64_peak_vgpr_kernel(double* out, int iters) {
+    v4d acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;
+}
 __global__ __launch_bounds__(256) void stream_copy_kernel(const double2* __restrict__ src,
                                                           double2* __restrict__ dst, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -274,6 +298,20 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
         HIP_TRY(ctx, hipEventSynchronize(e1));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
         double flops = (double)nblk * 4.0 * iters * 8.0 * 2048.0;  // 16*16*4*2 per MFMA
+        *value = flops / (ms * 1e-3) / 1e12;
+        (void)hipFree(out);
+    } else if (kind == 2) {
+        double* out = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&out, 64));
+        const int wps = (bytes >= 1 && bytes <= 8) ? (int)bytes : 1;
+        const int iters = 20000 / wps, nblk = 256 * wps;
+        hipLaunchKernelGGL(mfma_f64_peak_vgpr_kernel, dim3(nblk), dim3(256), 0, ctx->stream, out, 10);
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(mfma_f64_peak_vgpr_kernel, dim3(nblk), dim3(256), 0, ctx->stream, out, iters);
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(e1));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        double flops = (double)nblk * 4.0 * iters * 16.0 * 2048.0;
         *value = flops / (ms * 1e-3) / 1e12;
         (void)hipFree(out);
     } else if (kind == 1) {

@@ -176,6 +176,10 @@ int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, double* C, 
                     int K, int a_trans, int b_trans, int epi, int kmode, int lower_only,
                     int tile_map);
 
+/* Diagnostic build of the sweep GEMM (option "sweep_diag"=1): per-phase s_memtime sums
+ * [issue loads, mfma block, vmcnt wait, lds store, barrier, slab count]; reset != 0 zeroes them. */
+int gpry_debug_read_diag(gpry_ctx* ctx, uint64_t out[6], int reset);
+
 #ifdef __cplusplus
 }
 #endif
