@@ -139,7 +139,7 @@ def main():
     dev = gpr.device
     comm = None
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
         import torch.distributed as dist   # rendezvous only (CPU/gloo); the data path is RCCL
         dist.init_process_group("gloo")
         box = [_lib.RcclComm.unique_id() if rank == 0 else None]
@@ -232,6 +232,15 @@ def main():
                          "frac": kb_gbps / HBM_PEAK_GBPS, "avg_launch_ms": kb_ms / max(kb_n, 1),
                          "bytes_per_launch": 8.0 * N * N + 8.0 * N * d},
     }
+    if rank == 0:
+        # measured ceilings of this very GPU, quoted beside the spec peaks used for `frac`
+        try:
+            result["measured_peaks"] = {
+                "mfma_f64_vgpr_acc_TFLOPs": dev.microbench(2, 1),
+                "hbm_copy_GBps": dev.microbench(1, 1 << 30),
+                "hbm_fill_GBps": dev.microbench(3, 1 << 30)}
+        except Exception as e:
+            result["measured_peaks"] = {"error": repr(e)}
     if rank == 0 and world == 1 and args.cpu_baseline == "auto":
         try:
             result["cpu_baseline"] = cpu_baseline(N, d, args.M, npts, lml_evals, cache_models / K)

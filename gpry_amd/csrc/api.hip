@@ -29,9 +29,9 @@ static int copy_out_matrix(gpry_ctx* ctx, const double* dsrc, int64_t ld, int64_
 
 static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* info_host) {
     // A <- K + diag(alpha); A <- chol(A) (lower); V <- A^-1
+    GPRY_TRY(launch_scale_train(ctx));      // X / l (N x d, microseconds)
     {
-        StageScope s(ctx, "kernel_build");
-        GPRY_TRY(launch_scale_train(ctx));
+        StageScope s(ctx, "kernel_build");   // the O(N^2 d) covariance build proper
         GPRY_TRY(launch_kernel_train(ctx, A, 1));
     }
     if (ctx->opt_chol == 1) {
@@ -66,9 +66,9 @@ extern "C" {
 int gpry_kernel_train(gpry_ctx* ctx, int add_alpha, double* K_out) {
     GPRY_TRY(require_model(ctx, false));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GPRY_TRY(launch_scale_train(ctx));
     {
         StageScope s(ctx, "kernel_build");
-        GPRY_TRY(launch_scale_train(ctx));
         GPRY_TRY(launch_kernel_train(ctx, ctx->dW, add_alpha));
     }
     if (K_out) GPRY_TRY(copy_out_matrix(ctx, ctx->dW, ctx->Np, ctx->N, ctx->N, K_out));
@@ -280,7 +280,8 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
             g.M = (int)Np; g.N = (int)mcp; g.K = (int)Np;
             g.kmode = KM_A_LOWER; g.lower_only = 0; g.tile_map = TM_SWEEP | (ctx->opt_sweep_tilemap << 4); g.stagger = ctx->opt_sweep_stagger; g.extra_lds = ctx->opt_sweep_extra_lds; g.kskew = ctx->opt_sweep_kskew;
             if (ctx->opt_sweep_diag) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); g.diag = ctx->dsel + 16; }
-            GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_SUMSQ));
+            if (ctx->opt_sweep_dma && !ctx->opt_sweep_diag) GPRY_TRY(sweep_gemm_dma_launch(ctx, g));
+            else GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_SUMSQ));
         }
         {
             StageScope s(ctx, "sweep_finish");

@@ -35,6 +35,8 @@ struct gpry_ctx {
     int opt_sweep_stagger = 0;
     int opt_sweep_extra_lds = 0;
     int opt_sweep_diag = 0;
+    int opt_sweep_dma = 1;       // 1: LDS-DMA staged sweep GEMM (sweep_gemm.hip, +3.6 % measured); 0: register-staged
+    int opt_kb_tile = 64;        // kernel-build tile size (32 or 64; 64 measured faster)
     int opt_sweep_kskew = 0;
 
     // training set (transformed space)
@@ -154,6 +156,7 @@ struct GemmArgs {
 };
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
+int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g);   // sweep_gemm.hip (LDS-DMA staging)
 
 // ---- kernel_build.hip --------------------------------------------------------------
 int upload_params(gpry_ctx* ctx, const double* theta);

@@ -175,6 +175,8 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
         ctx->opt_sweep_chunk = round_up(value, 1024); return 0;
     }
     if (!strcmp(key, "timing")) { ctx->opt_timing = (int)value; return 0; }
+    if (!strcmp(key, "sweep_dma")) { ctx->opt_sweep_dma = (int)value; return 0; }
+    if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }
     if (!strcmp(key, "sweep_kskew")) { ctx->opt_sweep_kskew = (int)value; return 0; }
     if (!strcmp(key, "sweep_diag")) { ctx->opt_sweep_diag = (int)value; return 0; }
     if (!strcmp(key, "sweep_extra_lds")) { ctx->opt_sweep_extra_lds = (int)value; return 0; }
@@ -280,6 +282,19 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const double2* __restr
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(256) void xcc_probe_kernel(int* out) {
+    // HW_REG_XCC_ID (id 20), bits 3:0 = XCC id
+    int x = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));
+    // keep the block alive for a while so that the whole grid is not drained by a few CUs
+    for (int i = 0; i < 20; i++) __builtin_amdgcn_s_sleep(64);
+    if (threadIdx.x == 0) out[blockIdx.x] = x;
+}
+__global__ __launch_bounds__(256) void stream_fill_kernel(double2* __restrict__ dst, int64_t n, double v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = make_double2(v, v + 1.0);
+}
+
 extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* value) {
     hipEvent_t e0, e1;
     HIP_TRY(ctx, hipEventCreate(&e0));
@@ -331,6 +346,37 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
         HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
         *value = (double)reps * 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9;
         (void)hipFree(src); (void)hipFree(dst);
+    } else if (kind == 4) {   // dispatch probe: fraction of blocks b that run on XCC (b % 8 + c) % 8
+        const int nblk = 4096;
+        int* d = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&d, nblk * sizeof(int)));
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(nblk), dim3(256), 0, ctx->stream, d);
+        std::vector<int> h(nblk);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(h.data(), d, nblk * sizeof(int), hipMemcpyDeviceToHost));
+        int best = 0;
+        for (int c = 0; c < 8; c++) {
+            int ok = 0;
+            for (int b = 0; b < nblk; b++) ok += ((h[b] & 15) == (b + c) % 8);
+            if (ok > best) best = ok;
+        }
+        *value = (double)best / nblk;
+        (void)hipFree(d);
+    } else if (kind == 3) {   // pure streaming write (the kernel build is write-dominated)
+        if (bytes < (1 << 20)) bytes = 1 << 20;
+        int64_t n = bytes / 16;
+        double2* dst = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&dst, (size_t)n * 16));
+        hipLaunchKernelGGL(stream_fill_kernel, dim3(2048), dim3(256), 0, ctx->stream, dst, n, 1.0);
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        const int reps = 5;
+        for (int r = 0; r < reps; r++)
+            hipLaunchKernelGGL(stream_fill_kernel, dim3(2048), dim3(256), 0, ctx->stream, dst, n, 2.0 + r);
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(e1));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        *value = (double)reps * (double)n * 16.0 / (ms * 1e-3) / 1e9;
+        (void)hipFree(dst);
     } else {
         return gpry_fail(ctx, -1, "microbench: unknown kind %d", kind);
     }

@@ -102,24 +102,27 @@ __device__ __forceinline__ void tri_decode(int64_t t, int* bi, int* bj) {
     *bi = i; *bj = (int)(t - (int64_t)i * (i + 1) / 2);
 }
 
-// One 64x64 tile of K per workgroup (lower block triangle); each thread owns a 4x4
-// patch.  Off-diagonal tiles are mirrored through an LDS transpose so that both the
-// (bi,bj) and (bj,bi) images are written as full 512-byte row segments with 16-byte
-// stores.  Algorithmic traffic: read X once (8 N d), write K once (8 N^2).
-template <int KID>
-__global__ __launch_bounds__(256) void kernel_train_kernel(
+// One TS x TS tile of K per workgroup (lower block triangle), (TS/4)^2 threads, each
+// thread owns a 4x4 patch.  Off-diagonal tiles are mirrored through an LDS transpose so that
+// both the (bi,bj) and (bj,bi) images are written as full row segments with 16-byte stores.
+// TS = 32 (one wave per tile) keeps ~8000 tiles in flight at N = 4096, so that the launch is
+// not quantised into a few long rounds.  Algorithmic traffic: read X once (8 N d), write K
+// once (8 N^2).
+template <int KID, int TS>
+__global__ __launch_bounds__((TS / 4) * (TS / 4)) void kernel_train_kernel(
     const double* __restrict__ Xs, const double* __restrict__ noise, double* __restrict__ K,
     int64_t ld, KernParams kp, int add_noise) {
+    constexpr int NT = (TS / 4) * (TS / 4), TQ = TS / 4, TP = TS + 2;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int dp = kp.dpad;
-    double* Xi = sm;             // [dp][64]
-    double* Xj = sm + dp * 64;   // [dp][64]
+    double* Xi = sm;             // [dp][TS]
+    double* Xj = sm + dp * TS;   // [dp][TS]
     int bi, bj; tri_decode(blockIdx.x, &bi, &bj);
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-    for (int e = t; e < 64 * dp; e += 256) {
+    const int t = threadIdx.x, tx = t % TQ, ty = t / TQ;
+    for (int e = t; e < TS * dp; e += NT) {
         int row = e / dp, k = e - row * dp;
-        Xi[k * 64 + row] = Xs[((int64_t)bi * 64 + row) * dp + k];
-        Xj[k * 64 + row] = Xs[((int64_t)bj * 64 + row) * dp + k];
+        Xi[k * TS + row] = Xs[((int64_t)bi * TS + row) * dp + k];
+        Xj[k * TS + row] = Xs[((int64_t)bj * TS + row) * dp + k];
     }
     __syncthreads();
     double r2[4][4];
@@ -128,8 +131,8 @@ __global__ __launch_bounds__(256) void kernel_train_kernel(
 #pragma unroll
         for (int b = 0; b < 4; b++) r2[a][b] = 0.0;
     for (int k = 0; k < dp; k++) {
-        const double2* pi = reinterpret_cast<const double2*>(Xi + k * 64 + ty * 4);
-        const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + tx * 4);
+        const double2* pi = reinterpret_cast<const double2*>(Xi + k * TS + ty * 4);
+        const double2* pj = reinterpret_cast<const double2*>(Xj + k * TS + tx * 4);
         double2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
         double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void kernel_train_kernel(
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            int64_t i = (int64_t)bi * 64 + ty * 4 + a, j = (int64_t)bj * 64 + tx * 4 + b;
+            int64_t i = (int64_t)bi * TS + ty * 4 + a, j = (int64_t)bj * TS + tx * 4 + b;
             double v = kp.C * corr_r2<KID>(r2[a][b]);
             if (i == j) v = kp.C + (add_noise ? noise[i < kp.N ? i : 0] : 0.0);
             if (i >= kp.N || j >= kp.N) v = (i == j) ? 1.0 : 0.0;   // identity padding
@@ -150,35 +153,39 @@ __global__ __launch_bounds__(256) void kernel_train_kernel(
         }
 #pragma unroll
     for (int a = 0; a < 4; a++) {
-        int64_t i = (int64_t)bi * 64 + ty * 4 + a;
-        double2* p = reinterpret_cast<double2*>(K + i * ld + (int64_t)bj * 64 + tx * 4);
+        int64_t i = (int64_t)bi * TS + ty * 4 + a;
+        double2* p = reinterpret_cast<double2*>(K + i * ld + (int64_t)bj * TS + tx * 4);
         p[0] = make_double2(val[a][0], val[a][1]);
         p[1] = make_double2(val[a][2], val[a][3]);
     }
     if (bi == bj) return;
-    __syncthreads();            // X tiles no longer needed: reuse LDS as a [64][66] transpose pad
+    __syncthreads();            // X tiles no longer needed: reuse LDS as a [TS][TS+2] transpose pad
     double* T = sm;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) T[(tx * 4 + b) * 66 + ty * 4 + a] = val[a][b];
+        for (int b = 0; b < 4; b++) T[(tx * 4 + b) * TP + ty * 4 + a] = val[a][b];
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         int jr = ty * 4 + a;   // row of the mirrored tile (a column index j of K)
-        double2* p = reinterpret_cast<double2*>(K + ((int64_t)bj * 64 + jr) * ld + (int64_t)bi * 64 + tx * 4);
-        const double2* q = reinterpret_cast<const double2*>(T + jr * 66 + tx * 4);
+        double2* p = reinterpret_cast<double2*>(K + ((int64_t)bj * TS + jr) * ld + (int64_t)bi * TS + tx * 4);
+        const double2* q = reinterpret_cast<const double2*>(T + jr * TP + tx * 4);
         p[0] = q[0]; p[1] = q[1];
     }
 }
 
 int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
     KernParams kp = make_kp(ctx);
-    int64_t nb = ctx->Np / 64;
+    const int TS = ctx->opt_kb_tile == 64 ? 64 : 32;
+    int64_t nb = ctx->Np / TS;
     int64_t ntile = nb * (nb + 1) / 2;
-    size_t smem = sizeof(double) * (size_t)((2 * ctx->dpad * 64 > 64 * 66) ? 2 * ctx->dpad * 64 : 64 * 66);
-#define KT(KID) hipLaunchKernelGGL((kernel_train_kernel<KID>), dim3((unsigned)ntile), dim3(256), smem, \
-                                   ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise)
+    size_t smem = sizeof(double) * (size_t)((2 * ctx->dpad * TS > TS * (TS + 2)) ? 2 * ctx->dpad * TS : TS * (TS + 2));
+#define KT(KID)                                                                                        \
+    if (TS == 64) hipLaunchKernelGGL((kernel_train_kernel<KID, 64>), dim3((unsigned)ntile), dim3(256), smem, \
+                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise);  \
+    else hipLaunchKernelGGL((kernel_train_kernel<KID, 32>), dim3((unsigned)ntile), dim3(64), smem,    \
+                            ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise)
     DISPATCH_KID(ctx->kernel_id, KT)
 #undef KT
     HIP_TRY(ctx, hipGetLastError());

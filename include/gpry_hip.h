@@ -162,8 +162,12 @@ int gpry_comm_barrier(gpry_comm* comm);
 int gpry_timing_reset(gpry_ctx* ctx);
 int gpry_timing_get(gpry_ctx* ctx, const char* name, double* total_ms, int64_t* count);
 /* Raw micro-benchmarks used by bench.py to quote measured peaks beside the spec:
- * kind 0: f64 MFMA 16x16x4 issue loop -> *value = TFLOP/s
- * kind 1: HBM streaming copy of `bytes` -> *value = GB/s (read+write bytes / time) */
+ * kind 0: f64 MFMA 16x16x4 issue loop, compiler-allocated (AGPR) accumulators; `bytes` =
+ *         workgroups per CU (1..8) -> *value = TFLOP/s  (measured 35-49: AGPR accumulators
+ *         run the f64 MFMA well below rate, which is why the GEMM keeps them in VGPRs)
+ * kind 2: the same loop with the accumulators pinned to VGPRs -> TFLOP/s (measured 77.1-77.7)
+ * kind 1: HBM streaming copy of `bytes` -> *value = GB/s (read+write bytes / time)
+ * kind 3: HBM streaming fill of `bytes`  -> *value = GB/s written */
 int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* value);
 
 /* ---- testing hook ------------------------------------------------------------------- */

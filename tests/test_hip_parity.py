@@ -293,3 +293,19 @@ def test_full_size_properties_config3(dev):
         e[k] = 1e-5
         fd = (dev.lml(theta + e, False)[0] - dev.lml(theta - e, False)[0]) / 2e-5
         assert abs(fd - grad[k]) <= 1e-5 * max(1.0, abs(grad[k]))
+
+
+def test_rccl_communicator_single_rank(dev):
+    """RCCL entry points on a 1-rank communicator (the multi-rank merge logic is covered by
+    tests/test_multirank_cpu.py; 8-GPU runs are the driver's)."""
+    from gpry_amd import _lib
+    comm = _lib.RcclComm(dev, 1, 0, _lib.RcclComm.unique_id())
+    rec = np.zeros(5, dtype=_lib.CAND_DTYPE)
+    rec["acq"] = np.arange(5.0)
+    rec["idx"] = np.arange(5) * 7
+    got = comm.allgather(rec)
+    assert got.shape == (1, 5) and np.array_equal(got[0], rec)
+    x = np.array([3.0, -np.inf, 7.5])
+    np.testing.assert_array_equal(comm.allreduce_max(x), x)
+    comm.barrier()
+    comm.close()

@@ -107,6 +107,46 @@ def test_gpr_attributes_copy_pickle_and_errors():
         gpr.predict(Xc[:1], return_mean_grad=True)
 
 
+def test_default_svm_classifier_and_trust_region_gate_predictions():
+    """Runner's defaults: account_for_inf='SVM' with -inf targets in the data, plus a trust
+    region.  Infinite points stay out of the GP training set, classified-infinite candidates
+    get mean=-inf / std=0, candidates outside the trust box get mean=-inf with their std."""
+    from gpry_amd import _lib
+    bounds, X, y, Xc = orc.synthetic_like_goldens(150, 3, 400, seed=9)
+    y = y.copy()
+    bad = X[:, 0] > 1.0
+    y[bad] = -np.inf                           # an "unphysical" half-space
+    assert 10 < bad.sum() < 140
+    gpr = make_gpr(bounds, 3, theta=np.log(np.array([4.0, 0.3, 0.3, 0.3])), account_for_inf="SVM",
+                   inf_threshold="20s", trust_region_factor=1.5, random_state=1)
+    gpr.append_to_data(X, y, fit_gpr=False)
+    assert gpr.n == (~bad).sum() and gpr.n_total == 150
+    assert np.array_equal(gpr.X_train, X[~bad]) and len(gpr.X_train_infinite) == bad.sum()
+    mean, std = gpr.predict(Xc, return_std=True)
+    finite = gpr.predict_is_finite(Xc)
+    inside = orc.is_in_bounds(Xc, gpr.trust_bounds)
+    assert 0 < (~finite).sum() < len(Xc) and 0 < (~inside).sum()
+    assert np.all(np.isneginf(mean[~finite])) and not std[~finite].any()
+    assert np.all(np.isneginf(mean[~inside])) and np.all(std[finite & ~inside] > 0)
+    ok = finite & inside
+    # same numbers as the oracle trained on the finite subset
+    ref = orc.OracleGPR(bounds, kernel_id=3)
+    ref.theta = np.log(np.array([4.0, 0.3, 0.3, 0.3]))
+    ref.append_to_data(X[~bad], y[~bad], fit_gpr=False, fit_preprocessors=True)
+    rm, rs = ref.predict(Xc, return_std=True)
+    np.testing.assert_allclose(mean[ok], rm[ok], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(std[finite], rs[finite], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(gpr.predict_std(Xc)[finite], rs[finite], rtol=1e-6, atol=1e-9)
+    # NORA on top: nothing is proposed where the classifier or the trust region says no
+    from gpry_amd.gp_acquisition import NORA
+    acq = NORA(bounds, sampler="uniform", verbose=0)
+    acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+    Xp, yp, ap = acq.multi_add(gpr, n_points=3, bounds=gpr.trust_bounds, rng=np.random.default_rng(0))
+    assert len(Xp) == 3 and np.all(np.isfinite(yp)) and np.all(np.isfinite(ap))
+    assert np.all(gpr.predict_is_finite(Xp)) and np.all(orc.is_in_bounds(Xp, gpr.trust_bounds))
+    assert _lib.MASK_CLASSIFIED_INF == 1
+
+
 def test_conditioned_models_match_refactorised_oracle():
     """Bordered factor == deepcopy + append_to_data(fit_gpr=False) of the reference path."""
     bounds, X, y, Xc = orc.synthetic_like_goldens(200, 4, 300, seed=77)

@@ -13,12 +13,12 @@ dev = _lib.Device(0)
 dev.set_train(X, y, np.full(N, 1e-4))
 dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
 assert dev.factorize() == 0
-variants = [("skew0", 3, 65536, 0, 0), ("skew1", 3, 65536, 1, 0), ("skew2", 3, 65536, 2, 0), ("skew4", 3, 65536, 4, 0), ("skew1_tm2", 2, 65536, 1, 0), ("skew1_tm4", 4, 65536, 1, 0)]
+variants = [("reg", 3, 65536, 0, 0), ("dma", 3, 65536, 0, 1), ("dma_tm2", 2, 65536, 0, 1), ("dma_tm4", 4, 65536, 0, 1)]
 res = {v[0]: [] for v in variants}
 ref = None
 for rnd in range(3):
     for name, tm, chunk, stg, xl in variants:
-        dev.set_option("sweep_extra_lds", xl)
+        dev.set_option("sweep_dma", xl)
         dev.set_option("sweep_kskew", stg)
         dev.set_option("sweep_tilemap", tm)
         dev.set_option("sweep_chunk", chunk)
@@ -30,9 +30,8 @@ for rnd in range(3):
         dev.sweep_logexp(None, 0.1, 0.0, 1e-2, M=M, want=())
         ms, n = dev.timing("sweep_gemm")
         res[name].append(M * (N * N + 2.0 * N) / (ms * 1e-3) / 1e12)
-dev.set_option("sweep_extra_lds", 0)
+dev.set_option("sweep_dma", 0)
 for xl in (0,):
-    dev.set_option("sweep_extra_lds", xl)
     dev.set_option("sweep_diag", 1)
     dev.read_diag(True)
     dev.sweep_logexp(None, 0.1, 0.0, 1e-2, M=M, want=())
