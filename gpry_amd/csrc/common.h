@@ -157,6 +157,7 @@ struct GemmArgs {
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
 int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g);   // sweep_gemm.hip (LDS-DMA staging)
+int sweep_gemm_dma256_launch(gpry_ctx* ctx, const GemmArgs& g);  // 128x256 tile, 8 waves, 3-stage ring
 
 // ---- kernel_build.hip --------------------------------------------------------------
 int upload_params(gpry_ctx* ctx, const double* theta);

@@ -149,3 +149,147 @@ int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g) {
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// Variant 2: 128 x 256 tile, 8 waves (2 x 4), one workgroup per CU, three-stage LDS ring.
+// A slab of V (128 x 16) now serves 256 candidates, i.e. 25 % fewer staged bytes per MFMA
+// than the 128 x 128 tile, and a DMA piece has two slab times to land: at step s the wave
+// waits only for its own pieces of slab s (s_waitcnt vmcnt(6) leaves slab s+1 in flight),
+// crosses a raw s_barrier, issues slab s+2 into the buffer that was read in step s-1, and
+// multiplies slab s.
+#define BN2 256
+#define SB2 272
+#define B2_DOUBLES (16 * SB2)
+#define STAGE2 (A_DOUBLES + B2_DOUBLES)
+
+__global__ __launch_bounds__(512, 2) void sweep_gemm_dma256_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double smem[3 * STAGE2];
+    const int M = g.M, N = g.N, K = g.K;
+    const int tiles_m = M / BM, tiles_n = N / BN2;
+    int ti, tj;
+    {
+        const int b = blockIdx.x;
+        const int a = (g.tile_map >> 4) & 15, c = 5 - a;      // 32 tiles per XCD wave of workgroups
+        const int nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
+        const int xcd = b & 7, q = b >> 3;
+        const int s = (q >> 5) * 8 + xcd, within = q & 31;
+        if (s >= nsi * nsj) return;
+        const int si = nsi - 1 - s / nsj, sj = s % nsj;
+        ti = (si << a) + (within >> c);
+        tj = (sj << c) + (within & ((1 << c) - 1));
+        if (ti >= tiles_m || tj >= tiles_n) return;
+    }
+    const int row0 = ti * BM, col0 = tj * BN2;
+    const int kend = min(K, row0 + BM);
+    const int nslab = kend / BK;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, gq = lane >> 4;
+
+    const double* srcA[2];
+    int dstA[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int q = wave * 2 + j;
+        const int row = q * 8 + (lane >> 3), pp = lane & 7;
+        const int p = pp ^ ((row >> 1) & 7);
+        srcA[j] = g.A + (int64_t)(row0 + row) * g.lda + 2 * p;
+        dstA[j] = q * 128;
+    }
+    const double* srcB[4];
+    int dstB[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int idx = wave * 4 + j, krow = idx >> 1, half = idx & 1;
+        srcB[j] = g.B + (int64_t)krow * g.ldb + col0 + half * 128 + 2 * lane;
+        dstB[j] = krow * SB2 + half * 128;
+    }
+    auto issue = [&](int s, int buf) {
+        double* As = smem + buf * STAGE2;
+        double* Bs = As + A_DOUBLES;
+        const int k0 = s * BK;
+#pragma unroll
+        for (int j = 0; j < 2; j++) dma16(srcA[j] + k0, As + dstA[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) dma16(srcB[j] + (int64_t)k0 * g.ldb, Bs + dstB[j]);
+    };
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    int aoff[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++) {
+        const int row = wr * 64 + mi * 16 + r;
+        aoff[mi][0] = row * 16;
+        aoff[mi][1] = (row >> 1) & 7;
+    }
+
+    issue(0, 0);
+    if (nslab > 1) issue(1, 1);
+    int buf = 0;
+    for (int s = 0; s < nslab; s++) {
+        // own pieces of slab s have landed (the newest six, slab s+1, may still be in flight)
+        if (s + 1 < nslab) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        int nb = buf + 2; if (nb >= 3) nb -= 3;
+        if (s + 2 < nslab) issue(s + 2, nb);
+        const double* As = smem + buf * STAGE2;
+        const double* Bs = As + A_DOUBLES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; kk++) {
+            const int k = kk * 4 + gq;
+            double a[4], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+                a[mi] = As[aoff[mi][0] + 2 * ((k >> 1) ^ aoff[mi][1]) + (k & 1)];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) b[ni] = Bs[k * SB2 + wc * 64 + ni * 16 + r];
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of slab s are done
+        buf = buf + 1; if (buf >= 3) buf = 0;
+    }
+    __syncthreads();
+    double cs[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) sacc = fma(acc[mi][ni][q], acc[mi][ni][q], sacc);
+        sacc += __shfl_xor(sacc, 16);
+        sacc += __shfl_xor(sacc, 32);
+        cs[ni] = sacc;
+    }
+    double* red = smem;
+    if (gq == 0) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) red[wr * 256 + wc * 64 + ni * 16 + r] = cs[ni];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256)
+        g.C[(int64_t)ti * g.ldc + col0 + threadIdx.x] = red[threadIdx.x] + red[256 + threadIdx.x];
+}
+
+int sweep_gemm_dma256_launch(gpry_ctx* ctx, const GemmArgs& g) {
+    if (g.M % BM || g.N % BN2 || g.K % BK) return gpry_fail(ctx, -1, "sweep_gemm_dma256: bad dims");
+    const int tiles_m = g.M / BM, tiles_n = g.N / BN2;
+    const int a = (g.tile_map >> 4) & 15, c = 5 - a;
+    if (c < 0) return gpry_fail(ctx, -1, "sweep_gemm_dma256: tile map exponent must be <= 5");
+    int64_t nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
+    int64_t ns = (nsi * nsj + 7) / 8 * 8;
+    hipLaunchKernelGGL(sweep_gemm_dma256_kernel, dim3((unsigned)(ns * 32)), dim3(512), 0, ctx->stream, g);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
