@@ -1,0 +1,123 @@
+"""Test double of ``gpry_amd._lib.Device``: same methods, numpy/scipy arithmetic from the oracle.
+
+Lets the CPU suite (``-m "not gpu"``) drive the *host* side of the product (the
+``GaussianProcessRegressor`` mirror, the restart farm, NORA sharding) end to end without a GPU.
+Test infrastructure only: nothing under ``gpry_amd/`` imports it.
+"""
+import numpy as np
+
+from oracle import gpry_oracle as orc
+from gpry_amd._lib import CAND_DTYPE, MASK_CLASSIFIED_INF, MASK_OUTSIDE_TRUST
+
+
+class OracleDevice:
+    def __init__(self, device=0):
+        self.N = self.d = 0
+        self.kid, self.theta = orc.RBF, None
+        self.lo = self.span = None
+        self.y_mean, self.y_std, self.clip_hi = 0.0, 1.0, np.inf
+        self.n_lml = self.n_factorize = 0
+        self._factor = None
+
+    # -- model state --------------------------------------------------------------------
+    def set_train(self, X_, y_, alpha):
+        self.X_ = np.array(X_, dtype=float)
+        self.N, self.d = self.X_.shape
+        self.y_ = np.array(y_, dtype=float)
+        self.alpha = np.array(np.broadcast_to(alpha, (self.N,)), dtype=float)
+        self._factor = None
+
+    def set_theta(self, kernel_id, theta):
+        self.kid, self.theta = int(kernel_id), np.array(theta, dtype=float)
+        assert self.theta.shape == (self.d + 1,)
+        self._factor = None
+
+    def set_affine(self, x_lo=None, x_span=None, y_mean=0.0, y_std=1.0, clip_hi=np.inf):
+        self.lo = None if x_lo is None else np.array(x_lo, dtype=float)
+        self.span = None if x_span is None else np.array(x_span, dtype=float)
+        self.y_mean, self.y_std, self.clip_hi = float(y_mean), float(y_std), float(clip_hi)
+
+    def set_option(self, key, value):
+        pass
+
+    def sync(self):
+        pass
+
+    # -- factor / lml -------------------------------------------------------------------
+    def factorize(self):
+        self.n_factorize += 1
+        K = orc.kernel_matrix(self.X_, self.theta, self.kid)
+        K[np.diag_indices_from(K)] += self.alpha
+        try:
+            self._factor = orc.factorize(K, self.y_)
+        except np.linalg.LinAlgError as e:
+            self._factor = None
+            msg = str(e)
+            return int(msg.split("-th")[0]) if "-th" in msg else 1
+        return 0
+
+    def get_factor(self, want_L=True, want_V=True, want_alpha=True):
+        L, V, a = self._factor
+        return (L.copy() if want_L else None, V.copy() if want_V else None,
+                a.copy() if want_alpha else None)
+
+    def lml(self, theta, eval_gradient=False):
+        self.n_lml += 1
+        out = orc.log_marginal_likelihood(self.X_, self.y_, self.alpha, np.asarray(theta, float),
+                                          self.kid, eval_gradient=eval_gradient)
+        if eval_gradient:
+            return float(out[0]), np.array(out[1]), int(not np.isfinite(out[0]))
+        return float(out), int(not np.isfinite(out))
+
+    # -- predict / sweep ----------------------------------------------------------------
+    def _to_unit(self, X):
+        X = np.atleast_2d(np.asarray(X, dtype=float))
+        return X if self.lo is None else (X - self.lo) / self.span
+
+    def predict(self, X, return_std=False, mask=None):
+        X_ = self._to_unit(X)
+        L, V, a = self._factor
+        Kt = orc.kernel_matrix(X_, self.theta, self.kid, Y=self.X_)
+        mean = np.minimum(Kt.dot(a) * self.y_std + self.y_mean, self.clip_hi)
+        if mask is not None:
+            mask = np.asarray(mask, dtype=np.uint8)
+            mean[(mask & (MASK_CLASSIFIED_INF | MASK_OUTSIDE_TRUST)) != 0] = -np.inf
+        if not return_std:
+            return mean
+        Mm = V.dot(Kt.T)
+        var = orc.kernel_diag(X_, self.theta) - np.einsum("ji,ji->i", Mm, Mm)
+        var[var < 0] = 0.0
+        std = np.sqrt(var) * self.y_std
+        if mask is not None:
+            std[(mask & MASK_CLASSIFIED_INF) != 0] = 0.0
+        return mean, std
+
+    def sweep_logexp(self, X, zeta, baseline, sigma_n, mask=None, M=None, want=("y", "sigma", "acq")):
+        if X is None:
+            X = self._pool
+        self._pool = np.array(X, dtype=float)
+        if len(X):
+            y, s = self.predict(X, return_std=True, mask=mask)
+        else:
+            y, s = np.empty(0), np.empty(0)
+        self.acq, self.y, self.s = orc.logexp_f(y, s, baseline, sigma_n, zeta), y, s
+        return {"y": y, "sigma": s, "acq": self.acq, "n_nan": int(np.isnan(self.acq).sum())}
+
+    def sweep_topk(self, K, exclude=None):
+        M = len(self.acq)
+        ok = np.ones(M, bool)
+        if exclude is not None and len(exclude):
+            ok[np.asarray(exclude, dtype=int)] = False
+        order = np.lexsort((-np.arange(M), -self.acq))
+        order = order[ok[order]]
+        sel = order[:K]
+        top = np.zeros(len(sel), dtype=CAND_DTYPE)
+        top["acq"], top["y"], top["sigma"], top["idx"] = self.acq[sel], self.y[sel], self.s[sel], sel
+        bound = self.acq[order[K]] if len(order) > K else -np.inf
+        return top, bound
+
+
+def attach(gpr, device=None):
+    """Give a host-side ``gpry_amd.gpr.GaussianProcessRegressor`` the oracle-backed device."""
+    gpr._dev = device or OracleDevice()
+    return gpr

@@ -1,0 +1,164 @@
+"""CPU tests of the host side of the fit path: the GaussianProcessRegressor mirror driven through
+an oracle-backed device double (tests/oracle_device.py) against the reference's golden vectors,
+and the restart farm (gpry_amd/parallel.py, gpry/run.py:1238-1293) on two gloo ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle_device import OracleDevice, attach
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SPEC = {0: "RBF", 1: {"Matern": {"nu": 0.5}}, 2: {"Matern": {"nu": 1.5}},
+               3: {"Matern": {"nu": 2.5}}}
+
+
+def make_gpr(bounds, kid, **kw):
+    from gpry_amd.gpr import GaussianProcessRegressor
+    from gpry_amd.preprocessing import Normalize_bounds, Normalize_y
+    kw.setdefault("account_for_inf", None)
+    gpr = GaussianProcessRegressor(kernel=KERNEL_SPEC[kid], bounds=bounds,
+                                   preprocessing_X=Normalize_bounds(bounds),
+                                   preprocessing_y=Normalize_y(), **kw)
+    return attach(gpr)
+
+
+@pytest.mark.parametrize("kid,N", [(0, 48), (3, 60)])
+def test_host_fit_logic_reproduces_reference_fits(kid, N):
+    """F6: restart schedule, RNG order and optimiser calls of fit_gpr_hyperparameters -- with
+    the oracle's arithmetic under the host code the reference's optimum is hit closely."""
+    g = load_golden("fit")
+    p = f"f6_k{kid}_"
+    gpr = make_gpr(g[p + "bounds"], kid, n_restarts_optimizer=4, random_state=3)
+    X, y, Xc = g[p + "X"], g[p + "y"], g[p + "Xc"]
+    gpr.append_to_data(X[:N], y[:N], fit_gpr=True)
+    assert gpr.fitted and gpr.n == N
+    assert abs(gpr.log_marginal_likelihood_value_ - g[p + "lml_full"]) < 1e-5
+    np.testing.assert_allclose(gpr.kernel_.theta, g[p + "theta_full"], rtol=1e-3, atol=1e-3)
+    m, s = gpr.predict(Xc, return_std=True)
+    np.testing.assert_allclose(m, g[p + "mean_full"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(s, g[p + "std_full"], rtol=1e-4, atol=1e-5)
+    gpr.append_to_data(X[N:], y[N:], fit_gpr="simple")
+    assert abs(gpr.log_marginal_likelihood_value_ - g[p + "lml_simple"]) < 1e-4
+    m, s = gpr.predict(Xc, return_std=True)
+    np.testing.assert_allclose(m, g[p + "mean_simple"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(s, g[p + "std_simple"], rtol=1e-3, atol=1e-4)
+
+
+def test_host_append_fixed_theta_reproduces_reference_factor():
+    """F8 through the host mirror: frozen theta, re-fitted pre-processors, lazy factor."""
+    from gpry_amd.kernels import clone
+    g = load_golden("predict")
+    X, y, Xc = g["f8_X"], g["f8_y"], g["f8_Xc"]
+    gpr = make_gpr(g["f8_bounds"], 2)
+    k = clone(gpr.kernel)
+    k.theta = g["f8_theta"]
+    gpr.kernel_, gpr._fitted = k, True
+    gpr.append_to_data(X[:32], y[:32], fit_gpr=False)
+    np.testing.assert_allclose(gpr.predict_std(Xc), g["f8_std_before"], rtol=1e-7)
+    gpr.append_to_data(X[32:], y[32:], fit_gpr=False, fit_classifier=False)
+    np.testing.assert_allclose(gpr.L_, g["f8_L"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(gpr.alpha_, g["f8_alpha_"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(gpr.predict(Xc), g["f8_mean_after"], rtol=1e-9, atol=1e-10)
+    assert gpr.device.n_factorize == 2      # one factorisation per append, none per predict
+
+
+def test_split_and_rank_generators():
+    from gpry_amd.parallel import split_number_for_parallel_processes as split, get_random_generator
+    assert list(split(5, 3)) == [2, 2, 1] and list(split(32, 8)) == [4] * 8
+    assert list(split(2, 4)) == [1, 1, 0, 0] and list(split(0, 2)) == [0, 0]
+    r = get_random_generator(7)
+    ref = np.random.default_rng(np.random.SeedSequence(7).spawn(1)[0])
+    assert r.integers(1 << 30) == ref.integers(1 << 30)
+    assert get_random_generator(r) is r
+
+
+def test_single_process_farm_equals_plain_fit():
+    from gpry_amd.parallel import fit_gpr_parallel
+    g = load_golden("fit")
+    p = "f6_k3_"
+    a = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=3, random_state=5)
+    b = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=3, random_state=5)
+    X, y = g[p + "X"][:40], g[p + "y"][:40]
+    a.append_to_data(X, y, fit_gpr=True)
+    lml, best, lmls = fit_gpr_parallel(b, X, y, comm=None, fit="full")
+    assert best == 0 and lml == a.log_marginal_likelihood_value_
+    np.testing.assert_array_equal(a.kernel_.theta, b.kernel_.theta)
+    # fit=None keeps theta and only appends
+    th = b.kernel_.theta.copy()
+    fit_gpr_parallel(b, g[p + "X"][40:44], g[p + "y"][40:44], fit=None)
+    np.testing.assert_array_equal(b.kernel_.theta, th)
+    assert b.n == 44
+
+
+# ---- two ranks over gloo -------------------------------------------------------------------
+def _farm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_multirank_cpu import GlooComm
+        from gpry_amd.parallel import fit_gpr_parallel, get_random_generator
+        g = load_golden("fit")
+        p = "f6_k3_"
+        comm = GlooComm()
+        rng = get_random_generator(11, comm)
+        gpr = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=5, random_state=rng)
+        X, y = g[p + "X"][:40], g[p + "y"][:40]
+        lml, best, lmls = fit_gpr_parallel(gpr, X, y, comm=comm, fit="full")
+        n_opt_lml = gpr.device.n_lml
+        check = gpr.log_marginal_likelihood(gpr.kernel_.theta)
+        m = gpr.predict(g[p + "Xc"][:16])
+        # second round: 'simple' = one run per rank, then theta kept on a plain append
+        lml2, best2, lmls2 = fit_gpr_parallel(gpr, g[p + "X"][40:50], g[p + "y"][40:50], comm=comm,
+                                              fit="simple")
+        th2 = gpr.kernel_.theta.copy()
+        fit_gpr_parallel(gpr, g[p + "X"][50:52], g[p + "y"][50:52], comm=comm, fit=None)
+        q.put((rank, lml, best, list(lmls), list(gpr.kernel_.theta), check, list(m), n_opt_lml,
+               lml2, best2, list(th2), bool(np.array_equal(th2, gpr.kernel_.theta)), gpr.n))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_restart_farm():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_farm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    r0, r1 = res
+    # both ranks agree on the winner, hold its theta, and their factor reproduces its LML
+    assert r0[1] == r1[1] == max(r0[3]) and r0[2] == r1[2] == int(np.argmax(r0[3]))
+    assert r0[3] == r1[3] and r0[4] == r1[4]
+    assert abs(r0[5] - r0[1]) < 1e-8 and abs(r1[5] - r1[1]) < 1e-8
+    np.testing.assert_array_equal(r0[6], r1[6])
+    assert r0[7] > 0 and r1[7] > 0          # 5 restarts -> 3 on rank 0, 2 on rank 1: both worked
+    assert r0[8] == r1[8] and r0[9] == r1[9] and r0[10] == r1[10]
+    assert r0[11] and r1[11] and r0[12] == r1[12] == 52
+
+    # serial replay of the farm in this process: same starts, same optimiser, same winner
+    g = load_golden("fit")
+    p = "f6_k3_"
+    X, y = g[p + "X"][:40], g[p + "y"][:40]
+    lm = []
+    for rank, n in ((0, 3), (1, 2)):
+        rng = np.random.default_rng(np.random.SeedSequence(11).spawn(2)[rank])
+        gpr = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=5, random_state=rng)
+        gpr.append_to_data(X, y, fit_gpr={"n_restarts": n, "start_from_current": rank == 0})
+        lm.append(gpr.log_marginal_likelihood_value_)
+    np.testing.assert_allclose(lm, r0[3], rtol=1e-12)

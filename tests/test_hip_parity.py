@@ -258,9 +258,10 @@ def test_topk_ties_exclusions_and_exhaustion(dev):
     np.testing.assert_array_equal(out2["acq"], acq)
 
 
-def test_full_size_properties_config3(dev):
-    """BASELINE configs[2] sizes (N=4096, d=16, Matern-5/2): size-independent properties."""
-    N, d, M = 4096, 16, 20000
+@pytest.mark.parametrize("N,d,kid", [(1024, 8, 0), (4096, 16, 3), (8192, 20, 3)])
+def test_full_size_properties(dev, N, d, kid):
+    """BASELINE configs 2, 3 and 5 sizes: size-independent properties of the device path."""
+    M = 20000
     bounds, X, y, Xc = orc.synthetic_problem(N, d, M)
     pre = orc.NormalizeBounds(bounds)
     X_ = pre.transform(X)
@@ -268,7 +269,7 @@ def test_full_size_properties_config3(dev):
     alpha = np.full(N, (1e-2 / ys) ** 2)
     theta = np.log(np.array([4.0] + [0.3] * d))
     dev.set_train(X_, (y - ym) / ys, alpha)
-    dev.set_theta(3, theta)
+    dev.set_theta(kid, theta)
     dev.set_affine(pre.lo, pre.hi - pre.lo, ym, ys, np.inf)
     assert dev.factorize() == 0
     L, V, a = dev.get_factor()

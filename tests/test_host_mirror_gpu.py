@@ -224,3 +224,22 @@ def test_ranked_pool_methods_agree_with_oracle():
         rp.add(Xc, ym, sm, a, method=method)
         np.testing.assert_array_equal(pool.X, rp.X)
         np.testing.assert_allclose(pool.acq_cond[:8], rp.acq_cond[:8], rtol=1e-6)
+
+
+def test_restart_farm_on_one_rank_rccl():
+    """gpry_amd.parallel.fit_gpr_parallel over a 1-rank RCCL communicator gives the plain
+    multi-restart fit (gpry/run.py:1238-1293; two gloo ranks: tests/test_fit_farm_cpu.py)."""
+    from gpry_amd import _lib
+    from gpry_amd.parallel import fit_gpr_parallel
+    g = load_golden("fit")
+    p = "f6_k3_"
+    a = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=4, random_state=3)
+    b = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=4, random_state=3)
+    X, y = g[p + "X"][:60], g[p + "y"][:60]
+    a.append_to_data(X, y, fit_gpr=True)
+    comm = _lib.RcclComm(b.device, 1, 0, _lib.RcclComm.unique_id())
+    lml, best, lmls = fit_gpr_parallel(b, X, y, comm=comm, fit="full")
+    comm.close()
+    assert best == 0 and lml == a.log_marginal_likelihood_value_
+    np.testing.assert_array_equal(a.kernel_.theta, b.kernel_.theta)
+    assert abs(lml - g[p + "lml_full"]) < 1e-5
