@@ -223,7 +223,7 @@ def main():
                   "sweep_candidates_per_s_per_gpu": M_rank / (sweep_ms * 1e-3) if sweep_ms else None,
                   "shortlist": acq.stats.get("shortlist"), "cache_models_per_step": cache_models / K,
                   "rank_host_ms": acq.stats.get("rank_s", 0) * 1e3},
-        "roofline": {"kernel": "gemm_f64_kernel<A=V row-major lower, B=K*^T, sumsq epilogue>",
+        "roofline": {"kernel": "sweep_gemm_dma_sp_kernel (V lower-triangular x K*^T panel, sum-of-squares epilogue)",
                      "bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "avg_launch_ms": gemm_ms / max(gemm_n, 1), "launches": gemm_n,

@@ -35,9 +35,10 @@ struct gpry_ctx {
     int opt_sweep_stagger = 0;
     int opt_sweep_extra_lds = 0;
     int opt_sweep_diag = 0;
-    int opt_sweep_dma = 1;       // 1: LDS-DMA staged sweep GEMM (sweep_gemm.hip, +3.6 % measured); 0: register-staged
+    int opt_sweep_dma = 3;       // 3: LDS-DMA + explicit software pipeline (default); 1: LDS-DMA; 2: 128x256 ring; 0: register-staged
     int opt_kb_tile = 64;        // kernel-build tile size (32 or 64; 64 measured faster)
     int opt_sweep_kskew = 0;
+    int opt_sweep_persist = 0;   // 1: persistent workgroups + per-XCD tile tickets (sweep_dma=3 only)
 
     // training set (transformed space)
     int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
@@ -59,6 +60,7 @@ struct gpry_ctx {
     double* dalpha_ = nullptr; // Np
     double* dvec = nullptr;    // small vectors / reductions (8 * Np + 4096 doubles)
     int* dinfo = nullptr;      // device status word(s)
+    int* dsched = nullptr;     // tile ticket counters of the persistent sweep GEMM (8 used)
     double* dparams = nullptr; // device copy of [C, 1/l..., lo..., span...] etc.
 
     // sweep state
@@ -153,11 +155,14 @@ struct GemmArgs {
     int extra_lds;         // bytes of unused dynamic LDS (occupancy experiments)
     int kskew;             // >0: rotate the slab order of tile (ti,tj) by ((ti+tj)&7)*kskew slabs
     unsigned long long* diag;  // non-null: run the stamped diagnostic build, sums land here
+    int* sched;            // persistent sweep kernel: one ticket counter per XCD
+    int persist;           // sweep_gemm_dma_sp: resident workgroups pulling tiles from g.sched
 };
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
 int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g);   // sweep_gemm.hip (LDS-DMA staging)
 int sweep_gemm_dma256_launch(gpry_ctx* ctx, const GemmArgs& g);  // 128x256 tile, 8 waves, 3-stage ring
+int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g);  // variant 1 + explicit software pipeline
 
 // ---- kernel_build.hip --------------------------------------------------------------
 int upload_params(gpry_ctx* ctx, const double* theta);

@@ -153,7 +153,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
                     ctx->dalpha_, ctx->dvec, ctx->dinfo, ctx->dparams, ctx->dXc, ctx->dmask, ctx->dy_all,
                     ctx->dsig_all, ctx->dacq_all, ctx->dKst, ctx->dpart, ctx->dkeys, ctx->dhist,
                     ctx->dcand, ctx->dsel, ctx->dU, ctx->dXkb, ctx->dkbout, ctx->pr.dXc, ctx->pr.dmask,
-                    ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq};
+                    ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq, ctx->dsched};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     (void)hipStreamDestroy(ctx->stream);
@@ -176,6 +176,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     }
     if (!strcmp(key, "timing")) { ctx->opt_timing = (int)value; return 0; }
     if (!strcmp(key, "sweep_dma")) { ctx->opt_sweep_dma = (int)value; return 0; }
+    if (!strcmp(key, "sweep_persist")) { ctx->opt_sweep_persist = (int)value; return 0; }
     if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }
     if (!strcmp(key, "sweep_kskew")) { ctx->opt_sweep_kskew = (int)value; return 0; }
     if (!strcmp(key, "sweep_diag")) { ctx->opt_sweep_diag = (int)value; return 0; }
@@ -289,6 +290,14 @@ __global__ __launch_bounds__(256) void xcc_probe_kernel(int* out) {
     for (int i = 0; i < 20; i++) __builtin_amdgcn_s_sleep(64);
     if (threadIdx.x == 0) out[blockIdx.x] = x;
 }
+__global__ __launch_bounds__(256, 2) void lds_alloc_probe_kernel(unsigned* out) {
+    // HW_REG_LDS_ALLOC (id 6), whole register; 70 KB of LDS so that two workgroups share a CU
+    __shared__ double pad[8960];
+    unsigned x = __builtin_amdgcn_s_getreg(6 | (0 << 6) | ((32 - 1) << 11));
+    pad[threadIdx.x] = (double)x;
+    for (int i = 0; i < 20; i++) __builtin_amdgcn_s_sleep(64);
+    if (threadIdx.x == 0) out[blockIdx.x] = x + (pad[5] < 0.0 ? 1u : 0u);
+}
 __global__ __launch_bounds__(256) void stream_fill_kernel(double2* __restrict__ dst, int64_t n, double v) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -361,6 +370,19 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
             if (ok > best) best = ok;
         }
         *value = (double)best / nblk;
+        (void)hipFree(d);
+    } else if (kind == 5) {   // HW_REG_LDS_ALLOC of co-resident 70-KB workgroups: histogram to stderr
+        const int nblk = 2048;
+        unsigned* d = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&d, nblk * sizeof(unsigned)));
+        hipLaunchKernelGGL(lds_alloc_probe_kernel, dim3(nblk), dim3(256), 0, ctx->stream, d);
+        std::vector<unsigned> h(nblk);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(h.data(), d, nblk * sizeof(unsigned), hipMemcpyDeviceToHost));
+        std::map<unsigned, int> hist;
+        for (unsigned v : h) hist[v]++;
+        for (auto& kv : hist) fprintf(stderr, "LDS_ALLOC 0x%08x : %d blocks\n", kv.first, kv.second);
+        *value = (double)hist.size();
         (void)hipFree(d);
     } else if (kind == 3) {   // pure streaming write (the kernel build is write-dominated)
         if (bytes < (1 << 20)) bytes = 1 << 20;

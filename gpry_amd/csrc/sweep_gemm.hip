@@ -145,7 +145,7 @@ int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g) {
     const int a = (g.tile_map >> 4) & 15, c = 6 - a;
     int64_t nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
     int64_t ns = (nsi * nsj + 7) / 8 * 8;
-    hipLaunchKernelGGL(sweep_gemm_dma_kernel, dim3((unsigned)(ns * 64)), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(sweep_gemm_dma_kernel, dim3((unsigned)(ns * 64)), dim3(256), (size_t)g.extra_lds, ctx->stream, g);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -290,6 +290,362 @@ int sweep_gemm_dma256_launch(gpry_ctx* ctx, const GemmArgs& g) {
     int64_t nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
     int64_t ns = (nsi * nsj + 7) / 8 * 8;
     hipLaunchKernelGGL(sweep_gemm_dma256_kernel, dim3((unsigned)(ns * 32)), dim3(512), 0, ctx->stream, g);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Variant 3: the 128 x 128 / 4-wave tile of variant 1 with an explicit software pipeline.
+// The compiler treats a pending LDS-DMA as a "flat" access and therefore turns every wait on
+// a fragment read into s_waitcnt lgkmcnt(0), placed right behind the newest ds_read: the
+// MFMA pipe drains while the wave sits out the LDS latency, once per k-step.  Here the
+// fragment reads are inline asm (invisible to the waitcnt pass) with hand-placed counters:
+//   * fragments are double-buffered in registers; the eight LDS reads of k-step kk+1 are
+//     issued BEFORE the 16 MFMAs of k-step kk and waited for with lgkmcnt(8) semantics
+//     (only the older fragment set must have arrived);
+//   * the slab barrier sits before the LAST k-step of a slab: behind it the wave first
+//     requests the fragments of the next slab's k-step 0 and the DMA of slab s+2 (into the
+//     buffer everybody has just finished reading), then multiplies k-step 3 -- neither the
+//     LDS latency after a barrier nor the DMA issue sits in front of an idle MFMA pipe, and
+//     a DMA piece has 1.25 slab times to land instead of 1.
+struct Frag { double a0, a1, a2, a3, b0, b1, b2, b3; };
+
+#define BUF_BYTES (BUF_DOUBLES * 8)        // 0x8800
+#define B_BASE_BYTES (A_DOUBLES * 8)       // 0x4000
+#define B_KSTEP_BYTES (4 * SMC * 8)        // 4 k-rows
+#define A_MI_BYTES (16 * 16 * 8)           // 16 rows of the unpadded V image
+
+// Eight ds_read_b64 per k-step.  ds_read_b64 banks on (addr/4) mod 64 in 32-lane groups, for
+// which both images are conflict-free; the ds_read2(st64)_b64 the compiler would merge the V
+// reads into banks on mod 32 in 16-lane groups and is 2-way conflicted on the swizzled image
+// (rows r, r+1 share a 16-B piece; SQ_LDS_BANK_CONFLICT = 40 % of the LDS cycles).
+template <int BUF, int KK>
+__device__ __forceinline__ void load_frag(Frag& f, unsigned addrA, unsigned addrB) {
+    constexpr int oa = BUF * BUF_BYTES;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.a0) : "v"(addrA), "n"(oa) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.a1) : "v"(addrA), "n"(oa + A_MI_BYTES) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.a2) : "v"(addrA), "n"(oa + 2 * A_MI_BYTES) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.a3) : "v"(addrA), "n"(oa + 3 * A_MI_BYTES) : "memory");
+    constexpr int ob = B_BASE_BYTES + BUF * BUF_BYTES + KK * B_KSTEP_BYTES;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.b0) : "v"(addrB), "n"(ob) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.b1) : "v"(addrB), "n"(ob + 128) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.b2) : "v"(addrB), "n"(ob + 256) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.b3) : "v"(addrB), "n"(ob + 384) : "memory");
+}
+
+// wait until at most NPEND LDS reads are outstanding; the fragment is threaded through the
+// statement so that its consumers cannot be moved in front of the wait
+template <int NPEND>
+__device__ __forceinline__ void wait_frag(Frag& f) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(f.a0), "+v"(f.a1), "+v"(f.a2), "+v"(f.a3), "+v"(f.b0), "+v"(f.b1), "+v"(f.b2), "+v"(f.b3)
+                 : "n"(NPEND) : "memory");
+}
+
+__device__ __forceinline__ void mma_frag(v4d (&acc)[4][4], const Frag& f) {
+    const double a[4] = {f.a0, f.a1, f.a2, f.a3};
+    const double b[4] = {f.b0, f.b1, f.b2, f.b3};
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+}
+
+__device__ __forceinline__ void mma_row(v4d (&acc)[4][4], const Frag& f, int mi) {
+    const double a = mi == 0 ? f.a0 : mi == 1 ? f.a1 : mi == 2 ? f.a2 : f.a3;
+    acc[mi][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b0, acc[mi][0], 0, 0, 0);
+    acc[mi][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b1, acc[mi][1], 0, 0, 0);
+    acc[mi][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b2, acc[mi][2], 0, 0, 0);
+    acc[mi][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b3, acc[mi][3], 0, 0, 0);
+}
+
+// DIAG build: s_memtime stamps around the slab synchronisation (they cost an extra
+// lgkmcnt(0) each, so the run is slower; the shares are what matters): g.diag[0] += cycles in
+// the vmcnt/lgkmcnt wait, [1] += cycles in s_barrier, [2] += cycles of the whole slab step,
+// [3] += wave lifetime in 100-MHz ticks, [5] += wave-slabs, [4] += wave-tiles.
+__device__ __forceinline__ void mma_half(v4d (&acc)[4][4], const Frag& f, int mi, int h) {
+    const double a = mi == 0 ? f.a0 : mi == 1 ? f.a1 : mi == 2 ? f.a2 : f.a3;
+    if (h == 0) {
+        acc[mi][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b0, acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b1, acc[mi][1], 0, 0, 0);
+    } else {
+        acc[mi][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b2, acc[mi][2], 0, 0, 0);
+        acc[mi][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b3, acc[mi][3], 0, 0, 0);
+    }
+}
+
+template <bool DIAG, int TAIL, bool PERSIST>
+__global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * BUF_DOUBLES];
+    __shared__ int s_next;
+    const int M = g.M, N = g.N, K = g.K;
+    const int tiles_m = M / BM, tiles_n = N / BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 15, gq = lane >> 4;
+    unsigned long long dsum0 = 0, dsum1 = 0, dsum2 = 0, tprev = 0, nslab_sum = 0, ntile = 0;
+    unsigned long long rstart = 0;
+    if (DIAG) rstart = __builtin_amdgcn_s_memrealtime();
+
+    // Persistent workgroups: the grid is exactly the number of resident slots (8 XCDs x
+    // slots per XCD); a workgroup takes its first tile from its block index and every further
+    // one from its XCD's ticket counter g.sched[xcd] (fetched at the start of the current
+    // tile, so the atomic's latency is hidden).  The hardware dispatcher hands out workgroups
+    // in order and round-robin over the shader engines, which left 5 % of the wave slots empty
+    // when every tile was its own workgroup (tiles differ 32x in length).
+    const int xcd = blockIdx.x & 7;
+    const int ta = (g.tile_map >> 4) & 15, tc = 6 - ta;
+    const int nsi = (tiles_m + (1 << ta) - 1) >> ta, nsj = (tiles_n + (1 << tc) - 1) >> tc;
+    const int q_end = ((nsi * nsj + 7) / 8) * 64;       // tickets per XCD
+    int q = blockIdx.x >> 3;
+    int vx = xcd, hop = 0;      // queue being served: the own XCD's first, the others' leftovers last
+  while (true) {
+    if (q >= q_end) {
+        // this queue is exhausted: help the next XCD with its tail (synchronous fetch, tail only)
+        if (!PERSIST || ++hop == 8) break;
+        vx = (xcd + hop) & 7;
+        if (threadIdx.x == 0) s_next = atomicAdd(&g.sched[vx], 1);
+        __syncthreads();
+        q = s_next;
+        __syncthreads();
+        continue;
+    }
+    int q_next = 0;
+    if (PERSIST && threadIdx.x == 0) q_next = atomicAdd(&g.sched[vx], 1);
+    int ti, tj;
+    bool valid;
+    {
+        const int s = (q >> 6) * 8 + vx, within = q & 63;
+        const int si = nsi - 1 - s / nsj, sj = s % nsj;
+        ti = (si << ta) + (within >> tc);
+        tj = (sj << tc) + (within & ((1 << tc) - 1));
+        valid = s < nsi * nsj && ti < tiles_m && tj < tiles_n;
+    }
+    if (valid) {
+    const int row0 = ti * BM, col0 = tj * BN;
+    const int kend = min(K, row0 + BM);
+    const int nslab = kend / BK;          // multiple of 8
+
+    const double* srcA[4];
+    int dstA[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q = wave * 4 + j;
+        const int row = q * 8 + (lane >> 3), pp = lane & 7;
+        const int p = pp ^ ((row >> 1) & 7);
+        srcA[j] = g.A + (int64_t)(row0 + row) * g.lda + 2 * p;
+        dstA[j] = q * 128;
+    }
+    const double* srcB = g.B + (int64_t)(wave * 4) * g.ldb + col0 + 2 * lane;
+
+    auto issue = [&](int s, int buf) {
+        double* As = smem + buf * BUF_DOUBLES;
+        double* Bs = As + A_DOUBLES;
+        const int k0 = s * BK;
+#pragma unroll
+        for (int j = 0; j < 4; j++) dma16(srcA[j] + k0, As + dstA[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) dma16(srcB + (int64_t)(k0 + j) * g.ldb, Bs + (wave * 4 + j) * SMC);
+    };
+    // one eighth of a slab's DMA (piece j of V for j < 4, piece j-4 of K*^T otherwise)
+    auto issue_piece = [&](int s, int buf, int j) {
+        double* As = smem + buf * BUF_DOUBLES;
+        double* Bs = As + A_DOUBLES;
+        const int k0 = s * BK;
+        if (j < 4) dma16(srcA[j] + k0, As + dstA[j]);
+        else dma16(srcB + (int64_t)(k0 + j - 4) * g.ldb, Bs + (wave * 4 + j - 4) * SMC);
+    };
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // LDS byte addresses of this lane's fragments (buffer and k-step of B are immediates).
+    // A image: row (wr*64 + mi*16 + r) at 128 B per row, 16-B piece ((k>>1) ^ key), key =
+    // (row>>1)&7 = (r>>1)&7 for every mi; k = kk*4 + gq  =>  piece = ((gq>>1) ^ key) ^ (2*kk).
+    const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
+    unsigned addrA[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+        addrA[kk] = smem_base + (wr * 64 + r) * 128 + 16 * ((((gq >> 1) ^ (r >> 1)) & 7) ^ (2 * kk)) + 8 * (gq & 1);
+    const unsigned addrB = smem_base + gq * (SMC * 8) + (wc * 64 + r) * 8;
+
+    issue(0, 0);
+    issue(1, 1);                                             // nslab >= 8
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // slab 0 landed, slab 1 in flight
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    Frag f0, f1;
+    load_frag<0, 0>(f0, addrA[0], addrB);
+    if (DIAG) {
+        wait_frag<0>(f0);
+        tprev = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+#define SLAB_STEP(BUF, S)                                                                    \
+    {                                                                                        \
+        load_frag<BUF, 1>(f1, addrA[1], addrB);                                              \
+        wait_frag<8>(f0);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_frag(acc, f0);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        load_frag<BUF, 2>(f0, addrA[2], addrB);                                              \
+        wait_frag<8>(f1);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_frag(acc, f1);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        load_frag<BUF, 3>(f1, addrA[3], addrB);                                              \
+        wait_frag<8>(f0);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_frag(acc, f0);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        /* every wave holds its last fragments of slab S; slab S+1 has landed everywhere */  \
+        if (DIAG) {                                                                          \
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();                      \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 \
+            wait_frag<0>(f1);                                                                \
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();                      \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+            __builtin_amdgcn_s_barrier();                                                    \
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();                      \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+            dsum0 += t1 - t0; dsum1 += t2 - t1; dsum2 += t0 - tprev; tprev = t0;             \
+        } else {                                                                             \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 \
+            wait_frag<0>(f1);                                                                \
+            __builtin_amdgcn_s_barrier();                                                    \
+        }                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        /* branch-free tail: the last slabs re-fetch slab nslab-1 into the (dead) buffer and  \
+           read fragments nobody uses, so that the DMA issue and the fragment reads of the    \
+           next slab can sit in the shadow of k-step 3's MFMAs */                              \
+        const int s2 = min((S) + 2, nslab - 1);                                              \
+        if (TAIL == 1) {                                                                     \
+        mma_half(acc, f1, 0, 0);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        load_frag<(BUF) ^ 1, 0>(f0, addrA[0], addrB);                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_half(acc, f1, 0, 1);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        issue_piece(s2, BUF, 0);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_half(acc, f1, 1, 0);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        issue_piece(s2, BUF, 1);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_half(acc, f1, 1, 1);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        issue_piece(s2, BUF, 2);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_half(acc, f1, 2, 0);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        issue_piece(s2, BUF, 3);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_half(acc, f1, 2, 1);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        issue_piece(s2, BUF, 4);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_half(acc, f1, 3, 0);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        issue_piece(s2, BUF, 5); issue_piece(s2, BUF, 6);                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_half(acc, f1, 3, 1);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        issue_piece(s2, BUF, 7);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        } else {                                                                             \
+        mma_row(acc, f1, 0);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        load_frag<(BUF) ^ 1, 0>(f0, addrA[0], addrB);                                        \
+        issue_piece(s2, BUF, 0); issue_piece(s2, BUF, 1);                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_row(acc, f1, 1);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        issue_piece(s2, BUF, 2); issue_piece(s2, BUF, 3); issue_piece(s2, BUF, 4);           \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_row(acc, f1, 2);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        issue_piece(s2, BUF, 5); issue_piece(s2, BUF, 6); issue_piece(s2, BUF, 7);           \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mma_row(acc, f1, 3);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                    \
+    }
+
+    for (int s = 0; s < nslab; s += 2) {
+        SLAB_STEP(0, s)
+        SLAB_STEP(1, s + 1)
+    }
+#undef SLAB_STEP
+
+    double cs[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) sacc = fma(acc[mi][ni][q], acc[mi][ni][q], sacc);
+        sacc += __shfl_xor(sacc, 16);
+        sacc += __shfl_xor(sacc, 32);
+        cs[ni] = sacc;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // trailing DMA / fragment reads
+    if (DIAG) { nslab_sum += nslab; ntile += 1; }
+    __syncthreads();
+    double* red = smem;
+    if (gq == 0) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) red[wr * 128 + wc * 64 + ni * 16 + r] = cs[ni];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128)
+        g.C[(int64_t)ti * g.ldc + col0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
+    }  // valid
+    if (!PERSIST) break;
+    if (threadIdx.x == 0) s_next = q_next;
+    __syncthreads();      // also: everybody is done with `red` before the next tile's DMA
+    q = s_next;
+  }  // ticket loop
+    if (DIAG && g.diag != nullptr && lane == 0) {
+        atomicAdd(&g.diag[0], dsum0); atomicAdd(&g.diag[1], dsum1); atomicAdd(&g.diag[2], dsum2);
+        // [3]: lifetime of the wave in 100-MHz ticks (slot occupancy = sum / (slots * kernel time))
+        atomicAdd(&g.diag[3], __builtin_amdgcn_s_memrealtime() - rstart); atomicAdd(&g.diag[4], ntile);
+        atomicAdd(&g.diag[5], nslab_sum);
+    }
+}
+
+int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g0) {
+    GemmArgs g = g0;
+    if (g.M % BM || g.N % BN || g.K % BM) return gpry_fail(ctx, -1, "sweep_gemm_dma_sp: dims must be multiples of 128");
+    if (!ctx->dsched) GPRY_TRY(dev_alloc(ctx, &ctx->dsched, 64));
+    // resident slots: two 69.6-KB workgroups per CU (one if extra LDS is requested), 32 CUs per XCD
+    const int per_cu = (2 * (int)sizeof(double) * BUF_DOUBLES + g.extra_lds) * 2 <= 160 * 1024 ? 2 : 1;
+    const int slots = 32 * per_cu;
+    if (g.persist) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->dsched, slots, 8, ctx->stream));
+    g.sched = ctx->dsched;
+    const dim3 grid((unsigned)(8 * slots));
+    const int tiles_m = g.M / BM, tiles_n = g.N / BN;
+    const int a = (g.tile_map >> 4) & 15, c = 6 - a;
+    const int64_t nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
+    const dim3 grid_all((unsigned)(((nsi * nsj + 7) / 8 * 8) * 64));
+    // default: one workgroup per tile (grid launch); persist=1: resident workgroups + tickets
+    // (keeps 97 % instead of 95 % of the wave slots filled but is ~1 % slower end to end: a lone
+    // workgroup already keeps the matrix pipe 90 % busy, and the chip is power-limited)
+    const size_t xl = (size_t)g.extra_lds;
+    if (g.persist) {
+        if (g.diag) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<true, 0, true>), grid, dim3(256), xl, ctx->stream, g);
+        else hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, 0, true>), grid, dim3(256), xl, ctx->stream, g);
+    } else {
+        if (g.diag) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<true, 0, false>), grid_all, dim3(256), xl, ctx->stream, g);
+        else if (g.kskew == 1) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, 1, false>), grid_all, dim3(256), xl, ctx->stream, g);
+        else hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, 0, false>), grid_all, dim3(256), xl, ctx->stream, g);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
