@@ -25,6 +25,8 @@ struct StageTimer {
 struct gpry_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // cross-kernel panels of the sweep are built here (overlap)
+    hipEvent_t ev_start = nullptr, ev_built[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     char err[1024] = {0};
 
     // options
@@ -38,6 +40,7 @@ struct gpry_ctx {
     int opt_sweep_dma = 3;       // 3: LDS-DMA + explicit software pipeline (default); 1: LDS-DMA; 2: 128x256 ring; 0: register-staged
     int opt_kb_tile = 64;        // kernel-build tile size (32 or 64; 64 measured faster)
     int opt_sweep_kskew = 0;
+    int opt_sweep_overlap = 0;   // 1: build the panel of chunk c+1 on a second stream while chunk c is contracted (measured: slower, the co-running cross_build costs the contraction +10 %)
     int opt_sweep_persist = 0;   // 1: persistent workgroups + per-XCD tile tickets (sweep_dma=3 only)
 
     // training set (transformed space)
@@ -116,8 +119,8 @@ int gpry_fail(gpry_ctx* ctx, int code, const char* fmt, ...);
 
 // scoped device timing of one stage on ctx->stream
 struct StageScope {
-    gpry_ctx* ctx; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr;
-    StageScope(gpry_ctx* c, const char* n);
+    gpry_ctx* ctx; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr;
+    StageScope(gpry_ctx* c, const char* n, hipStream_t stream = nullptr);
     ~StageScope();
 };
 void timers_collect(gpry_ctx* ctx);
@@ -169,7 +172,8 @@ int upload_params(gpry_ctx* ctx, const double* theta);
 int launch_scale_train(gpry_ctx* ctx);                         // dXs from dX and theta
 int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise); // full symmetric K
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
-                       int64_t ldk, double* Kst, double* mean_part, int raw_affine);
+                       int64_t ldk, double* Kst, double* mean_part, int raw_affine,
+                       hipStream_t st = nullptr);
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
                       double* grad_out_dev);
 

@@ -34,14 +34,15 @@ int dev_free(gpry_ctx* ctx, void* p) {
     return 0;
 }
 
-StageScope::StageScope(gpry_ctx* c, const char* n) : ctx(c), name(n) {
+StageScope::StageScope(gpry_ctx* c, const char* n, hipStream_t stream) : ctx(c), name(n) {
+    st = stream ? stream : ctx->stream;
     if (!ctx->opt_timing) return;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
-    (void)hipEventRecord(e0, ctx->stream);
+    (void)hipEventRecord(e0, st);
 }
 StageScope::~StageScope() {
     if (!e0) return;
-    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventRecord(e1, st);
     ctx->timers[name].pending.push_back({e0, e1});
 }
 void timers_collect(gpry_ctx* ctx) {
@@ -137,6 +138,11 @@ int gpry_ctx_create(int device, gpry_ctx** out) {
     ctx->tf.y_std = 1.0; ctx->tf.clip_hi = INFINITY;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    hipEvent_t* evs[] = {&ctx->ev_start, &ctx->ev_built[0], &ctx->ev_built[1], &ctx->ev_free[0], &ctx->ev_free[1]};
+    for (hipEvent_t* ev : evs)
+        if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipEventCreate"); }
     if (hipMalloc((void**)&ctx->dinfo, 16 * sizeof(int)) != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipMalloc info"); }
     (void)hipMemset(ctx->dinfo, 0, 16 * sizeof(int));
     *out = ctx;
@@ -147,6 +153,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     timers_collect(ctx);
     trtri_plan_free(ctx);
     void* bufs[] = {ctx->dX, ctx->dXs, ctx->dy, ctx->dnoise, ctx->dA, ctx->dV, ctx->dW, ctx->dW2, ctx->dW3,
@@ -157,6 +164,9 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (hipEvent_t ev : {ctx->ev_start, ctx->ev_built[0], ctx->ev_built[1], ctx->ev_free[0], ctx->ev_free[1]})
+        if (ev) (void)hipEventDestroy(ev);
     delete ctx;
     return 0;
 }
@@ -177,6 +187,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "timing")) { ctx->opt_timing = (int)value; return 0; }
     if (!strcmp(key, "sweep_dma")) { ctx->opt_sweep_dma = (int)value; return 0; }
     if (!strcmp(key, "sweep_persist")) { ctx->opt_sweep_persist = (int)value; return 0; }
+    if (!strcmp(key, "sweep_overlap")) { ctx->opt_sweep_overlap = (int)value; return 0; }
     if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }
     if (!strcmp(key, "sweep_kskew")) { ctx->opt_sweep_kskew = (int)value; return 0; }
     if (!strcmp(key, "sweep_diag")) { ctx->opt_sweep_diag = (int)value; return 0; }

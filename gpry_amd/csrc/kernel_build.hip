@@ -251,14 +251,15 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
 }
 
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk,
-                       double* Kst, double* mean_part, int raw_affine) {
+                       double* Kst, double* mean_part, int raw_affine, hipStream_t st) {
+    if (!st) st = ctx->stream;
     KernParams kp = make_kp(ctx);
     kp.has_aff = raw_affine && ctx->tf.has_x_affine;
     AffParams ap = make_ap(ctx, kp.has_aff);
     dim3 grid((unsigned)((mc + 255) / 256), (unsigned)(ctx->Np / 128));
     int64_t M = ctx->sw_M;
     if (ctx->d > 32) return gpry_fail(ctx, -1, "d > 32 is not supported");
-#define CB2(DP, KID) hipLaunchKernelGGL((cross_build_kernel<DP, KID>), grid, dim3(256), 0, ctx->stream, Xc, M, \
+#define CB2(DP, KID) hipLaunchKernelGGL((cross_build_kernel<DP, KID>), grid, dim3(256), 0, st, Xc, M, \
                                         m0, mc, ctx->dXs, ctx->dalpha_, Kst, ldk, mean_part, kp, ap)
 #define CB4(KID) { if (ctx->d <= 4) CB2(4, KID); else if (ctx->d <= 8) CB2(8, KID); \
                    else if (ctx->d <= 16) CB2(16, KID); else CB2(32, KID); }
