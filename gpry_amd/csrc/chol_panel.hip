@@ -115,8 +115,14 @@ __device__ __forceinline__ void store_block(double* __restrict__ G, int64_t ld, 
     }
 }
 
+// `arrive` / `target`: the diagonal workgroup overwrites D with its factor in place, while every
+// other workgroup of the launch reads D.  Workgroups count in on `arrive` once their loads have
+// landed, and the diagonal workgroup stores only when all of them have (target = arrivals
+// expected up to and including this launch).  Without this the result depends on all workgroups
+// starting before the first one finishes -- not true when another stream shares the GPU.
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int64_t ld, int64_t j0,
-                                                         int64_t K0, int64_t n_real, int* info) {
+                                                         int64_t K0, int64_t n_real, int* info,
+                                                         int* arrive, int target) {
     __shared__ __attribute__((aligned(16))) double sD[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sB[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sPt[64 * PLD];
@@ -136,6 +142,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
         if (!is_diag) load_block(A + R * ld + K0, ld, sPo, t);
     }
     __syncthreads();
+    if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- left-looking update with the previous 64 columns of the outer panel
     if (kprev) {
 #pragma unroll
@@ -181,6 +188,10 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
         return;
     }
     if (is_diag) {
+        if (t == 0)
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+                __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
         store_block(A + j0 * ld + j0, ld, sD, t, true);
         return;
     }
@@ -202,25 +213,66 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
 
 // A = L L^T in place (lower; the strict upper triangle is left untouched).  Outer blocks of
 // 128 columns: two fused panel steps, then one MFMA SYRK (K = 128) on the trailing matrix.
+// Trailing update C -= P P^T (lower tiles only) of the rows/cols [r0, Np) x [c0, c0 + nc) with the
+// 128-column panel P = A[:, K0:K0+128].
+static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int64_t r0, int64_t c0,
+                           int64_t nc, hipStream_t st) {
+    if (r0 >= Np || nc <= 0) return 0;
+    GemmArgs g = {};
+    g.A = A + r0 * Np + K0; g.lda = Np;
+    g.B = A + c0 * Np + K0; g.ldb = Np;
+    g.C = A + r0 * Np + c0; g.ldc = Np;
+    g.M = (int)(Np - r0); g.N = (int)nc; g.K = 128;
+    g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo; g.stream = st;
+    return gemm_f64_launch(ctx, g, false, true, EPI_SUB);
+}
+
 int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 2 * sizeof(int), st));
-    for (int64_t K0 = 0; K0 < Np; K0 += 128) {
-        for (int64_t j0 = K0; j0 < K0 + 128; j0 += 64) {
-            unsigned nblk = (unsigned)((Np - j0) / 64);
-            hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), 0, st, A, Np, j0, K0, ctx->N, ctx->dinfo);
-        }
-        int64_t rest = Np - (K0 + 128);
-        if (rest > 0) {
-            GemmArgs g = {};
-            g.A = A + (K0 + 128) * Np + K0; g.lda = Np;
-            g.B = g.A; g.ldb = Np;
-            g.C = A + (K0 + 128) * Np + (K0 + 128); g.ldc = Np;
-            g.M = (int)rest; g.N = (int)rest; g.K = 128;
-            g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
-            GPRY_TRY(gemm_f64_launch(ctx, g, false, true, EPI_SUB));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
+    int arrivals = 0;
+    // Look-ahead: after panel k only the next panel's 128 columns of the trailing matrix are
+    // updated on the main stream; the rest of the update runs on stream2 underneath panel k+1
+    // (the panel chain is latency-bound and leaves the machine empty).  Every element still
+    // receives its rank-128 updates in the same order from the same kernel: bit-identical.
+    const bool la = ctx->opt_chol_lookahead && ctx->stream2 != nullptr && Np > 512;
+    bool rest_pending = false;
+    if (la) {
+        const size_t need = 2 * (size_t)(Np / 128);
+        while (ctx->ev_pool.size() < need) {
+            hipEvent_t ev;
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->ev_pool.push_back(ev);
         }
     }
+    int step = 0;
+    hipEvent_t ev_rest_prev = nullptr;
+    for (int64_t K0 = 0; K0 < Np; K0 += 128, step++) {
+        for (int64_t j0 = K0; j0 < K0 + 128; j0 += 64) {
+            unsigned nblk = (unsigned)((Np - j0) / 64);
+            arrivals += (int)nblk;
+            hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), 0, st, A, Np, j0, K0, ctx->N, ctx->dinfo,
+                               ctx->dinfo + 2, arrivals);
+        }
+        const int64_t r0 = K0 + 128;
+        if (r0 >= Np) break;
+        if (!la) {
+            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0, r0, Np - r0, st));
+            continue;
+        }
+        hipEvent_t ev_panel = ctx->ev_pool[2 * step], ev_rest = ctx->ev_pool[2 * step + 1];
+        HIP_TRY(ctx, hipEventRecord(ev_panel, st));                            // panel k done
+        if (rest_pending) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_rest_prev, 0));      // rest(k-1) done
+        GPRY_TRY(trailing_update(ctx, A, Np, K0, r0, r0, 128, st));            // next panel's columns
+        if (r0 + 128 < Np) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ev_panel, 0));
+            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0 + 128, r0 + 128, Np - r0 - 128, ctx->stream2));
+            HIP_TRY(ctx, hipEventRecord(ev_rest, ctx->stream2));
+            ev_rest_prev = ev_rest;
+            rest_pending = true;
+        }
+    }
+    if (rest_pending) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_rest_prev, 0));
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

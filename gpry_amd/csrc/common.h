@@ -27,6 +27,7 @@ struct gpry_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // cross-kernel panels of the sweep are built here (overlap)
     hipEvent_t ev_start = nullptr, ev_built[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev_pool;        // one pair per Cholesky look-ahead step (never re-recorded within a call)
     char err[1024] = {0};
 
     // options
@@ -42,6 +43,8 @@ struct gpry_ctx {
     int opt_sweep_kskew = 0;
     int opt_sweep_overlap = 0;   // 1: build the panel of chunk c+1 on a second stream while chunk c is contracted (measured: slower, the co-running cross_build costs the contraction +10 %)
     int opt_sweep_persist = 0;   // 1: persistent workgroups + per-XCD tile tickets (sweep_dma=3 only)
+    int opt_chol_lookahead = 0;  // 1: trailing update of the next panel's columns first, the rest on stream2
+                                 // (bit-identical; 4.50 vs 4.14 ms at N=4096: cross-stream events cost more than the overlap saves)
 
     // training set (transformed space)
     int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
@@ -160,6 +163,7 @@ struct GemmArgs {
     unsigned long long* diag;  // non-null: run the stamped diagnostic build, sums land here
     int* sched;            // persistent sweep kernel: one ticket counter per XCD
     int persist;           // sweep_gemm_dma_sp: resident workgroups pulling tiles from g.sched
+    hipStream_t stream;    // null: ctx->stream
 };
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);

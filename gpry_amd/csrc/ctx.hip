@@ -167,6 +167,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (hipEvent_t ev : {ctx->ev_start, ctx->ev_built[0], ctx->ev_built[1], ctx->ev_free[0], ctx->ev_free[1]})
         if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     delete ctx;
     return 0;
 }
@@ -188,6 +189,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "sweep_dma")) { ctx->opt_sweep_dma = (int)value; return 0; }
     if (!strcmp(key, "sweep_persist")) { ctx->opt_sweep_persist = (int)value; return 0; }
     if (!strcmp(key, "sweep_overlap")) { ctx->opt_sweep_overlap = (int)value; return 0; }
+    if (!strcmp(key, "chol_lookahead")) { ctx->opt_chol_lookahead = (int)value; return 0; }
     if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }
     if (!strcmp(key, "sweep_kskew")) { ctx->opt_sweep_kskew = (int)value; return 0; }
     if (!strcmp(key, "sweep_diag")) { ctx->opt_sweep_diag = (int)value; return 0; }

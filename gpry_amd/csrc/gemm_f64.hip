@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
 template <bool AT, bool BT>
 static int launch_epi(gpry_ctx* ctx, const GemmArgs& g, int epi, dim3 grid) {
-    hipStream_t st = ctx->stream;
+    hipStream_t st = g.stream ? g.stream : ctx->stream;
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_STORE>), grid, dim3(256), (size_t)g.extra_lds, st, g); break;
         case EPI_STORE_NEG: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_STORE_NEG>), grid, dim3(256), (size_t)g.extra_lds, st, g); break;

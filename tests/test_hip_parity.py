@@ -310,3 +310,26 @@ def test_rccl_communicator_single_rank(dev):
     np.testing.assert_array_equal(comm.allreduce_max(x), x)
     comm.barrier()
     comm.close()
+
+
+def test_cholesky_with_concurrent_trailing_update_is_bit_identical(dev):
+    """The look-ahead schedule (trailing update on a second stream underneath the next panel)
+    must reproduce the in-order factor bit for bit.  Regression test for a race it exposed:
+    the diagonal workgroup of a panel step used to overwrite D with its factor while late
+    workgroups of the same launch were still reading D."""
+    N, d = 8192, 20
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 1, (N, d))
+    dev.set_train(X, rng.standard_normal(N), np.full(N, 1e-4))
+    dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
+    try:
+        dev.set_option("chol_lookahead", 0)
+        assert dev.factorize() == 0
+        L0 = np.tril(dev.get_factor(want_V=False, want_alpha=False)[0])
+        dev.set_option("chol_lookahead", 1)
+        for _ in range(2):
+            assert dev.factorize() == 0
+            L1 = np.tril(dev.get_factor(want_V=False, want_alpha=False)[0])
+            assert np.array_equal(L0, L1)
+    finally:
+        dev.set_option("chol_lookahead", 0)
