@@ -57,6 +57,7 @@ SIGNATURES = {
     "gpry_get_factor": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gpry_lml": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_double), _vp, _P(C.c_int)]),
     "gpry_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "gpry_predict_grad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     "gpry_sweep_logexp": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_double, C.c_double,
                                     C.c_double, _vp, _vp, _vp, _P(C.c_int64)]),
     "gpry_sweep_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _P(C.c_int64),
@@ -250,6 +251,16 @@ class Device:
             self._check(self._lib.gpry_predict(self._h, _ptr(X), M, _ptr(mask), _ptr(mean),
                                                _ptr(std)), "gpry_predict")
         return (mean, std) if return_std else mean
+
+    def predict_grad(self, x, want_kinv=True, want_kgrad=False, want_mean=True):
+        """x-gradient contractions for one point: ``(G^T alpha_, G^T K^-1 k*[, G])``."""
+        x = _f64(x, (self.d,))
+        mg = np.empty(self.d) if want_mean else None
+        kg = np.empty(self.d)
+        G = np.empty((self.N, self.d)) if want_kgrad else None
+        self._check(self._lib.gpry_predict_grad(self._h, _ptr(x), int(bool(want_kinv)), _ptr(G),
+                                                _ptr(mg), _ptr(kg)), "gpry_predict_grad")
+        return (mg, kg, G) if want_kgrad else (mg, kg)
 
     def sweep_logexp(self, X, zeta, baseline, sigma_n, mask=None, M=None, want=("y", "sigma", "acq")):
         """Run the fused sweep.  ``X=None`` re-uses the candidate set resident on the device."""

@@ -54,24 +54,41 @@ class LogExp(AcquisitionFunction):
                     np.log(np.sqrt(np.clip(std ** 2. - noise_level ** 2., 0., None))))
 
     def __call__(self, X, gp, eval_gradient=False):
-        if eval_gradient:
-            raise NotImplementedError("x-gradients of the acquisition function are not on the "
-                                      "device path yet (SURVEY.md section 8f, item 3)")
+        """Value (and x-gradient, gpry/acquisition_functions.py:937-1009) at ``X``."""
         X = self.check_X(X)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            mu, std = gp.predict(X, return_std=True)
+            if eval_gradient:
+                mu, std, mu_grad, std_grad = gp.predict(X, return_std=True, return_mean_grad=True,
+                                                        return_std_grad=True)
+            else:
+                mu, std = gp.predict(X, return_std=True)
         if self.sigma_n is None:
             sigma_n = gp.noise_level
             noise = np.mean(sigma_n) if isinstance(sigma_n, Iterable) else sigma_n
         else:
-            noise = self.sigma_n
+            noise = sigma_n = self.sigma_n
         var = std ** 2 - noise ** 2.
         mask = (var > 0) & np.isfinite(mu)
         values = np.full_like(std, -np.inf)
         if np.any(mask):
             values[mask] = self.f(mu[mask], std[mask], gp.y_max, noise, self.zeta)
-        return values
+        if not eval_gradient:
+            return values
+        # the reference's gradient: std_grad / (std - sigma_n) + 2 zeta mu_grad, +inf where
+        # std <= sigma_n (:993-1007; it uses the raw gp.noise_level here, as we do)
+        if np.array(std_grad).ndim > 1:
+            grad = np.zeros_like(std_grad)
+            if np.any(mask):
+                grad[mask] = np.array(std_grad)[mask] / (std[mask] - sigma_n) + \
+                    2 * self.zeta * np.array(mu_grad)[mask]
+            if np.any(~mask):
+                grad[~mask] = np.ones_like(std_grad[~mask]) * np.inf
+        elif std[0] > sigma_n:
+            grad = std_grad / (std[0] - sigma_n) + 2 * self.zeta * mu_grad
+        else:
+            grad = np.ones_like(std_grad) * np.inf
+        return values, grad
 
     def __repr__(self):
         return f"LogExp(zeta={self.zeta:.3f})"

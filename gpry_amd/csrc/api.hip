@@ -368,6 +368,39 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
     return 0;
 }
 
+int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgrad, double* mean_grad,
+                      double* kinvk_grad) {
+    GPRY_TRY(require_model(ctx, want_kinv || mean_grad != nullptr));   // kgrad alone needs no factor
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!x) return gpry_fail(ctx, -1, "predict_grad: x is NULL");
+    const int64_t Np = ctx->Np;
+    const int dpad = ctx->dpad, d = ctx->d;
+    if (Np * dpad > ctx->g_cap) {
+        if (ctx->dG) GPRY_TRY(dev_free(ctx, ctx->dG));
+        ctx->dG = nullptr; ctx->g_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dG, Np * dpad));
+        ctx->g_cap = Np * dpad;
+    }
+    if (!ctx->factor_valid) GPRY_TRY(launch_scale_train(ctx));   // scaled rows are normally made by the factorisation
+    if (want_kinv) GPRY_TRY(ensure_part(ctx, (Np / 128) * Np));
+    double* kstar = ctx->dvec; double* u = ctx->dvec + Np; double* w = ctx->dvec + 2 * Np;
+    double* out = ctx->dvec + 3 * Np; double* xdev = out + 2 * GPRY_MAX_DIM;
+    HIP_TRY(ctx, hipMemcpyAsync(xdev, x, sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
+    {
+        StageScope s(ctx, "predict_grad");
+        GPRY_TRY(launch_gradx(ctx, xdev, 1, want_kinv, kstar, ctx->dG, u, w, ctx->dpart, out));
+    }
+    double h[2 * GPRY_MAX_DIM];
+    HIP_TRY(ctx, hipMemcpyAsync(h, out, sizeof(double) * 2 * dpad, hipMemcpyDeviceToHost, ctx->stream));
+    if (kgrad) GPRY_TRY(copy_out_matrix(ctx, ctx->dG, dpad, ctx->N, d, kgrad));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < d; k++) {
+        if (mean_grad) mean_grad[k] = h[k];
+        if (kinvk_grad) kinvk_grad[k] = want_kinv ? h[dpad + k] : 0.0;
+    }
+    return 0;
+}
+
 int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask, double zeta,
                       double baseline, double sigma_n, double* y_all, double* sigma_all, double* acq_all,
                       int64_t* n_nan) {

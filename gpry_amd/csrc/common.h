@@ -82,6 +82,8 @@ struct gpry_ctx {
     } pr;
     double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
     int64_t kst_cap = 0;       // doubles allocated
+    double* dG = nullptr;      // Np x dpad: d k(x, X_j)/dx of the last gpry_predict_grad
+    int64_t g_cap = 0;
     double* dpart = nullptr;   // partial sums (sumsq per i-tile, mean per j-chunk)
     int64_t part_cap = 0;
     // top-k scratch
@@ -178,6 +180,8 @@ int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise); // full symmet
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
                        int64_t ldk, double* Kst, double* mean_part, int raw_affine,
                        hipStream_t st = nullptr);
+int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, double* kstar, double* G,
+                 double* u, double* w, double* part, double* out);
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
                       double* grad_out_dev);
 

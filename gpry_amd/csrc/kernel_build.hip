@@ -466,3 +466,125 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, do
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------
+// x-gradients for one point (gpry/gpr.py:1236-1266 with
+// gpry/kernels.py:257-278 RBF, :326-432 Matern, :687-699 product rule): for every training row j
+//   kstar[j] = C k(x, X_j),   G[j][k] = C d k(x, X_j) / d x_k     (coordinates of the kernel)
+// with diff = (x - X_j) / l, r = |diff|:
+//   RBF         -exp(-r^2/2) diff/l
+//   Matern 1/2  -exp(-r)/r diff/l        (r = 0: -1/l, the reference's fill value)
+//   Matern 3/2  -3 exp(-sqrt3 r) diff/l
+//   Matern 5/2  -(5/3) (1 + sqrt5 r) exp(-sqrt5 r) diff/l
+// Thread <-> training row; rows j >= N give zeros.
+template <int KID>
+__global__ __launch_bounds__(256) void gradx_kernel(const double* __restrict__ x, const double* __restrict__ Xs,
+                                                    double* __restrict__ kstar, double* __restrict__ G,
+                                                    int64_t Np, KernParams kp, AffParams ap) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= Np) return;
+    double diff[GPRY_MAX_DIM];
+    double r2 = 0.0;
+    for (int k = 0; k < kp.d; k++) {
+        double v = x[k];
+        if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
+        v = v / ap.ls[k];
+        diff[k] = v - Xs[j * kp.dpad + k];
+        r2 = fma(diff[k], diff[k], r2);
+    }
+    const bool real = j < kp.N;
+    double kv, coef;      // k(r) and the factor of diff/l
+    if (KID == GPRY_RBF) { kv = exp(-0.5 * r2); coef = -kv; }
+    else if (KID == GPRY_MATERN12) { double r = sqrt(r2); kv = exp(-r); coef = r != 0.0 ? -kv / r : 0.0; }
+    else if (KID == GPRY_MATERN32) { double t = sqrt(r2) * SQRT3; double e = exp(-t); kv = (1.0 + t) * e; coef = -3.0 * e; }
+    else { double t = sqrt(r2) * SQRT5; double e = exp(-t); kv = (1.0 + t + t * t * (1.0 / 3.0)) * e; coef = -(5.0 / 3.0) * (1.0 + t) * e; }
+    kstar[j] = real ? kp.C * kv : 0.0;
+    for (int k = 0; k < kp.dpad; k++) {
+        double g = 0.0;
+        if (real && k < kp.d) {
+            g = kp.C * coef * diff[k] / ap.ls[k];
+            if (KID == GPRY_MATERN12 && r2 == 0.0) g = -kp.C / ap.ls[k];
+        }
+        G[j * kp.dpad + k] = g;
+    }
+}
+
+// u = V kstar (V lower triangular, row-major): one wave per row
+__global__ __launch_bounds__(256) void gx_trmv_lower_kernel(const double* __restrict__ V, int64_t ld,
+                                                         const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    double s = 0.0;
+    for (int64_t k = lane; k <= i; k += 64) s = fma(V[i * ld + k], x[k], s);
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[i] = s;
+}
+// partial sums of w = V^T u: block (cb, rb) covers columns cb*256.. and rows rb*128..; thread <->
+// column (coalesced along the row); part[rb][j].  Deterministic (no atomics).
+__global__ __launch_bounds__(256) void gx_trmv_lower_t_part_kernel(const double* __restrict__ V, int64_t ld,
+                                                                const double* __restrict__ u,
+                                                                double* __restrict__ part, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * 128;
+    double s = 0.0;
+    if (j < n && i0 + 127 >= j) {
+        const int64_t ib = i0 > j ? i0 : j;
+        for (int64_t i = ib; i < i0 + 128 && i < n; i++) s = fma(V[i * ld + j], u[i], s);
+    }
+    if (j < n) part[(int64_t)blockIdx.y * n + j] = s;
+}
+__global__ void gx_colsum_kernel(const double* __restrict__ part, int nrow, int64_t n, double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int r = 0; r < nrow; r++) s += part[(int64_t)r * n + j];
+    out[j] = s;
+}
+// out[k] = sum_j G[j][k] a[j] and out[dpad + k] = sum_j G[j][k] w[j]: one workgroup per k
+__global__ __launch_bounds__(256) void gradx_contract_kernel(const double* __restrict__ G, int dpad,
+                                                             const double* __restrict__ a, const double* __restrict__ w,
+                                                             int64_t n, double* __restrict__ out) {
+    __shared__ double ra[256], rw[256];
+    const int k = blockIdx.x, t = threadIdx.x;
+    double sa = 0.0, sw = 0.0;
+    for (int64_t j = t; j < n; j += 256) {
+        const double g = G[j * dpad + k];
+        sa = fma(g, a[j], sa);
+        if (w) sw = fma(g, w[j], sw);
+    }
+    ra[t] = sa; rw[t] = sw;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (t < s) { ra[t] += ra[t + s]; rw[t] += rw[t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) { out[k] = ra[0]; out[dpad + k] = rw[0]; }
+}
+
+// x: device pointer to the point (d doubles, raw or transformed as in gpry_predict).
+// Outputs (device): kstar[Np], G[Np x dpad], out[2*dpad] = {G^T alpha_, G^T K^-1 kstar};
+// scratch u, w (Np each), part ((Np/128) x Np).
+int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, double* kstar, double* G,
+                 double* u, double* w, double* part, double* out) {
+    KernParams kp = make_kp(ctx);
+    kp.has_aff = raw_affine && ctx->tf.has_x_affine;
+    AffParams ap = make_ap(ctx, kp.has_aff);
+    const int64_t Np = ctx->Np;
+    hipStream_t st = ctx->stream;
+#define GX(KID) hipLaunchKernelGGL((gradx_kernel<KID>), dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, \
+                                   x, ctx->dXs, kstar, G, Np, kp, ap)
+    DISPATCH_KID(ctx->kernel_id, GX)
+#undef GX
+    if (want_kinv) {
+        hipLaunchKernelGGL(gx_trmv_lower_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, ctx->dV, Np, kstar, u, Np);
+        const int nrb = (int)(Np / 128);
+        hipLaunchKernelGGL(gx_trmv_lower_t_part_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)nrb), dim3(256), 0, st,
+                           ctx->dV, Np, u, part, Np);
+        hipLaunchKernelGGL(gx_colsum_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, part, nrb, Np, w);
+    }
+    hipLaunchKernelGGL(gradx_contract_kernel, dim3((unsigned)ctx->dpad), dim3(256), 0, st, G, ctx->dpad,
+                       ctx->dalpha_, want_kinv ? w : nullptr, Np, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

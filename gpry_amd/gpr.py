@@ -612,33 +612,58 @@ class GaussianProcessRegressor(_RM, _BE):
                 return_std_grad=False, validate=True, ignore_trust_region=False):
         """Posterior mean (and std) at ``X`` in untransformed units (gpry/gpr.py:1022-1273).
 
-        Clipping, classifier and trust-region gates behave as in the reference.  The
-        x-gradient outputs are not on the device path yet.
+        Clipping, classifier and trust-region gates behave as in the reference.  The x-gradient
+        outputs (one point at a time, :1236-1266) are taken with respect to the TRANSFORMED
+        coordinates, scaled once (mean) and twice (std) by ``std_y`` -- as the reference does.
         """
         self.n_eval += len(X)
         if return_std_grad and not (return_std and return_mean_grad):
             raise ValueError("Not returning std_gradient without returning the std and the mean grad.")
         if X.shape[0] != 1 and (return_mean_grad or return_std_grad):
             raise ValueError("Mean grad and std grad not implemented for n_samples > 1")
-        if return_mean_grad or return_std_grad:
-            raise NotImplementedError("predict(..., return_mean_grad/return_std_grad) has no device "
-                                      "implementation yet (SURVEY.md section 8f, item 3)")
         X = self._validate_X(X, validate)
         if self.X_train_ is None:  # not fit: GP prior
             y_mean = np.zeros(X.shape[0])
             if self.trust_bounds is not None and not ignore_trust_region:
                 y_mean[~is_in_bounds(X, self.trust_bounds)] = self.minus_inf_value
+            out = [y_mean]
             if return_std:
-                return y_mean, np.sqrt(self.kernel.diag(X))
-            return y_mean
+                out.append(np.sqrt(self.kernel.diag(X)))
+            if return_mean_grad:
+                out.append(np.zeros_like(X))
+                if return_std_grad:
+                    out.append(np.zeros_like(X))
+            return tuple(out) if len(out) > 1 else out[0]
         self._ensure_factor()
         self._push_affine()
         mask = self._masks(X, validate, ignore_trust_region)
-        out = self.device.predict(X, return_std=return_std, mask=mask)
-        y_mean = out[0] if return_std else out
+        res = self.device.predict(X, return_std=return_std, mask=mask)
+        y_mean = res[0] if return_std else res
+        y_std = res[1] if return_std else None
         if self.minus_inf_value != -np.inf:
             y_mean[np.isneginf(y_mean)] = self.minus_inf_value
-        return (y_mean, out[1]) if return_std else y_mean
+        if not return_mean_grad:
+            return (y_mean, y_std) if return_std else y_mean
+        # ---- one point: gradients (gpry/gpr.py:1236-1266)
+        n_dims = X.shape[1]
+        classified_inf = mask is not None and bool(mask[0] & _lib.MASK_CLASSIFIED_INF)
+        if classified_inf:     # :1157-1171: mean -inf, std 0, mean gradient +inf, std gradient 0
+            grad_mean = np.ones((1, n_dims)) * self.inf_value
+            grad_std = np.zeros((1, n_dims))
+        else:
+            _, std_y = self._y_affine()
+            want_std_grad = bool(return_std_grad) and not np.allclose(y_std, np.zeros(n_dims))
+            mg, kg = self.device.predict_grad(X[0], want_kinv=want_std_grad)
+            grad_mean = mg * std_y
+            grad_std = np.zeros(n_dims)
+            if want_std_grad:
+                y_std_untransformed = y_std / std_y
+                grad_std = -kg / y_std_untransformed * std_y * std_y
+            if self.infinities_classifier is not None:   # the reference re-embeds into (n, d) arrays
+                grad_mean, grad_std = grad_mean[None, :], grad_std[None, :]
+        if return_std_grad:
+            return y_mean, y_std, grad_mean, grad_std
+        return (y_mean, y_std, grad_mean) if return_std else (y_mean, grad_mean)
 
     def predict_std(self, X, validate=True):
         """gpry/gpr.py:1275-1352 (no trust-region gate, classifier-masked rows give 0)."""

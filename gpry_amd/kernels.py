@@ -139,6 +139,21 @@ class Kernel:
         dev.set_theta(kid, th)
         return dev.kernel_cross(X)
 
+    def gradient_x(self, x, X_train):
+        """d k(x, X_train) / d x, shape (n_train, d), for one point ``x`` (gpry/kernels.py:193-210,
+        RBF :257-278, Matern :326-432, product rule :687-699), evaluated on the device.
+        (The reference's own Matern(nu=0.5) path raises through ``Product.gradient_x`` because of
+        a shape slip at :355-359; here it returns the gradient that code describes.)"""
+        from gpry_amd.gpr import _scratch_device
+        X_train = np.atleast_2d(np.asarray(X_train, dtype=float))
+        x = np.asarray(x, dtype=float).reshape(-1)
+        kid, th = self.device_spec(X_train.shape[1])
+        dev = _scratch_device()
+        dev.set_train(X_train, np.zeros(len(X_train)), np.zeros(len(X_train)))
+        dev.set_theta(kid, th)
+        dev.set_affine()
+        return dev.predict_grad(x, want_kinv=False, want_kgrad=True, want_mean=False)[2]
+
     def diag(self, X):
         return np.diag(self(X))
 

@@ -111,6 +111,18 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml,
 int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
                  double* mean, double* std);
 
+/* ---- f3: x-gradients for one point (gpry/gpr.py:1236-1266) ------------------------- */
+/* x: d doubles, raw/transformed as in gpry_predict.  With G[j][k] = d k(x, X_j) / d x_k in the
+ * kernel's coordinates (kernel_.gradient_x: gpry/kernels.py:257-278 RBF, :326-432 Matern,
+ * :687-699 product), returns
+ *   kgrad      (nullable, N x d)  G
+ *   mean_grad  (nullable, d)      G^T alpha_                  -> grad_mean = std_y * mean_grad
+ *   kinvk_grad (nullable, d)      G^T K^-1 k*(x), if want_kinv -> grad_std = -std_y^2 * kinvk_grad / sigma_
+ * in transformed units; the y-scalings (once for the mean, twice for the std, as the
+ * reference does) are left to the caller. */
+int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgrad,
+                      double* mean_grad, double* kinvk_grad);
+
 /* ---- a8-a13: fused NORA sweep ----------------------------------------------------- */
 /* For all M candidates: mean, std (as gpry_predict), acq = LogExp.f(mean, std,
  * baseline, sigma_n, zeta) (gpry/acquisition_functions.py:1068-1074), kept resident on

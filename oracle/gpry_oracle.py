@@ -152,6 +152,55 @@ def log_marginal_likelihood(X_, y_, alpha, theta, kernel_id, eval_gradient=False
 
 
 # ----------------------------------------------------------------------------
+# f3: x-gradients
+# ----------------------------------------------------------------------------
+def kernel_gradient_x(x_, X_train_, theta, kernel_id):
+    """``kernel_.gradient_x(x, X_train)`` of ``C * RBF|Matern`` (gpry/kernels.py:257-278,
+    326-432, product rule :687-699): d k(x, X_j) / d x, shape (N, d), in the coordinates the
+    kernel sees (the reference never applies the chain rule of ``Normalize_bounds``)."""
+    x_ = np.asarray(x_, dtype=float)
+    X_train_ = np.asarray(X_train_, dtype=float)
+    const = math.exp(theta[0])
+    ls = np.exp(np.asarray(theta[1:], dtype=float))
+    diff = (x_ - X_train_) / ls
+    dist_sq = np.sum(diff ** 2, axis=1)
+    dist = np.sqrt(dist_sq)
+    nz = dist != 0.0
+    if kernel_id == RBF:
+        g = -np.exp(-0.5 * dist_sq)[:, None] * diff / ls
+    elif kernel_id == MATERN12:
+        g = -np.ones_like(diff)                      # x == X_j: the reference's -1 / l
+        e = -np.exp(-dist)
+        g[nz] = (e[nz] / dist[nz])[:, None] * diff[nz]
+        g = g / ls
+    elif kernel_id == MATERN32:
+        by = np.zeros_like(dist)
+        by[nz] = math.sqrt(3) / dist[nz]
+        f_grad = diff / ls * by[:, None]
+        gexp = np.exp(-math.sqrt(3) * dist)[:, None]
+        g = gexp * f_grad * (-(math.sqrt(3) * dist))[:, None]
+    else:
+        f = (1 + math.sqrt(5) * dist + (5.0 / 3.0) * dist_sq)[:, None]
+        rec = np.zeros_like(dist)
+        rec[nz] = math.sqrt(5) / dist[nz]
+        d2 = diff / ls
+        f1_grad = rec[:, None] * d2
+        f_grad = f1_grad + (10.0 / 3.0) * d2
+        gexp = np.exp(-math.sqrt(5) * dist)[:, None]
+        g = f * (-gexp * f1_grad) + gexp * f_grad
+    return const * g
+
+
+def logexp_gradient(std, mu_grad, std_grad, sigma_n, zeta):
+    """Gradient branch of ``BaseLogExp.__call__`` for one point
+    (gpry/acquisition_functions.py:993-1007): ``std_grad / (std - sigma_n) + 2 zeta mu_grad``,
+    ``+inf`` where ``std <= sigma_n``."""
+    if std > sigma_n:
+        return std_grad / (std - sigma_n) + 2 * zeta * mu_grad
+    return np.ones_like(std_grad) * np.inf
+
+
+# ----------------------------------------------------------------------------
 # a12: LogExp
 # ----------------------------------------------------------------------------
 def logexp_f(mu, std, baseline, noise_level, zeta):
@@ -425,6 +474,23 @@ class OracleGPR:
         var -= np.einsum("ji,ji->i", M, M, optimize=True)
         var[var < 0] = 0.0
         return self.pre_y.inverse_transform_scale(np.sqrt(var))
+
+    def predict_with_grad(self, x):
+        """``predict(x[None], return_std=True, return_mean_grad=True, return_std_grad=True)``
+        for one point (gpry/gpr.py:1236-1266): gradients with respect to the transformed
+        coordinates, the mean's scaled once and the std's twice by ``std_y``."""
+        X = np.atleast_2d(x)
+        y_mean, y_std = self.predict(X, return_std=True)
+        X_ = self.pre_X.transform(X)
+        K_trans = kernel_matrix(X_, self.theta, self.kernel_id, Y=self.X_train_)
+        grad = kernel_gradient_x(X_[0], self.X_train_, self.theta, self.kernel_id)
+        grad_mean = self.pre_y.inverse_transform_scale(grad.T.dot(self.alpha_))
+        grad_std = np.zeros(X_.shape[1])
+        if not np.allclose(y_std, grad_std):
+            y_std_untransformed = self.pre_y.transform_scale(y_std)
+            grad_std = -np.dot(K_trans, np.dot(self.V_.T.dot(self.V_), grad))[0] / y_std_untransformed
+            grad_std = self.pre_y.inverse_transform_scale(self.pre_y.inverse_transform_scale(grad_std))
+        return y_mean, y_std, grad_mean, grad_std
 
     def predict_std(self, X):
         """gpry/gpr.py:1275-1352."""

@@ -92,6 +92,19 @@ class OracleDevice:
             std[(mask & MASK_CLASSIFIED_INF) != 0] = 0.0
         return mean, std
 
+    def predict_grad(self, x, want_kinv=True, want_kgrad=False, want_mean=True):
+        x_ = self._to_unit(np.asarray(x, dtype=float)[None, :])[0]
+        G = orc.kernel_gradient_x(x_, self.X_, self.theta, self.kid)
+        mg = kg = None
+        if want_mean or want_kinv:
+            L, V, a = self._factor
+            mg = G.T.dot(a)
+            kg = np.zeros(self.d)
+            if want_kinv:
+                Kt = orc.kernel_matrix(x_[None, :], self.theta, self.kid, Y=self.X_)
+                kg = np.dot(Kt, np.dot(V.T.dot(V), G))[0]
+        return (mg, kg, G) if want_kgrad else (mg, kg)
+
     def sweep_logexp(self, X, zeta, baseline, sigma_n, mask=None, M=None, want=("y", "sigma", "acq")):
         if X is None:
             X = self._pool

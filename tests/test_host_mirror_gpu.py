@@ -103,8 +103,8 @@ def test_gpr_attributes_copy_pickle_and_errors():
     Xd = np.vstack([X[:8], X[:8]])
     with pytest.raises(np.linalg.LinAlgError, match="not returning a positive definite"):
         bad.append_to_data(Xd, np.append(y[:8], y[:8]), fit_gpr=False)
-    with pytest.raises(NotImplementedError):
-        gpr.predict(Xc[:1], return_mean_grad=True)
+    with pytest.raises(ValueError):
+        gpr.predict(Xc[:2], return_mean_grad=True)       # gradients: one point at a time
 
 
 def test_default_svm_classifier_and_trust_region_gate_predictions():
@@ -243,3 +243,60 @@ def test_restart_farm_on_one_rank_rccl():
     assert best == 0 and lml == a.log_marginal_likelihood_value_
     np.testing.assert_array_equal(a.kernel_.theta, b.kernel_.theta)
     assert abs(lml - g[p + "lml_full"]) < 1e-5
+
+
+@pytest.mark.parametrize("kid", [0, 2, 3])
+def test_f10_predict_gradients_vs_reference(kid):
+    """x-gradients on the device (gpry_predict_grad) against the reference's vectors, incl. a
+    point that coincides with a training point and the LogExp gradient built from them."""
+    from gpry_amd.acquisition_functions import LogExp
+    g = load_golden("gradients")
+    p = f"f10_k{kid}_"
+    gpr = make_gpr(g["f10_bounds"], kid, theta=g[p + "theta"])
+    gpr.append_to_data(g["f10_X"], g["f10_y"], fit_gpr=False)
+    af = LogExp(dimension=3)
+    X_ = gpr.preprocessing_X.transform(g["f10_X"])
+    for i, x in enumerate(g["f10_Xc"]):
+        m, s, mg, sg = gpr.predict(x[None, :], return_std=True, return_mean_grad=True, return_std_grad=True)
+        np.testing.assert_allclose(m[0], g[p + "mean"][i], rtol=1e-9)
+        np.testing.assert_allclose(s[0], g[p + "std"][i], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(mg, g[p + "mean_grad"][i], rtol=1e-8, atol=1e-9)
+        # k*^T K^-1 G / sigma_: cond(K) ~ 1e9 here (RBF, 72 points in 3-d) and sigma_ is small at
+        # the point that sits on a training point -- 1e-4 is the reference's own noise floor
+        np.testing.assert_allclose(sg, g[p + "std_grad"][i], rtol=1e-4, atol=1e-6)
+        a, ag = af(x[None, :], gpr, eval_gradient=True)
+        ref = g[p + "acq_grad"][i]
+        assert np.array_equal(np.isinf(ag), np.isinf(ref))
+        np.testing.assert_allclose(ag[np.isfinite(ref)], ref[np.isfinite(ref)], rtol=1e-4, atol=1e-5)
+        x_ = gpr.preprocessing_X.transform(x[None, :])[0]
+        np.testing.assert_allclose(gpr.kernel_.gradient_x(x_, X_), g[p + "kgrad"][i], rtol=1e-11, atol=1e-13)
+
+
+def test_matern12_gradient_x_and_finite_differences_at_size():
+    """Matern-1/2 kernel gradient (the reference's product path raises; its factor kernel is
+    pinned in F10), and the device gradients against central differences of the device's own
+    mean / std at N=1024, d=8 (ragged padding: N=1000)."""
+    g = load_golden("gradients")
+    gpr = make_gpr(g["f10_bounds"], 1, theta=g["f10_k1_theta"])
+    gpr.append_to_data(g["f10_X"], g["f10_y"], fit_gpr=False)
+    X_ = gpr.preprocessing_X.transform(g["f10_X"])
+    for i, x in enumerate(g["f10_Xc"]):
+        x_ = gpr.preprocessing_X.transform(x[None, :])[0]
+        np.testing.assert_allclose(gpr.kernel_.gradient_x(x_, X_), g["f10_k1_kgrad"][i], rtol=1e-11, atol=1e-13)
+    bounds, X, y, Xc = orc.synthetic_like_goldens(1000, 8, 4, seed=3)
+    theta = np.log(np.array([4.0] + [0.3] * 8))
+    for kid in (0, 3):
+        gpr = make_gpr(bounds, kid, theta=theta)
+        gpr.append_to_data(X, y, fit_gpr=False)
+        span = bounds[:, 1] - bounds[:, 0]
+        for x in Xc[:2]:
+            m, s, mg, sg = gpr.predict(x[None, :], return_std=True, return_mean_grad=True, return_std_grad=True)
+            _, std_y = gpr._y_affine()
+            for k in (0, 3, 7):
+                e = np.zeros(8)
+                e[k] = 1e-6 * span[k]                       # step 1e-6 in the transformed coordinate
+                mp, sp = gpr.predict((x + e)[None, :], return_std=True)
+                mm, sm = gpr.predict((x - e)[None, :], return_std=True)
+                assert abs((mp[0] - mm[0]) / 2e-6 - mg[k]) <= 1e-5 * max(1.0, abs(mg[k]))
+                # the reference scales the std gradient by std_y twice: undo one factor
+                assert abs((sp[0] - sm[0]) / 2e-6 - sg[k] / std_y) <= 1e-4 * max(1.0, abs(sg[k] / std_y))

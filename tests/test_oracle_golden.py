@@ -202,3 +202,37 @@ def test_f9_config1_curved_degeneracy_plumbing():
     m, s = gpr.predict(g["f9_Xc"], return_std=True)
     np.testing.assert_allclose(m, g["f9_mean"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(s, g["f9_std"], rtol=1e-4, atol=1e-6)
+
+
+# ---- F10: x-gradients ------------------------------------------
+@pytest.mark.parametrize("kid", [0, 1, 2, 3])
+def test_f10_kernel_gradient_x_vs_reference(kid):
+    g = load_golden("gradients")
+    pre = orc.NormalizeBounds(g["f10_bounds"])
+    X_ = pre.transform(g["f10_X"])
+    theta = g[f"f10_k{kid}_theta"]
+    for i, x in enumerate(g["f10_Xc"]):
+        got = orc.kernel_gradient_x(pre.transform(x[None, :])[0], X_, theta, kid)
+        np.testing.assert_allclose(got, g[f"f10_k{kid}_kgrad"][i], rtol=1e-11, atol=1e-13)
+    assert int(g["f10_k1_reference_raises"]) == 1   # the reference's Matern-1/2 path is broken
+
+
+@pytest.mark.parametrize("kid", [0, 2, 3])
+def test_f10_predict_gradients_and_logexp_gradient_vs_reference(kid):
+    g = load_golden("gradients")
+    p = f"f10_k{kid}_"
+    m = orc.OracleGPR(g["f10_bounds"], kernel_id=kid)
+    m.theta = np.array(g[p + "theta"])
+    m.fitted = True
+    m.append_to_data(g["f10_X"], g["f10_y"], fit_gpr=False, fit_preprocessors=True)
+    for i, x in enumerate(g["f10_Xc"]):
+        mean, std, mg, sg = m.predict_with_grad(x)
+        np.testing.assert_allclose(mean[0], g[p + "mean"][i], rtol=1e-9)
+        np.testing.assert_allclose(std[0], g[p + "std"][i], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(mg, g[p + "mean_grad"][i], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(sg, g[p + "std_grad"][i], rtol=1e-5, atol=1e-8)
+        ag = orc.logexp_gradient(std[0], mg, sg, m.noise_level, float(g[p + "zeta"]))
+        ref = g[p + "acq_grad"][i]
+        assert np.array_equal(np.isinf(ag), np.isinf(ref))
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(ag[fin], ref[fin], rtol=1e-5, atol=1e-7)
