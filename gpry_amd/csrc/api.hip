@@ -359,6 +359,31 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return 0;
     if (!X) return gpry_fail(ctx, -1, "predict: X is NULL");
+    if (!std && M <= ctx->opt_predict_small) {
+        // Latency path (samplers call this per point, gpry/gp_acquisition.py:769-793): the points,
+        // the mask and the result live in one pinned host buffer that the kernel reads and
+        // writes directly -- one launch and one stream synchronisation, no copies, no timers.
+        // The training rows are split over up to 8 workgroups per point; the host adds the
+        // slices in a fixed order and applies the affine map, the clip and the mask.
+        int nsplit = (int)(ctx->N / 1024);
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > 8) nsplit = 8;
+        const int64_t xb = round_up(sizeof(double) * M * ctx->d, 256);
+        GPRY_TRY(ensure_pinned(ctx, xb + sizeof(double) * M * nsplit));
+        char* h = (char*)ctx->hpin;
+        memcpy(h, X, sizeof(double) * M * ctx->d);
+        double* hp = (double*)(h + xb);
+        GPRY_TRY(launch_predict_mean_small(ctx, (const double*)h, M, nsplit, hp));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int64_t m = 0; m < M; m++) {
+            double mu_ = 0.0;
+            for (int sidx = 0; sidx < nsplit; sidx++) mu_ += hp[m * nsplit + sidx];
+            double y = fmin(mu_ * ctx->tf.y_std + ctx->tf.y_mean, ctx->tf.clip_hi);
+            if (mask && mask[m]) y = -INFINITY;
+            mean[m] = y;
+        }
+        return 0;
+    }
     PredictSetGuard guard(ctx);
     GPRY_TRY(upload_candidates(ctx, X, M, mask));
     GPRY_TRY(run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0));

@@ -43,6 +43,7 @@ struct gpry_ctx {
     int opt_sweep_kskew = 0;
     int opt_sweep_overlap = 0;   // 1: build the panel of chunk c+1 on a second stream while chunk c is contracted (measured: slower, the co-running cross_build costs the contraction +10 %)
     int opt_sweep_persist = 0;   // 1: persistent workgroups + per-XCD tile tickets (sweep_dma=3 only)
+    int64_t opt_predict_small = 2048;  // mean-only gpry_predict of at most this many points: one fused launch
     int opt_chol_lookahead = 0;  // 1: trailing update of the next panel's columns first, the rest on stream2
                                  // (bit-identical; 4.50 vs 4.14 ms at N=4096: cross-stream events cost more than the overlap saves)
 
@@ -180,6 +181,7 @@ int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise); // full symmet
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
                        int64_t ldk, double* Kst, double* mean_part, int raw_affine,
                        hipStream_t st = nullptr);
+int launch_predict_mean_small(gpry_ctx* ctx, const double* Xc, int64_t M, int nsplit, double* part_out);
 int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, double* kstar, double* G,
                  double* u, double* w, double* part, double* out);
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,

@@ -588,3 +588,96 @@ int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, 
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------
+// Low-latency posterior mean for small batches (the per-point
+// calls of nested samplers / MCMC, gpry/gp_acquisition.py:769-793, gpry/mc.py:387-391).
+// One workgroup per point: mean = y_std * sum_j alpha_j C k(x, X_j) + y_mean, clipped and
+// masked as gpry_predict does (gpry/gpr.py:1180-1201) -- one launch, no panel, no partials.
+template <int DP, int KID>
+__global__ __launch_bounds__(256) void predict_mean_small_kernel(
+    const double* __restrict__ Xc, const double* __restrict__ Xs, const double* __restrict__ alpha_,
+    double* __restrict__ part_out, int64_t rows_per_split, KernParams kp, AffParams ap) {
+    constexpr int P = DP / 2;             // lanes per training row: one 16-byte piece each
+    constexpr int CH = 4096;              // rows per LDS chunk
+    __shared__ double r2s[CH];
+    __shared__ double red[256];
+    const int64_t m = blockIdx.x;
+    const int t = threadIdx.x, sub = t % P, rloc = t / P;
+    // this lane's two scaled coordinates of the point
+    double x0 = 0.0, x1 = 0.0;
+    {
+        const int k0 = 2 * sub, k1 = 2 * sub + 1;
+        if (k0 < kp.d) { double v = Xc[m * kp.d + k0]; if (kp.has_aff) v = (v - ap.lo[k0]) / ap.span[k0]; x0 = v / ap.ls[k0]; }
+        if (k1 < kp.d) { double v = Xc[m * kp.d + k1]; if (kp.has_aff) v = (v - ap.lo[k1]) / ap.span[k1]; x1 = v / ap.ls[k1]; }
+    }
+    const bool piece_ok = 2 * sub < kp.dpad;
+    double acc = 0.0;
+    // blockIdx.y: which slice of the training rows (the host adds the slices up)
+    const int64_t row_lo = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t row_hi = (row_lo + rows_per_split < kp.N) ? row_lo + rows_per_split : kp.N;
+    for (int64_t c0 = row_lo; c0 < row_hi; c0 += CH) {
+        const int nrow = (int)((row_hi - c0 < CH) ? row_hi - c0 : CH);
+        // phase 1: squared distances, rows read as whole cache lines (P lanes per row); eight
+        // passes are loaded back to back so that their memory latencies overlap
+        constexpr int RP = 256 / P;       // rows per pass
+        for (int r0 = 0; r0 < nrow; r0 += 8 * RP) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int row = r0 + u * RP + rloc;
+                v[u] = make_double2(0.0, 0.0);
+                if (row < nrow && piece_ok)
+                    v[u] = *reinterpret_cast<const double2*>(Xs + (c0 + row) * kp.dpad + 2 * sub);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int row = r0 + u * RP + rloc;
+                const double d0 = x0 - v[u].x, d1 = x1 - v[u].y;
+                double part = piece_ok ? fma(d1, d1, d0 * d0) : 0.0;
+#pragma unroll
+                for (int o = 1; o < P; o <<= 1) part += __shfl_xor(part, o);
+                if (sub == 0 && row < nrow) r2s[row] = part;
+            }
+        }
+        __syncthreads();
+        // phase 2: one row per lane, four independent chains
+        for (int j0 = t; j0 < nrow; j0 += 1024) {
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int j = j0 + 256 * q;
+                v[q] = j < nrow ? alpha_[c0 + j] * (kp.C * corr_r2_fast<KID>(r2s[j])) : 0.0;
+            }
+            acc += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        __syncthreads();
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) part_out[m * gridDim.y + blockIdx.y] = red[0];
+}
+
+// part_out: M x nsplit partial sums of K* alpha_ (transformed units); the caller adds them and
+// applies y_std, y_mean, the clip and the mask.
+int launch_predict_mean_small(gpry_ctx* ctx, const double* Xc, int64_t M, int nsplit, double* part_out) {
+    KernParams kp = make_kp(ctx);
+    kp.has_aff = ctx->tf.has_x_affine;
+    AffParams ap = make_ap(ctx, kp.has_aff);
+    if (ctx->d > 32) return gpry_fail(ctx, -1, "d > 32 is not supported");
+    const int64_t rows_per_split = round_up((ctx->N + nsplit - 1) / nsplit, 32);
+#define PM2(DP, KID) hipLaunchKernelGGL((predict_mean_small_kernel<DP, KID>), dim3((unsigned)M, (unsigned)nsplit), \
+                                        dim3(256), 0, ctx->stream, Xc, ctx->dXs, ctx->dalpha_, part_out,          \
+                                        rows_per_split, kp, ap)
+#define PM4(KID) { if (ctx->d <= 4) PM2(4, KID); else if (ctx->d <= 8) PM2(8, KID); \
+                   else if (ctx->d <= 16) PM2(16, KID); else PM2(32, KID); }
+    DISPATCH_KID(ctx->kernel_id, PM4)
+#undef PM4
+#undef PM2
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

@@ -141,7 +141,8 @@ def test_f4_predict_clip_trust_vs_reference(dev, kid):
     np.testing.assert_allclose(mean, g[p + "mean"], rtol=1e-8, atol=1e-9)
     C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
     assert np.max(np.abs(std ** 2 - g[p + "std"] ** 2)) <= 1e-9 * C
-    np.testing.assert_allclose(dev.predict(Xc), mean, rtol=0, atol=0)
+    # mean-only calls take the fused low-latency path (other summation order)
+    np.testing.assert_allclose(dev.predict(Xc), mean, rtol=1e-9, atol=1e-10)
     outside = ~orc.is_in_bounds(Xc, g[p + "trust_bounds"])
     mask = outside.astype(np.uint8) * _lib.MASK_OUTSIDE_TRUST
     mean_tr, std_tr = dev.predict(Xc, return_std=True, mask=mask)

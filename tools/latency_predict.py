@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Wall-clock latency of gpry_predict for small batches (nested-sampler / MCMC call pattern)."""
+import os
+import sys
+import time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpry_amd import _lib  # noqa: E402
+
+for N, d in ((1024, 8), (4096, 16)):
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (N, d)); y = rng.standard_normal(N)
+    dev = _lib.Device(0)
+    dev.set_train(X, y, np.full(N, 1e-4))
+    dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
+    assert dev.factorize() == 0
+    if len(sys.argv) > 1:
+        dev.set_option("timing", int(sys.argv[1]))
+    for M in (1, 16, 400):
+        Xc = rng.uniform(0, 1, (M, d))
+        for std in (False, True):
+            for _ in range(5):
+                dev.predict(Xc, return_std=std)
+            t0 = time.perf_counter()
+            reps = 50
+            for _ in range(reps):
+                dev.predict(Xc, return_std=std)
+            us = (time.perf_counter() - t0) / reps * 1e6
+            print(f"N={N} d={d} M={M:5d} std={int(std)}: {us:8.1f} us per call, {us / M:8.2f} us per point")
+    dev.close()
