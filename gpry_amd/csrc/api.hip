@@ -67,6 +67,7 @@ int gpry_kernel_train(gpry_ctx* ctx, int add_alpha, double* K_out) {
     GPRY_TRY(require_model(ctx, false));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(launch_scale_train(ctx));
+    ctx->lml_cache = false;      // dW is about to be overwritten
     {
         StageScope s(ctx, "kernel_build");
         GPRY_TRY(launch_kernel_train(ctx, ctx->dW, add_alpha));
@@ -105,7 +106,19 @@ int gpry_factorize(gpry_ctx* ctx, int* info) {
     ctx->factor_valid = false;
     ctx->kb_n = 0;
     int inf = 0;
-    GPRY_TRY(build_factor(ctx, ctx->dA, ctx->dV, ctx->dW, &inf));
+    // The optimiser's last objective evaluation is normally at the theta it returns: its factor
+    // (L in dW, V in dW2; same kernels, same inputs => the bits a fresh factorisation would give)
+    // is adopted by swapping buffers instead of factorising again.
+    bool hit = ctx->opt_lml_cache && ctx->lml_cache && ctx->lml_kernel_id == ctx->kernel_id;
+    for (int k = 0; hit && k <= ctx->d; k++) hit = ctx->lml_theta[k] == ctx->theta[k];
+    ctx->lml_cache = false;
+    if (hit) {
+        std::swap(ctx->dA, ctx->dW);
+        std::swap(ctx->dV, ctx->dW2);
+        GPRY_TRY(launch_scale_train(ctx));
+    } else {
+        GPRY_TRY(build_factor(ctx, ctx->dA, ctx->dV, ctx->dW, &inf));
+    }
     if (info) *info = inf;
     if (inf != 0) return 0;
     // alpha_ = V^T (V y)
@@ -174,6 +187,8 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = gpry_fail(ctx, -2, "lml copy-out: %s", hipGetErrorString(e));
     }
+    ctx->lml_cache = (rc == 0 && inf == 0);
+    if (ctx->lml_cache) { memcpy(ctx->lml_theta, ctx->theta, sizeof(saved)); ctx->lml_kernel_id = ctx->kernel_id; }
     memcpy(ctx->theta, saved, sizeof(saved));
     ctx->have_theta = had;
     if (rc) return rc;

@@ -54,6 +54,11 @@ struct gpry_ctx {
     bool have_theta = false, factor_valid = false;
     double theta[1 + GPRY_MAX_DIM] = {0};
     gpry_affine tf;
+    // factor of the last successful gpry_lml evaluation: still sitting in dW (L) / dW2 (V)
+    bool lml_cache = false;
+    int lml_kernel_id = -1;
+    double lml_theta[1 + GPRY_MAX_DIM] = {0};
+    int opt_lml_cache = 1;
 
     double* dX = nullptr;      // N x d raw transformed training rows (row-major, ld = d)
     double* dXs = nullptr;     // Np x dpad rows scaled by 1/l (pad rows = 0)

@@ -191,6 +191,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "sweep_overlap")) { ctx->opt_sweep_overlap = (int)value; return 0; }
     if (!strcmp(key, "chol_lookahead")) { ctx->opt_chol_lookahead = (int)value; return 0; }
     if (!strcmp(key, "predict_small")) { ctx->opt_predict_small = (int64_t)value; return 0; }
+    if (!strcmp(key, "lml_cache")) { ctx->opt_lml_cache = (int)value; ctx->lml_cache = false; return 0; }
     if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }
     if (!strcmp(key, "sweep_kskew")) { ctx->opt_sweep_kskew = (int)value; return 0; }
     if (!strcmp(key, "sweep_diag")) { ctx->opt_sweep_diag = (int)value; return 0; }
@@ -217,6 +218,7 @@ int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const doub
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dnoise, alpha, sizeof(double) * N, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     ctx->factor_valid = false;
+    ctx->lml_cache = false;
     ctx->kb_n = 0;
     return 0;
 }

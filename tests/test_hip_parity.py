@@ -334,3 +334,42 @@ def test_cholesky_with_concurrent_trailing_update_is_bit_identical(dev):
             assert np.array_equal(L0, L1)
     finally:
         dev.set_option("chol_lookahead", 0)
+
+
+def test_factorize_adopts_the_factor_of_the_last_lml_evaluation(dev):
+    """gpry_factorize at the theta of the preceding gpry_lml call swaps that evaluation's factor
+    in instead of factorising again: same bits as a fresh factorisation, and no stale reuse once
+    theta, the training set or the scratch matrices have changed."""
+    bounds, X, y, Xc = orc.synthetic_like_goldens(300, 5, 64, seed=8)
+    pre = orc.NormalizeBounds(bounds)
+    X_ = pre.transform(X)
+    alpha = np.full(300, 1e-4)
+    th1 = np.log(np.array([3.0, 0.3, 0.4, 0.5, 0.35, 0.45]))
+    th2 = th1 + 0.1
+    dev.set_train(X_, y, alpha)
+    dev.set_option("lml_cache", 0)
+    dev.set_theta(3, th1)
+    assert dev.factorize() == 0
+    L_ref, V_ref, a_ref = dev.get_factor()
+    m_ref = dev.predict(pre.transform(Xc), return_std=True)
+    dev.set_option("lml_cache", 1)
+    dev.timing_reset()
+    dev.lml(th2, True)
+    dev.lml(th1, True)                       # last evaluation at th1
+    n_potrf = dev.timing("potrf")[1]
+    dev.set_theta(3, th1)
+    assert dev.factorize() == 0
+    assert dev.timing("potrf")[1] == n_potrf            # adopted, not refactorised
+    L, V, a = dev.get_factor()
+    assert np.array_equal(L, L_ref) and np.array_equal(V, V_ref) and np.array_equal(a, a_ref)
+    m = dev.predict(pre.transform(Xc), return_std=True)
+    assert np.array_equal(m[0], m_ref[0]) and np.array_equal(m[1], m_ref[1])
+    # a different theta, or an evaluation in between that reused the scratch matrices: refactorise
+    dev.lml(th1, True)
+    dev.set_theta(3, th2)
+    assert dev.factorize() == 0 and dev.timing("potrf")[1] == n_potrf + 2
+    dev.lml(th2, False)
+    dev.kernel_train()
+    assert dev.factorize() == 0 and dev.timing("potrf")[1] == n_potrf + 4
+    ref2 = orc.log_marginal_likelihood(X_, y, alpha, th2, 3)
+    assert abs(dev.lml(th2, False)[0] - ref2) <= 1e-10 * abs(ref2)
