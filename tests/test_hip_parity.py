@@ -373,3 +373,44 @@ def test_factorize_adopts_the_factor_of_the_last_lml_evaluation(dev):
     assert dev.factorize() == 0 and dev.timing("potrf")[1] == n_potrf + 4
     ref2 = orc.log_marginal_likelihood(X_, y, alpha, th2, 3)
     assert abs(dev.lml(th2, False)[0] - ref2) <= 1e-10 * abs(ref2)
+
+
+@pytest.mark.parametrize("M,chunk", [(70001, 32768), (5003, 1024)])
+def test_multi_chunk_sweep_with_masks_vs_oracle(dev, M, chunk):
+    """Chunked sweep (ragged last chunk), per-candidate masks, resident re-use and the shortlist
+    against the oracle evaluated in one piece."""
+    from gpry_amd import _lib
+    bounds, X, y, Xc = orc.synthetic_like_goldens(300, 6, M, seed=17)
+    m = orc.OracleGPR(bounds, kernel_id=2)
+    m.theta = np.log(np.array([4.0] + [0.3] * 6))
+    m.fitted = True
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    rng = np.random.default_rng(0)
+    mask = np.zeros(M, dtype=np.uint8)
+    mask[rng.random(M) < 0.05] = _lib.MASK_CLASSIFIED_INF
+    mask[rng.random(M) < 0.05] |= _lib.MASK_OUTSIDE_TRUST
+    rm, rs = m.predict(Xc, return_std=True)
+    rm = rm.copy(); rs = rs.copy()
+    rm[mask != 0] = -np.inf
+    rs[(mask & _lib.MASK_CLASSIFIED_INF) != 0] = 0.0
+    zeta = orc.auto_zeta(6)
+    racq = orc.logexp_f(rm, rs, m.y_max, m.noise_level, zeta)
+    try:
+        dev.set_option("sweep_chunk", chunk)
+        out = dev.sweep_logexp(Xc, zeta, m.y_max, m.noise_level, mask=mask)
+    finally:
+        dev.set_option("sweep_chunk", 32768)
+    fin = np.isfinite(rm)
+    assert np.array_equal(np.isneginf(out["y"]), ~fin)
+    np.testing.assert_allclose(out["y"][fin], rm[fin], rtol=1e-8, atol=1e-8)
+    C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
+    assert np.max(np.abs(out["sigma"] ** 2 - rs ** 2)) <= 1e-9 * C
+    assert np.array_equal(np.isneginf(out["acq"]), np.isneginf(racq))
+    ok = np.isfinite(racq)
+    np.testing.assert_allclose(out["acq"][ok], racq[ok], rtol=1e-6, atol=1e-6)
+    assert int(np.argmax(out["acq"])) == int(np.argmax(racq))
+    top, bound = dev.sweep_topk(200)
+    order = np.lexsort((-np.arange(M), -out["acq"]))
+    np.testing.assert_array_equal(top["idx"], order[:200])
+    assert bound == out["acq"][order[200]]
