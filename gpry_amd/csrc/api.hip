@@ -374,7 +374,7 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return 0;
     if (!X) return gpry_fail(ctx, -1, "predict: X is NULL");
-    if (!std && M <= ctx->opt_predict_small) {
+    if (!std && M <= ctx->opt_predict_small) {   // (predict_small = 0 switches both small-batch paths off)
         // Latency path (samplers call this per point, gpry/gp_acquisition.py:769-793): the points,
         // the mask and the result live in one pinned host buffer that the kernel reads and
         // writes directly -- one launch and one stream synchronisation, no copies, no timers.
@@ -396,6 +396,41 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
             double y = fmin(mu_ * ctx->tf.y_std + ctx->tf.y_mean, ctx->tf.clip_hi);
             if (mask && mask[m]) y = -INFINITY;
             mean[m] = y;
+        }
+        return 0;
+    }
+    if (std && M <= 16 && ctx->opt_predict_small > 0) {
+        // a handful of points with std: k* rows + one multi-vector triangular product (the panel
+        // path has a ~1 ms floor at N = 4096); partial sums come back through pinned memory
+        const int64_t Np = ctx->Np, nmb = (Np + 255) / 256, nsb = Np / 16;
+        const int64_t xb = round_up(sizeof(double) * M * ctx->d, 256);
+        GPRY_TRY(ensure_pinned(ctx, xb + sizeof(double) * M * (nmb + nsb)));
+        if (M * Np > ctx->g_cap) {
+            if (ctx->dG) GPRY_TRY(dev_free(ctx, ctx->dG));
+            ctx->dG = nullptr; ctx->g_cap = 0;
+            GPRY_TRY(dev_alloc(ctx, &ctx->dG, 16 * Np));
+            ctx->g_cap = 16 * Np;
+        }
+        char* h = (char*)ctx->hpin;
+        memcpy(h, X, sizeof(double) * M * ctx->d);
+        double* hm = (double*)(h + xb);
+        double* hs = hm + M * nmb;
+        GPRY_TRY(launch_predict_small_std(ctx, (const double*)h, (int)M, ctx->dG, hm, hs));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const double C = exp(ctx->theta[0]);
+        for (int64_t m = 0; m < M; m++) {
+            double mu_ = 0.0, ss = 0.0;
+            for (int64_t b = 0; b < nmb; b++) mu_ += hm[m * nmb + b];
+            for (int64_t b = 0; b < nsb; b++) ss += hs[m * nsb + b];
+            double y = fmin(mu_ * ctx->tf.y_std + ctx->tf.y_mean, ctx->tf.clip_hi);
+            unsigned mk = mask ? mask[m] : 0u;
+            if (mk) y = -INFINITY;
+            mean[m] = y;
+            double var = C - ss;
+            if (var < 0.0) var = 0.0;
+            double sd = sqrt(var) * ctx->tf.y_std;
+            if (mk & GPRY_MASK_CLASSIFIED_INF) sd = 0.0;
+            std[m] = sd;
         }
         return 0;
     }

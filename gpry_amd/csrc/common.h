@@ -187,6 +187,8 @@ int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
                        int64_t ldk, double* Kst, double* mean_part, int raw_affine,
                        hipStream_t st = nullptr);
 int launch_predict_mean_small(gpry_ctx* ctx, const double* Xc, int64_t M, int nsplit, double* part_out);
+int launch_predict_small_std(gpry_ctx* ctx, const double* Xc, int M, double* kstar, double* mean_part,
+                             double* ss_part);
 int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, double* kstar, double* G,
                  double* u, double* w, double* part, double* out);
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,

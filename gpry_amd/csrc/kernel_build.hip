@@ -681,3 +681,116 @@ int launch_predict_mean_small(gpry_ctx* ctx, const double* Xc, int64_t M, int ns
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------
+// Mean AND std for a handful of points (M <= 16): the panel path costs ~1 ms at N = 4096
+// whatever M is (its longest triangular tile runs 256 slabs on one workgroup); here
+//   kstar_rows_kernel   k*[m][j] (thread <-> training row) + alpha-weighted partials of the mean
+//   trmv_multi_kernel   u_m = V k*_m for all m at once: a wave owns 4 rows of V, reads them once
+//                       and keeps 4 x M accumulators; per-workgroup partials of |u_m|^2
+// and the host adds the partials in a fixed order (pinned, zero-copy buffers).
+template <int DP, int KID>
+__global__ __launch_bounds__(256) void kstar_rows_kernel(
+    const double* __restrict__ Xc, const double* __restrict__ Xs, const double* __restrict__ alpha_,
+    double* __restrict__ kstar, double* __restrict__ mean_part, int64_t Np, KernParams kp, AffParams ap) {
+    __shared__ double xs_s[DP];
+    __shared__ double red[256];
+    const int m = blockIdx.y, t = threadIdx.x;
+    if (t < DP) {
+        double v = 0.0;
+        if (t < kp.d) {
+            v = Xc[(int64_t)m * kp.d + t];
+            if (kp.has_aff) v = (v - ap.lo[t]) / ap.span[t];
+            v = v / ap.ls[t];
+        }
+        xs_s[t] = v;
+    }
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * 256 + t;
+    double kv = 0.0;
+    if (j < kp.N) {
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DP; k++) {
+            if (k < kp.dpad) {
+                double df = xs_s[k] - Xs[j * kp.dpad + k];
+                r2 = fma(df, df, r2);
+            }
+        }
+        kv = kp.C * corr_r2_fast<KID>(r2);
+    }
+    if (j < Np) kstar[(int64_t)m * Np + j] = kv;
+    red[t] = j < kp.N ? alpha_[j] * kv : 0.0;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) mean_part[(int64_t)m * gridDim.x + blockIdx.x] = red[0];
+}
+
+template <int MM>
+__global__ __launch_bounds__(256) void trmv_multi_kernel(const double* __restrict__ V, int64_t ld,
+                                                         const double* __restrict__ kstar, int M,
+                                                         double* __restrict__ ss_part) {
+    __shared__ double wsum[4][MM];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * 16 + w * 4;
+    double acc[4][MM];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int m = 0; m < MM; m++) acc[r][m] = 0.0;
+    for (int64_t k = lane; k <= i0 + 3; k += 64) {
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = V[(i0 + r) * ld + k];     // zero above the diagonal
+#pragma unroll
+        for (int m = 0; m < MM; m++) {
+            if (m < M) {
+                const double ks = kstar[(int64_t)m * ld + k];
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r][m] = fma(v[r], ks, acc[r][m]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MM; m++) {
+        double ss = 0.0;
+        if (m < M) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double u = acc[r][m];
+                for (int o = 32; o >= 1; o >>= 1) u += __shfl_xor(u, o);
+                ss = fma(u, u, ss);
+            }
+        }
+        if (lane == 0) wsum[w][m] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x < M)
+        ss_part[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] =
+            (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+}
+
+// kstar: M x Np device scratch; mean_part: M x (Np/256), ss_part: M x (Np/16) (pinned host is fine)
+int launch_predict_small_std(gpry_ctx* ctx, const double* Xc, int M, double* kstar, double* mean_part,
+                             double* ss_part) {
+    KernParams kp = make_kp(ctx);
+    kp.has_aff = ctx->tf.has_x_affine;
+    AffParams ap = make_ap(ctx, kp.has_aff);
+    const int64_t Np = ctx->Np;
+    if (M > 16) return gpry_fail(ctx, -1, "predict_small_std: M > 16");
+    dim3 grid((unsigned)(Np / 256 + (Np % 256 ? 1 : 0)), (unsigned)M);
+#define KS2(DP, KID) hipLaunchKernelGGL((kstar_rows_kernel<DP, KID>), grid, dim3(256), 0, ctx->stream, Xc, ctx->dXs, \
+                                        ctx->dalpha_, kstar, mean_part, Np, kp, ap)
+#define KS4(KID) { if (ctx->d <= 4) KS2(4, KID); else if (ctx->d <= 8) KS2(8, KID); \
+                   else if (ctx->d <= 16) KS2(16, KID); else KS2(32, KID); }
+    DISPATCH_KID(ctx->kernel_id, KS4)
+#undef KS4
+#undef KS2
+    if (M <= 4) hipLaunchKernelGGL(trmv_multi_kernel<4>, dim3((unsigned)(Np / 16)), dim3(256), 0, ctx->stream, ctx->dV, Np, kstar, M, ss_part);
+    else hipLaunchKernelGGL(trmv_multi_kernel<16>, dim3((unsigned)(Np / 16)), dim3(256), 0, ctx->stream, ctx->dV, Np, kstar, M, ss_part);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

@@ -414,3 +414,38 @@ def test_multi_chunk_sweep_with_masks_vs_oracle(dev, M, chunk):
     order = np.lexsort((-np.arange(M), -out["acq"]))
     np.testing.assert_array_equal(top["idx"], order[:200])
     assert bound == out["acq"][order[200]]
+
+
+@pytest.mark.parametrize("M", [1, 3, 16, 17])
+def test_small_batch_paths_agree_with_the_panel_path(dev, M):
+    """gpry_predict takes latency paths for small batches (fused mean kernel; k* rows + multi-vector
+    triangular product for <= 16 points with std): same numbers as the panel path, masks included."""
+    from gpry_amd import _lib
+    bounds, X, y, Xc = orc.synthetic_like_goldens(1000, 7, M, seed=23)
+    m = orc.OracleGPR(bounds, kernel_id=3)
+    m.theta = np.log(np.array([4.0] + [0.3] * 7))
+    m.fitted = True
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    mask = np.zeros(M, dtype=np.uint8)
+    if M > 2:
+        mask[1], mask[2] = _lib.MASK_CLASSIFIED_INF, _lib.MASK_OUTSIDE_TRUST
+    try:
+        dev.set_option("predict_small", 0)
+        mean_p, std_p = dev.predict(Xc, return_std=True, mask=mask)
+        dev.set_option("predict_small", 2048)
+        mean_s, std_s = dev.predict(Xc, return_std=True, mask=mask)
+        mean_only = dev.predict(Xc, mask=mask)
+    finally:
+        dev.set_option("predict_small", 2048)
+    rm, rs = m.predict(Xc, return_std=True)
+    fin = mask == 0
+    np.testing.assert_allclose(mean_p[fin], rm[fin], rtol=1e-8, atol=1e-8)
+    for got in (mean_s, mean_only):
+        assert np.array_equal(np.isneginf(got), ~fin)
+        np.testing.assert_allclose(got[fin], mean_p[fin], rtol=1e-10, atol=1e-10)
+    C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
+    assert np.max(np.abs(std_s ** 2 - std_p ** 2)) <= 1e-11 * C
+    assert np.max(np.abs(std_s[mask != _lib.MASK_CLASSIFIED_INF] ** 2 - rs[mask != _lib.MASK_CLASSIFIED_INF] ** 2)) <= 1e-9 * C
+    if M > 2:
+        assert std_s[1] == 0.0 and std_s[2] > 0.0

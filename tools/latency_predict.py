@@ -16,7 +16,7 @@ for N, d in ((1024, 8), (4096, 16)):
     assert dev.factorize() == 0
     if len(sys.argv) > 1:
         dev.set_option("timing", int(sys.argv[1]))
-    for M in (1, 16, 400):
+    for M in (1, 16, 17, 400):
         Xc = rng.uniform(0, 1, (M, d))
         for std in (False, True):
             for _ in range(5):
