@@ -58,6 +58,7 @@ SIGNATURES = {
     "gpry_lml": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_double), _vp, _P(C.c_int)]),
     "gpry_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "gpry_predict_grad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "gpry_set_gates": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_int, _vp]),
     "gpry_sweep_logexp": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_double, C.c_double,
                                     C.c_double, _vp, _vp, _vp, _P(C.c_int64)]),
     "gpry_sweep_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _P(C.c_int64),
@@ -251,6 +252,21 @@ class Device:
             self._check(self._lib.gpry_predict(self._h, _ptr(X), M, _ptr(mask), _ptr(mean),
                                                _ptr(std)), "gpry_predict")
         return (mean, std) if return_std else mean
+
+    def set_gates(self, sv=None, coef=None, gamma=0.0, intercept=0.0, positive_is_finite=True,
+                  trust_bounds=None):
+        """SVM / trust-region verdicts computed by the device inside ``sweep_logexp``."""
+        n_sv = 0
+        if sv is not None and len(sv):
+            sv = _f64(sv)
+            n_sv = sv.shape[0]
+            coef = _f64(coef, (n_sv,))
+        else:
+            sv = coef = None
+        tb = None if trust_bounds is None else _f64(trust_bounds, (self.d, 2))
+        self._check(self._lib.gpry_set_gates(self._h, _ptr(sv), _ptr(coef), n_sv, float(gamma),
+                                             float(intercept), int(bool(positive_is_finite)), _ptr(tb)),
+                    "gpry_set_gates")
 
     def predict_grad(self, x, want_kinv=True, want_kgrad=False, want_mean=True):
         """x-gradient contractions for one point: ``(G^T alpha_, G^T K^-1 k*[, G])``."""

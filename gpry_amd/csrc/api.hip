@@ -476,6 +476,34 @@ int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgr
     return 0;
 }
 
+int gpry_set_gates(gpry_ctx* ctx, const double* sv, const double* coef, int64_t n_sv, double gamma,
+                   double intercept, int positive_is_finite, const double* trust_bounds) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->d <= 0) return gpry_fail(ctx, -1, "set_gates before set_train");
+    if (n_sv < 0 || (n_sv > 0 && (!sv || !coef))) return gpry_fail(ctx, -1, "set_gates: bad support vectors");
+    if (n_sv > ctx->gate_sv_cap) {
+        if (ctx->gate_sv) GPRY_TRY(dev_free(ctx, ctx->gate_sv));
+        if (ctx->gate_coef) GPRY_TRY(dev_free(ctx, ctx->gate_coef));
+        ctx->gate_sv = ctx->gate_coef = nullptr; ctx->gate_sv_cap = 0;
+        const int64_t cap = round_up(n_sv, 256);
+        GPRY_TRY(dev_alloc(ctx, &ctx->gate_sv, cap * GPRY_MAX_DIM));
+        GPRY_TRY(dev_alloc(ctx, &ctx->gate_coef, cap));
+        ctx->gate_sv_cap = cap;
+    }
+    if (!ctx->gate_trust) GPRY_TRY(dev_alloc(ctx, &ctx->gate_trust, 2 * GPRY_MAX_DIM));
+    if (n_sv > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->gate_sv, sv, sizeof(double) * n_sv * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->gate_coef, coef, sizeof(double) * n_sv, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (trust_bounds)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->gate_trust, trust_bounds, sizeof(double) * 2 * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->gate_nsv = n_sv; ctx->gate_gamma = gamma; ctx->gate_intercept = intercept;
+    ctx->gate_positive_finite = positive_is_finite; ctx->gate_has_trust = trust_bounds != nullptr;
+    ctx->gates_on = (n_sv > 0 || trust_bounds != nullptr);
+    return 0;
+}
+
 int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask, double zeta,
                       double baseline, double sigma_n, double* y_all, double* sigma_all, double* acq_all,
                       int64_t* n_nan) {
@@ -483,7 +511,15 @@ int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return gpry_fail(ctx, -1, "sweep: M must be > 0");
     GPRY_TRY(upload_candidates(ctx, X, M, mask));
-    GPRY_TRY(run_sweep(ctx, M, mask != nullptr, true, true, zeta, baseline, sigma_n));
+    bool have_mask = mask != nullptr;
+    if (ctx->gates_on) {
+        // the SVM / trust-region verdicts are computed here, on top of the caller's bits
+        if (!have_mask) HIP_TRY(ctx, hipMemsetAsync(ctx->dmask, 0, (size_t)M, ctx->stream));
+        StageScope s(ctx, "gates");
+        GPRY_TRY(launch_gates(ctx, ctx->dXc, M, ctx->dmask));
+        have_mask = true;
+    }
+    GPRY_TRY(run_sweep(ctx, M, have_mask, true, true, zeta, baseline, sigma_n));
     if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dsel, 0, 8, ctx->stream));
     hipLaunchKernelGGL(count_nan_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->dacq_all, M, ctx->dsel);

@@ -75,6 +75,12 @@ struct gpry_ctx {
     int* dsched = nullptr;     // tile ticket counters of the persistent sweep GEMM (8 used)
     double* dparams = nullptr; // device copy of [C, 1/l..., lo..., span...] etc.
 
+    // gates evaluated on the device inside gpry_sweep_logexp (gpry_set_gates)
+    double* gate_sv = nullptr; double* gate_coef = nullptr; double* gate_trust = nullptr;
+    int64_t gate_nsv = 0, gate_sv_cap = 0;
+    double gate_gamma = 0.0, gate_intercept = 0.0;
+    int gate_positive_finite = 1, gate_has_trust = 0, gates_on = 0;
+
     // sweep state
     int64_t sw_M = 0, sw_cap = 0;
     double* dXc = nullptr;     // M x d candidates (raw as given)
@@ -187,6 +193,7 @@ int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
                        int64_t ldk, double* Kst, double* mean_part, int raw_affine,
                        hipStream_t st = nullptr);
 int launch_predict_mean_small(gpry_ctx* ctx, const double* Xc, int64_t M, int nsplit, double* part_out);
+int launch_gates(gpry_ctx* ctx, const double* Xc, int64_t M, uint8_t* mask);
 int launch_predict_small_std(gpry_ctx* ctx, const double* Xc, int M, double* kstar, double* mean_part,
                              double* ss_part);
 int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, double* kstar, double* G,

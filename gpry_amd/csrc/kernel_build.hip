@@ -794,3 +794,75 @@ int launch_predict_small_std(gpry_ctx* ctx, const double* Xc, int M, double* kst
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------
+// Gates of the sweep on the device: per candidate
+//   GPRY_MASK_OUTSIDE_TRUST   raw x outside the closed trust box (gpry/gpr.py:1107-1112, tools.py:263-290)
+//   GPRY_MASK_CLASSIFIED_INF  the SVM says "infinite": decision = sum_i coef_i exp(-gamma |x_ - sv_i|^2)
+//                             + intercept <= 0 in transformed coordinates (gpry/svm.py:308-347 ->
+//                             libsvm _dense_predict, sklearn SVC(kernel="rbf"), two classes)
+// ORed into mask[m] (which already holds the caller's bits or zeros).  Thread <-> candidate; the
+// support vectors pass through LDS in chunks of 128.
+template <int DP>
+__global__ __launch_bounds__(256) void gates_kernel(const double* __restrict__ Xc, int64_t M, int d,
+                                                    const double* __restrict__ sv, const double* __restrict__ coef,
+                                                    int64_t n_sv, double gamma, double intercept, int positive_is_finite,
+                                                    const double* __restrict__ trust, int has_trust, int has_aff,
+                                                    AffParams ap, uint8_t* __restrict__ mask) {
+    __shared__ double svl[128 * DP];
+    __shared__ double cl[128];
+    const int t = threadIdx.x;
+    const int64_t m = (int64_t)blockIdx.x * 256 + t;
+    const bool live = m < M;
+    double x_[DP];
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < DP; k++) {
+        double v = 0.0;
+        if (k < d && live) {
+            v = Xc[m * d + k];
+            if (has_trust && !(v >= trust[2 * k] && v <= trust[2 * k + 1])) bits |= GPRY_MASK_OUTSIDE_TRUST;
+            if (has_aff) v = (v - ap.lo[k]) / ap.span[k];
+        }
+        x_[k] = v;
+    }
+    if (n_sv > 0) {
+        double dec = 0.0;
+        for (int64_t s0 = 0; s0 < n_sv; s0 += 128) {
+            const int ns = (int)((n_sv - s0 < 128) ? n_sv - s0 : 128);
+            __syncthreads();
+            for (int e = t; e < ns * DP; e += 256) {
+                const int r = e / DP, k = e - r * DP;
+                svl[e] = k < d ? sv[(s0 + r) * d + k] : 0.0;
+            }
+            if (t < ns) cl[t] = coef[s0 + t];
+            __syncthreads();
+            for (int r = 0; r < ns; r++) {
+                double r2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < DP; k++) {
+                    const double df = x_[k] - svl[r * DP + k];
+                    r2 = fma(df, df, r2);
+                }
+                dec = fma(cl[r], fast_exp_neg(gamma * r2), dec);
+            }
+        }
+        dec += intercept;
+        const bool finite = positive_is_finite ? dec > 0.0 : !(dec > 0.0);
+        if (!finite) bits |= GPRY_MASK_CLASSIFIED_INF;
+    }
+    if (live) mask[m] |= (uint8_t)bits;
+}
+
+int launch_gates(gpry_ctx* ctx, const double* Xc, int64_t M, uint8_t* mask) {
+    AffParams ap = make_ap(ctx, ctx->tf.has_x_affine);
+    const unsigned nb = (unsigned)((M + 255) / 256);
+#define GT(DP) hipLaunchKernelGGL((gates_kernel<DP>), dim3(nb), dim3(256), 0, ctx->stream, Xc, M, ctx->d, ctx->gate_sv, \
+                                  ctx->gate_coef, ctx->gate_nsv, ctx->gate_gamma, ctx->gate_intercept,                \
+                                  ctx->gate_positive_finite, ctx->gate_trust, ctx->gate_has_trust,                   \
+                                  ctx->tf.has_x_affine, ap, mask)
+    if (ctx->d <= 4) GT(4); else if (ctx->d <= 8) GT(8); else if (ctx->d <= 16) GT(16); else GT(32);
+#undef GT
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

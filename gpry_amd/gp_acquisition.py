@@ -184,7 +184,10 @@ class NORA(GenericGPAcquisition):
         lo, hi = self._shard(M)
         gpr._ensure_factor()
         gpr._push_affine()
-        mask = gpr._masks(X[lo:hi], False, False) if hi > lo else None
+        # classifier / trust-region verdicts: on the device if they have a device form
+        mask = None
+        if hi > lo and not (hasattr(gpr, "_push_gates") and gpr._push_gates()):
+            mask = gpr._masks(X[lo:hi], False, False)
         noise = gpr.noise_level
         if np.iterable(noise):
             raise ValueError("NORA needs a scalar noise_level (the reference passes it raw to "

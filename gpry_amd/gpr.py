@@ -599,6 +599,28 @@ class GaussianProcessRegressor(_RM, _BE):
             mask = bits if mask is None else (mask | bits)
         return mask
 
+    def _push_gates(self, ignore_trust_region=False):
+        """Hand the classifier's decision function and the trust box to the device so that the
+        sweep computes the per-candidate mask itself.  Returns True
+        if the device now covers every gate ``_masks`` would apply, False if the caller must
+        keep using ``_masks`` (classifier without a device form); the device gates are switched
+        off in that case."""
+        clf = self.infinities_classifier
+        trust = None if (self.trust_bounds is None or ignore_trust_region) else self.trust_bounds
+        params = None
+        if clf is not None:
+            always_finite = getattr(clf, "all_finite", False) and getattr(clf, "y_train", None) is not None
+            params = clf.device_params() if hasattr(clf, "device_params") else None
+            if params is None and not always_finite:
+                self.device.set_gates()
+                return False
+        if params is None:
+            self.device.set_gates(trust_bounds=trust)
+        else:
+            sv, coef, gamma, intercept, pos = params
+            self.device.set_gates(sv, coef, gamma, intercept, pos, trust_bounds=trust)
+        return True
+
     def _validate_X(self, X, validate):
         if validate:
             X = np.asarray(X, dtype=float)

@@ -1,9 +1,11 @@
-"""Finite / infinite classifier that gates GP predictions (host side, off the hot path).
+"""Finite / infinite classifier that gates GP predictions.
 
 Same role and interface as ``gpry/svm.py`` (``fit`` :227, ``_is_finite_raw`` :273-295,
 ``is_finite`` :297, ``predict`` :308-347): an RBF support-vector classifier trained on
-"y above (max - threshold)" labels.  The device sweep consumes its verdict as a per-
-candidate mask; the classifier itself stays on the host (libsvm through scikit-learn).
+"y above (max - threshold)" labels.  Training stays on the host (libsvm through scikit-learn);
+its decision function -- an RBF expansion over the support vectors -- is exported with
+``device_params`` so that the NORA sweep evaluates it on the GPU for its 1e5-1e6 candidates
+(``gpry_set_gates``); small ``predict`` calls keep using libsvm.
 """
 import warnings
 
@@ -66,6 +68,19 @@ class SVM:
             self._svc = SVC(random_state=self.random_state, **self._svc_args)
             self._svc.fit(self.X_train, self.y_finite)
         return self.y_finite
+
+    def device_params(self):
+        """``(support_vectors, dual_coef, gamma, intercept, positive_is_finite)`` of the fitted
+        two-class RBF SVC, with ``predict(x) == (sum_i coef_i exp(-gamma |x - sv_i|^2) + intercept
+        > 0) == positive_is_finite``; ``None`` when there is nothing to evaluate on the device
+        (not trained, all points finite or none, other kernel)."""
+        svc = self._svc
+        if (self.y_train is None or self.all_finite or not self.at_least_one_finite or svc is None
+                or svc.kernel != "rbf" or len(svc.classes_) != 2):
+            return None
+        return (np.ascontiguousarray(svc.support_vectors_, dtype=float),
+                np.ascontiguousarray(svc.dual_coef_[0], dtype=float), float(svc._gamma),
+                float(svc.intercept_[0]), bool(svc.classes_[1]))
 
     def predict(self, X, validate=True):
         if self.y_train is None:

@@ -123,6 +123,18 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
 int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgrad,
                       double* mean_grad, double* kinvk_grad);
 
+/* ---- f4: gates of the sweep evaluated on the device --------------------------------- */
+/* Replaces the host-side verdicts that gpry/gpr.py:1107-1112 (trust region, raw coordinates,
+ * closed box) and :1145-1150 -> gpry/svm.py:308-347 (sklearn SVC, RBF kernel, two classes:
+ * libsvm _dense_predict on the TRANSFORMED coordinates) compute per candidate.  Once set,
+ * gpry_sweep_logexp ORs GPRY_MASK_OUTSIDE_TRUST / GPRY_MASK_CLASSIFIED_INF into the mask itself:
+ *   finite  <=>  (sum_i coef[i] exp(-gamma |x_ - sv[i]|^2) + intercept > 0) == positive_is_finite
+ * sv: n_sv x d support vectors, coef: dual_coef_[0], intercept: intercept_[0] of the fitted SVC;
+ * trust_bounds: d x 2 (lo, hi) or NULL.  n_sv = 0 and trust_bounds = NULL switch the gates off.
+ * gpry_predict is not affected (its callers pass their own mask). */
+int gpry_set_gates(gpry_ctx* ctx, const double* sv, const double* coef, int64_t n_sv, double gamma,
+                   double intercept, int positive_is_finite, const double* trust_bounds);
+
 /* ---- a8-a13: fused NORA sweep ----------------------------------------------------- */
 /* For all M candidates: mean, std (as gpry_predict), acq = LogExp.f(mean, std,
  * baseline, sigma_n, zeta) (gpry/acquisition_functions.py:1068-1074), kept resident on

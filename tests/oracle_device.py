@@ -40,6 +40,26 @@ class OracleDevice:
     def set_option(self, key, value):
         pass
 
+    def set_gates(self, sv=None, coef=None, gamma=0.0, intercept=0.0, positive_is_finite=True,
+                  trust_bounds=None):
+        self.gates = None
+        if (sv is not None and len(sv)) or trust_bounds is not None:
+            self.gates = (None if sv is None else np.array(sv), None if coef is None else np.array(coef),
+                          gamma, intercept, positive_is_finite,
+                          None if trust_bounds is None else np.array(trust_bounds))
+
+    def _gate_bits(self, X):
+        sv, coef, gamma, intercept, pos, tb = self.gates
+        bits = np.zeros(len(X), dtype=np.uint8)
+        if tb is not None:
+            bits[~np.all((X >= tb[:, 0]) & (X <= tb[:, 1]), axis=1)] |= MASK_OUTSIDE_TRUST
+        if sv is not None:
+            X_ = self._to_unit(X)
+            d2 = ((X_[:, None, :] - sv[None, :, :]) ** 2).sum(-1)
+            dec = np.exp(-gamma * d2).dot(coef) + intercept
+            bits[(dec > 0) != pos] |= MASK_CLASSIFIED_INF
+        return bits
+
     def sync(self):
         pass
 
@@ -109,12 +129,37 @@ class OracleDevice:
         if X is None:
             X = self._pool
         self._pool = np.array(X, dtype=float)
+        if getattr(self, "gates", None) is not None and len(X):
+            g = self._gate_bits(self._pool)
+            mask = g if mask is None else (np.asarray(mask, dtype=np.uint8) | g)
         if len(X):
             y, s = self.predict(X, return_std=True, mask=mask)
         else:
             y, s = np.empty(0), np.empty(0)
         self.acq, self.y, self.s = orc.logexp_f(y, s, baseline, sigma_n, zeta), y, s
         return {"y": y, "sigma": s, "acq": self.acq, "n_nan": int(np.isnan(self.acq).sum())}
+
+    # -- Kriging believer (u(x) = V k*(x) kept per registered candidate) -------------------
+    def kb_reset(self):
+        self._kb_X, self._kb_U = [], []
+
+    def kb_register(self, X, want_var0=True):
+        X_ = self._to_unit(X)
+        L, V, a = self._factor
+        Kt = orc.kernel_matrix(X_, self.theta, self.kid, Y=self.X_)
+        U = V.dot(Kt.T).T
+        first = len(self._kb_X)
+        self._kb_X.extend(list(X_))
+        self._kb_U.extend(list(U))
+        var0 = orc.kernel_diag(X_, self.theta) - np.einsum("ij,ij->i", U, U)
+        return first, (var0 if want_var0 else None)
+
+    def kb_gram(self, p, n):
+        assert n == len(self._kb_X)
+        U = np.array(self._kb_U)
+        Xk = np.array(self._kb_X)
+        kv = orc.kernel_matrix(Xk[p:p + 1], self.theta, self.kid, Y=Xk)[0]
+        return U.dot(U[p]), kv
 
     def sweep_topk(self, K, exclude=None):
         M = len(self.acq)

@@ -196,3 +196,57 @@ def test_host_predict_gradients_and_logexp_gradient_vs_reference(kid):
         gpr.predict(g["f10_Xc"][:2], return_std=True, return_mean_grad=True)
     with pytest.raises(ValueError):
         gpr.predict(g["f10_Xc"][:1], return_std_grad=True)
+
+
+# ---- gates on the device -----------------------------------------
+def _svm_problem(N=150, d=3, M=400, seed=9):
+    from oracle import gpry_oracle as orc
+    bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M, seed=seed)
+    y = y.copy()
+    y[X[:, 0] > 1.0] = -np.inf
+    return bounds, X, y, Xc
+
+
+def test_svm_device_params_reproduce_libsvm_verdicts():
+    """The exported RBF expansion is the fitted SVC's decision function, and its sign is the
+    classifier's verdict (gpry/svm.py:308-347)."""
+    from gpry_amd.svm import SVM
+    bounds, X, y, Xc = _svm_problem()
+    svm = SVM(random_state=1)
+    svm.fit(X, y, 20.0)
+    sv, coef, gamma, intercept, pos = svm.device_params()
+    dec = np.exp(-gamma * ((Xc[:, None, :] - sv[None, :, :]) ** 2).sum(-1)).dot(coef) + intercept
+    np.testing.assert_allclose(dec, svm._svc.decision_function(Xc), rtol=1e-9, atol=1e-12)
+    assert np.array_equal((dec > 0) == pos, svm.predict(Xc))
+    assert 0 < svm.predict(Xc).sum() < len(Xc)
+    empty = SVM()
+    assert empty.device_params() is None
+    allfin = SVM()
+    allfin.fit(X[:20], np.arange(20.0), 1e9)
+    assert allfin.all_finite and allfin.device_params() is None
+
+
+def test_nora_with_device_gates_equals_host_masks():
+    """Classifier + trust region evaluated by the (oracle-backed) device inside the sweep give the
+    proposals, y and sigma that the host-side masks give."""
+    from gpry_amd.kernels import clone
+    from gpry_amd.gp_acquisition import NORA
+    bounds, X, y, Xc = _svm_problem()
+    res = []
+    for use_device in (True, False):
+        gpr = make_gpr(bounds, 3, account_for_inf="SVM", inf_threshold="20s", trust_region_factor=1.5,
+                       random_state=1)
+        k = clone(gpr.kernel)
+        k.theta = np.log(np.array([4.0, 0.3, 0.3, 0.3]))
+        gpr.kernel_, gpr._fitted = k, True
+        gpr.append_to_data(X, y, fit_gpr=False)
+        if not use_device:
+            gpr._push_gates = lambda *a, **k: False
+        acq = NORA(bounds, sampler="uniform", verbose=0)
+        acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+        Xp, yp, ap = acq.multi_add(gpr, n_points=3, bounds=gpr.trust_bounds, rng=np.random.default_rng(0))
+        res.append((Xp, yp, ap, acq._y_mc.copy(), acq._sigma_y_mc.copy(), gpr.device))
+    assert res[0][5].gates is not None and getattr(res[1][5], "gates", None) is None
+    for a, b in zip(res[0][:5], res[1][:5]):
+        np.testing.assert_array_equal(a, b)
+    assert np.isneginf(res[0][3]).sum() > 0 and np.all(np.isfinite(res[0][1]))

@@ -300,3 +300,43 @@ def test_matern12_gradient_x_and_finite_differences_at_size():
                 assert abs((mp[0] - mm[0]) / 2e-6 - mg[k]) <= 1e-5 * max(1.0, abs(mg[k]))
                 # the reference scales the std gradient by std_y twice: undo one factor
                 assert abs((sp[0] - sm[0]) / 2e-6 - sg[k] / std_y) <= 1e-4 * max(1.0, abs(sg[k] / std_y))
+
+
+def test_device_gates_match_host_masks_in_the_sweep():
+    """SVM decision function + trust box evaluated by gates_kernel inside gpry_sweep_logexp against
+    the host verdicts (libsvm through scikit-learn, numpy box test) on 50k candidates."""
+    from gpry_amd import _lib
+    from gpry_amd.gp_acquisition import NORA
+    bounds, X, y, Xc = orc.synthetic_like_goldens(200, 4, 50000, seed=31)
+    y = y.copy()
+    y[X[:, 0] > 1.0] = -np.inf
+    gpr = make_gpr(bounds, 3, theta=np.log(np.array([4.0, 0.3, 0.3, 0.3, 0.3])), account_for_inf="SVM",
+                   inf_threshold="20s", trust_region_factor=1.5, random_state=1)
+    gpr.append_to_data(X, y, fit_gpr=False)
+    host = gpr._masks(Xc, False, False)
+    assert gpr._push_gates() is True
+    gpr._ensure_factor()
+    gpr._push_affine()
+    out = gpr.device.sweep_logexp(Xc, 0.3, gpr.y_max, gpr.noise_level)
+    sv, coef, gamma, intercept, pos = gpr.infinities_classifier.device_params()
+    dec = gpr.infinities_classifier._svc.decision_function(gpr.preprocessing_X.transform(Xc))
+    clear = np.abs(dec) > 1e-9                              # away from the decision boundary
+    dev_inf = np.isneginf(out["y"])
+    assert np.array_equal(dev_inf[clear], (host != 0)[clear])
+    dev_cls = out["sigma"] == 0.0
+    assert np.array_equal(dev_cls[clear], ((host & _lib.MASK_CLASSIFIED_INF) != 0)[clear])
+    assert 1000 < dev_inf.sum() < 49000 and 100 < dev_cls.sum()
+    gpr.device.set_gates()                                  # off again: same sweep with the host mask
+    out2 = gpr.device.sweep_logexp(Xc, 0.3, gpr.y_max, gpr.noise_level, mask=host)
+    same = clear
+    np.testing.assert_array_equal(out["acq"][same], out2["acq"][same])
+    # and through NORA: identical proposals either way
+    res = []
+    for use_device in (True, False):
+        if not use_device:
+            gpr._push_gates = lambda *a, **k: (gpr.device.set_gates(), False)[1]
+        acq = NORA(bounds, sampler="uniform", verbose=0)
+        acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+        res.append(acq.multi_add(gpr, n_points=4, bounds=gpr.trust_bounds, rng=np.random.default_rng(0)))
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, b)
