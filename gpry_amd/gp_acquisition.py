@@ -332,10 +332,14 @@ class NORA(GenericGPAcquisition):
         # rows to ignore: weight-0 samples of a reweighted set and points proposed since the
         # last resampling (:1037-1047; both samples assumed unique, as there)
         exclude = list(self._dropped)
-        for row in self._X_already_proposed:
-            hit = np.flatnonzero(np.all(X_dev == row, axis=1))
-            if hit.size:
-                exclude.append(int(hit[0]))
+        if len(self._X_already_proposed):
+            # first row of the pool equal to each proposed point; one pass over the first
+            # coordinate narrows 1e6 rows down to the handful worth comparing in full
+            near = np.flatnonzero(np.isin(X_dev[:, 0], self._X_already_proposed[:, 0]))
+            for row in self._X_already_proposed:
+                hit = near[np.all(X_dev[near] == row, axis=1)] if near.size else near
+                if hit.size:
+                    exclude.append(int(hit[0]))
         exclude = np.unique(np.asarray(exclude, dtype=np.int64))
         self.acq_func_y_sigma = partial(self.acq_func.f, baseline=gpr.y_max,
                                         noise_level=gpr.noise_level, zeta=self.acq_func.zeta)
