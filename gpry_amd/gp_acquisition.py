@@ -89,14 +89,19 @@ class NORA(GenericGPAcquisition):
     part of this package: use ``sampler="uniform"``, or override ``do_MC_sample`` to
     inject a pool ``(X, None, None, weights)``.  ``comm`` (optional) is a communicator with
     ``world``, ``rank`` and ``allgather(ndarray)`` (``gpry_amd._lib.RcclComm``) to shard the
-    sweep over several GPUs.
+    sweep over several GPUs.  ``gather_y``: whether every rank assembles the full ``(y, sigma_y)``
+    arrays of the pool after a sharded sweep (``last_MC_sample()[1:3]``; the reference merges
+    them on rank 0, gpry/mpi.py:118-131) -- ``True``, ``False`` (they stay ``None``, which the
+    reference's interface allows: "may be None if not computed while sampling"), or ``"auto"``
+    = only when a later reweighting will need them (``mc_every > 1``).  The ranking itself never
+    needs them: it works on the devices' shortlists.
     """
 
     def __init__(self, bounds, preprocessing_X=None, verbose=1, acq_func="LogExp", sampler=None,
                  mc_every="1d", nlive_per_training=3, nlive_max="25d", nlive_per_dim_max=None,
                  num_repeats="5d", num_repeats_per_dim=None, precision_criterion_target=0.01,
                  nprior_per_nlive=10, max_ncalls=None, tmpdir=None, comm=None,
-                 shortlist_size=None):
+                 shortlist_size=None, gather_y="auto"):
         super().__init__(bounds=np.asarray(bounds), preprocessing_X=preprocessing_X,
                          verbose=verbose, acq_func=acq_func)
         self.log_header = f"[ACQUISITION : {self.__class__.__name__}] "
@@ -122,6 +127,7 @@ class NORA(GenericGPAcquisition):
         self.pool = None
         self.comm = comm
         self.shortlist_size = shortlist_size
+        self.gather_y = gather_y
         self._X_already_proposed = np.empty((0, self.n_d))
         self.stats = {}
 
@@ -195,20 +201,26 @@ class NORA(GenericGPAcquisition):
         # the very same array object as last time is still resident in HBM: skip the upload
         resident = (X is getattr(self, "_sweep_X", None) and getattr(self, "_sweep_dev", None) is gpr.device
                     and (lo, hi) == (self._sweep_lo, self._sweep_hi))
+        sharded = self.comm is not None and self.comm.world > 1
+        gather = (self.mc_every > 1) if self.gather_y == "auto" else bool(self.gather_y)
+        want = ("y", "sigma") if (gather or not sharded) else ()
         out = gpr.device.sweep_logexp(None if resident else X[lo:hi], self.acq_func.zeta, gpr.y_max,
-                                      noise, mask=mask, M=hi - lo, want=("y", "sigma"))
+                                      noise, mask=mask, M=hi - lo, want=want)
         self._sweep_dev = gpr.device
         gpr.n_eval += M
         if out["n_nan"]:
             raise ValueError("Acquisition function value not a number: nan")
-        y, s = out["y"], out["sigma"]
-        if self.comm is not None and self.comm.world > 1:
+        y, s = (out.get("y"), out.get("sigma")) if want else (None, None)
+        if sharded and gather:
             per = -(-M // self.comm.world)
             buf = np.zeros((2, per))
             buf[0, :hi - lo], buf[1, :hi - lo] = y, s
             allb = self.comm.allgather(buf)
-            y = np.concatenate([allb[r, 0, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
-            s = np.concatenate([allb[r, 1, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
+            if per * self.comm.world == M:       # even shards: the gathered rows are the arrays
+                y, s = allb[:, 0, :].reshape(-1), allb[:, 1, :].reshape(-1)
+            else:
+                y = np.concatenate([allb[r, 0, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
+                s = np.concatenate([allb[r, 1, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
         self._sweep_X, self._sweep_lo, self._sweep_hi = X, lo, hi
         self.stats["sweep_s"] = time() - t0
         self.stats["sweep_M"] = M

@@ -31,7 +31,7 @@ class GlooComm:
         return np.stack([o.numpy().view(arr.dtype).reshape(arr.shape) for o in outs])
 
 
-def _worker(rank, world, port, tag, shortlist, q):
+def _worker(rank, world, port, tag, shortlist, q, gather="auto"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -43,6 +43,17 @@ def _worker(rank, world, port, tag, shortlist, q):
         gpr = FakeGPR(m)
         npts = len(g[p + "acq_cond"]) - 1
         comm = GlooComm()
+        if gather is False:
+            # nothing will need the pool's y / sigma (no reweighting): they are not gathered
+            acq = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=comm, shortlist_size=shortlist,
+                       gather_y=False)
+            acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+            Xp, yp, ap = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
+            ok = (np.array_equal(Xp, g[p + "X_pool"]) and np.allclose(ap, g[p + "acq_pool"], rtol=1e-8)
+                  and acq.last_MC_sample()[1] is None and acq.last_MC_sample()[2] is None
+                  and acq.last_MC_sample()[0] is Xc)
+            q.put((rank, bool(ok), True, comm.n_allgather + 100, (acq._sweep_lo, acq._sweep_hi)))
+            return
         acq = NORA(bounds, sampler="uniform", mc_every=2, verbose=0, comm=comm, shortlist_size=shortlist)
         acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
         Xp, yp, ap = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
@@ -58,15 +69,15 @@ def _worker(rank, world, port, tag, shortlist, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tag,shortlist", [("a", 8), ("b", 64)])
-def test_two_rank_sharded_multi_add_equals_single_rank_reference(tag, shortlist):
+@pytest.mark.parametrize("tag,shortlist,gather", [("a", 8, "auto"), ("b", 64, "auto"), ("b", 64, False)])
+def test_two_rank_sharded_multi_add_equals_single_rank_reference(tag, shortlist, gather):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, tag, shortlist, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tag, shortlist, q, gather)) for r in range(2)]
     for pr in procs:
         pr.start()
     res = [q.get(timeout=300) for _ in range(2)]
