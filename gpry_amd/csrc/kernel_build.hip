@@ -154,6 +154,13 @@ __device__ __forceinline__ void tri_decode(int64_t t, int* bi, int* bj) {
 // TS = 32 (one wave per tile) keeps ~8000 tiles in flight at N = 4096, so that the launch is
 // not quantised into a few long rounds.  Algorithmic traffic: read X once (8 N d), write K
 // once (8 N^2).
+typedef double nt_v2d __attribute__((ext_vector_type(2)));
+// streaming 16-byte store: K is written once and read next by another kernel
+__device__ __forceinline__ void nt_store2(double2* p, double a, double b) {
+    nt_v2d v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<nt_v2d*>(p));
+}
+
 template <int KID, int TS>
 __global__ __launch_bounds__((TS / 4) * (TS / 4)) void kernel_train_kernel(
     const double* __restrict__ Xs, const double* __restrict__ noise, double* __restrict__ K,
@@ -177,9 +184,12 @@ __global__ __launch_bounds__((TS / 4) * (TS / 4)) void kernel_train_kernel(
 #pragma unroll
         for (int b = 0; b < 4; b++) r2[a][b] = 0.0;
     for (int k = 0; k < dp; k++) {
+        // columns of this thread: {2tx, 2tx+1, TS/2+2tx, TS/2+2tx+1} -- the 16 lanes of a row then
+        // store 256 contiguous bytes per instruction (whole cache lines) instead of 16-byte pieces
+        // of every other 32 bytes
         const double2* pi = reinterpret_cast<const double2*>(Xi + k * TS + ty * 4);
-        const double2* pj = reinterpret_cast<const double2*>(Xj + k * TS + tx * 4);
-        double2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
+        const double2* pj = reinterpret_cast<const double2*>(Xj + k * TS + tx * 2);
+        double2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[TS / 4];
         double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -191,7 +201,8 @@ __global__ __launch_bounds__((TS / 4) * (TS / 4)) void kernel_train_kernel(
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            int64_t i = (int64_t)bi * TS + ty * 4 + a, j = (int64_t)bj * TS + tx * 4 + b;
+            int64_t i = (int64_t)bi * TS + ty * 4 + a;
+            int64_t j = (int64_t)bj * TS + (b >> 1) * (TS / 2) + tx * 2 + (b & 1);
             double v = kp.C * corr_r2<KID>(r2[a][b]);
             if (i == j) v = kp.C + (add_noise ? noise[i < kp.N ? i : 0] : 0.0);
             if (i >= kp.N || j >= kp.N) v = (i == j) ? 1.0 : 0.0;   // identity padding
@@ -200,9 +211,9 @@ __global__ __launch_bounds__((TS / 4) * (TS / 4)) void kernel_train_kernel(
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         int64_t i = (int64_t)bi * TS + ty * 4 + a;
-        double2* p = reinterpret_cast<double2*>(K + i * ld + (int64_t)bj * TS + tx * 4);
-        p[0] = make_double2(val[a][0], val[a][1]);
-        p[1] = make_double2(val[a][2], val[a][3]);
+        double2* p = reinterpret_cast<double2*>(K + i * ld + (int64_t)bj * TS + tx * 2);
+        nt_store2(p, val[a][0], val[a][1]);
+        nt_store2(p + TS / 4, val[a][2], val[a][3]);
     }
     if (bi == bj) return;
     __syncthreads();            // X tiles no longer needed: reuse LDS as a [TS][TS+2] transpose pad
@@ -210,14 +221,15 @@ __global__ __launch_bounds__((TS / 4) * (TS / 4)) void kernel_train_kernel(
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) T[(tx * 4 + b) * TP + ty * 4 + a] = val[a][b];
+        for (int b = 0; b < 4; b++) T[((b >> 1) * (TS / 2) + tx * 2 + (b & 1)) * TP + ty * 4 + a] = val[a][b];
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         int jr = ty * 4 + a;   // row of the mirrored tile (a column index j of K)
-        double2* p = reinterpret_cast<double2*>(K + ((int64_t)bj * TS + jr) * ld + (int64_t)bi * TS + tx * 4);
-        const double2* q = reinterpret_cast<const double2*>(T + jr * TP + tx * 4);
-        p[0] = q[0]; p[1] = q[1];
+        double2* p = reinterpret_cast<double2*>(K + ((int64_t)bj * TS + jr) * ld + (int64_t)bi * TS + tx * 2);
+        const double2* q = reinterpret_cast<const double2*>(T + jr * TP + tx * 2);
+        nt_store2(p, q[0].x, q[0].y);
+        nt_store2(p + TS / 4, q[TS / 4].x, q[TS / 4].y);
     }
 }
 

@@ -28,4 +28,4 @@ for la in ((1, 0) if len(sys.argv) > 4 else (1,)):
     print(f"chol_lookahead={la}: factor bit-identical to the first one: {same}; lml {lml[0]:.12g}")
     for k in ("kernel_build", "potrf", "trtri", "lauum", "lml_traces"):
         ms, n = dev.timing(k)
-        print(f"  {k}: {ms / max(n, 1):.3f} ms avg over {n}")
+        print(f"  {k}: {ms / max(n, 1) * 1e3:.1f} us avg over {n}")
