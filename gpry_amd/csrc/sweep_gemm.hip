@@ -364,18 +364,7 @@ __device__ __forceinline__ void mma_row(v4d (&acc)[4][4], const Frag& f, int mi)
 // lgkmcnt(0) each, so the run is slower; the shares are what matters): g.diag[0] += cycles in
 // the vmcnt/lgkmcnt wait, [1] += cycles in s_barrier, [2] += cycles of the whole slab step,
 // [3] += wave lifetime in 100-MHz ticks, [5] += wave-slabs, [4] += wave-tiles.
-__device__ __forceinline__ void mma_half(v4d (&acc)[4][4], const Frag& f, int mi, int h) {
-    const double a = mi == 0 ? f.a0 : mi == 1 ? f.a1 : mi == 2 ? f.a2 : f.a3;
-    if (h == 0) {
-        acc[mi][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b0, acc[mi][0], 0, 0, 0);
-        acc[mi][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b1, acc[mi][1], 0, 0, 0);
-    } else {
-        acc[mi][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b2, acc[mi][2], 0, 0, 0);
-        acc[mi][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b3, acc[mi][3], 0, 0, 0);
-    }
-}
-
-template <bool DIAG, int TAIL, bool PERSIST>
+template <bool DIAG, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double smem[2 * BUF_DOUBLES];
     __shared__ int s_next;
@@ -525,40 +514,6 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
            read fragments nobody uses, so that the DMA issue and the fragment reads of the    \
            next slab can sit in the shadow of k-step 3's MFMAs */                              \
         const int s2 = min((S) + 2, nslab - 1);                                              \
-        if (TAIL == 1) {                                                                     \
-        mma_half(acc, f1, 0, 0);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        load_frag<(BUF) ^ 1, 0>(f0, addrA[0], addrB);                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        mma_half(acc, f1, 0, 1);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        issue_piece(s2, BUF, 0);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        mma_half(acc, f1, 1, 0);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        issue_piece(s2, BUF, 1);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        mma_half(acc, f1, 1, 1);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        issue_piece(s2, BUF, 2);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        mma_half(acc, f1, 2, 0);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        issue_piece(s2, BUF, 3);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        mma_half(acc, f1, 2, 1);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        issue_piece(s2, BUF, 4);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        mma_half(acc, f1, 3, 0);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        issue_piece(s2, BUF, 5); issue_piece(s2, BUF, 6);                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        mma_half(acc, f1, 3, 1);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        issue_piece(s2, BUF, 7);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        } else {                                                                             \
         mma_row(acc, f1, 0);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                   \
         load_frag<(BUF) ^ 1, 0>(f0, addrA[0], addrB);                                        \
@@ -574,7 +529,6 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                                   \
         mma_row(acc, f1, 3);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                   \
-        }                                                                                    \
     }
 
     for (int s = 0; s < nslab; s += 2) {
@@ -639,12 +593,11 @@ int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g0) {
     // workgroup already keeps the matrix pipe 90 % busy, and the chip is power-limited)
     const size_t xl = (size_t)g.extra_lds;
     if (g.persist) {
-        if (g.diag) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<true, 0, true>), grid, dim3(256), xl, ctx->stream, g);
-        else hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, 0, true>), grid, dim3(256), xl, ctx->stream, g);
+        if (g.diag) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<true, true>), grid, dim3(256), xl, ctx->stream, g);
+        else hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, true>), grid, dim3(256), xl, ctx->stream, g);
     } else {
-        if (g.diag) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<true, 0, false>), grid_all, dim3(256), xl, ctx->stream, g);
-        else if (g.kskew == 1) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, 1, false>), grid_all, dim3(256), xl, ctx->stream, g);
-        else hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, 0, false>), grid_all, dim3(256), xl, ctx->stream, g);
+        if (g.diag) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<true, false>), grid_all, dim3(256), xl, ctx->stream, g);
+        else hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, false>), grid_all, dim3(256), xl, ctx->stream, g);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
