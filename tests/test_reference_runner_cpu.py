@@ -113,3 +113,45 @@ def test_reference_runner_with_an_infinite_region_uses_the_device_gates(monkeypa
     truth = np.array([loglike(*x) for x in Xt]) - 3 * np.log(12.0)
     assert np.max(np.abs(ours.gpr.predict(Xt) - truth)) < 0.1
     assert np.max(np.abs(ref.gpr.predict(Xt) - truth)) < 0.1
+
+
+def test_reference_batch_optimizer_runs_on_the_mirror_gpr(monkeypatch):
+    """The reference's own gradient-based acquisition (``BatchOptimizer``, gp_acquisition.py:270-389)
+    needs nothing but ``predict(..., return_mean_grad, return_std_grad)``, lies appended with
+    ``fit_gpr=False`` and deep copies: on top of the mirror GPR it drives the run to convergence."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_goldens import import_reference
+    import_reference()
+    import scipy.stats as st
+    import gpry.run
+    import gpry.gp_acquisition
+    rv = st.multivariate_normal([0.5, -0.3], [[1.0, 0.6], [0.6, 0.8]])
+
+    def loglike(x, y):
+        return rv.logpdf([x, y])
+
+    from oracle_device import OracleDevice
+    from gpry_amd import _lib
+    import gpry_amd.gpr as mirror_gpr
+    saved = {k: getattr(gpry.run, k) for k in ("GaussianProcessRegressor", "GenericGPAcquisition",
+                                                "Normalize_bounds", "Normalize_y")}
+    saved_nora, saved_gpr = gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor
+    monkeypatch.setattr(_lib, "Device", lambda index=0: OracleDevice())
+    try:
+        from gpry_amd.integration import patch_gpry
+        patch_gpry()
+        r = gpry.run.Runner(loglike, [[-5, 5], [-5, 5]], gpr={"kernel": {"Matern": {"nu": 2.5}}},
+                            gp_acquisition="BatchOptimizer", options={"max_total": 120, "max_finite": 120},
+                            checkpoint=None, verbose=0, seed=1)
+        r.generate_mc_sample = lambda *a, **k: None
+        r.diagnose_last_mc_sample = lambda *a, **k: True
+        r.run()
+    finally:
+        for k, v in saved.items():
+            setattr(gpry.run, k, v)
+        gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor = saved_nora, saved_gpr
+    assert isinstance(r.gpr, mirror_gpr.GaussianProcessRegressor)
+    assert type(r.acquisition).__name__ == "BatchOptimizer" and r.has_converged
+    Xt = rv.rvs(30, random_state=3)
+    truth = np.array([loglike(*x) for x in Xt]) - np.log(100.0)
+    assert np.max(np.abs(r.gpr.predict(Xt) - truth)) < 0.1
