@@ -28,3 +28,21 @@ for N, d in ((1024, 8), (4096, 16)):
             us = (time.perf_counter() - t0) / reps * 1e6
             print(f"N={N} d={d} M={M:5d} std={int(std)}: {us:8.1f} us per call, {us / M:8.2f} us per point")
     dev.close()
+
+# one point with x-gradients (what a gradient-based acquisition optimiser calls per step)
+for N, d in ((1024, 8), (4096, 16)):
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (N, d)); y = rng.standard_normal(N)
+    dev = _lib.Device(0)
+    dev.set_train(X, y, np.full(N, 1e-4))
+    dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
+    assert dev.factorize() == 0
+    x = rng.uniform(0, 1, d)
+    for kinv in (False, True):
+        for _ in range(5):
+            dev.predict_grad(x, want_kinv=kinv)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            dev.predict_grad(x, want_kinv=kinv)
+        print(f"N={N} d={d} predict_grad(want_kinv={kinv}): {(time.perf_counter() - t0) / 50 * 1e6:.1f} us per call")
+    dev.close()
