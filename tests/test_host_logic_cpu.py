@@ -250,3 +250,14 @@ def test_nora_argument_checks():
     with pytest.raises(ValueError):
         acq.multi_add(None, n_points=0)
     assert "NORA" in builtin_names()
+
+
+def test_header_is_plain_c99_and_the_c_client_compiles():
+    """include/gpry_hip.h must be consumable by a C compiler without C++ or torch headers."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = os.path.join(ROOT, "tests", "c_abi", "c_abi_smoke.c")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
+                    "-I", os.path.join(ROOT, "include"), src], check=True)
