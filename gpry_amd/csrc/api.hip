@@ -874,7 +874,10 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
     g.B = dB; g.ldb = b_trans ? K : N;
     g.C = dC; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.kmode = kmode; g.lower_only = lower_only; g.tile_map = tile_map;
-    GPRY_TRY(gemm_f64_launch(ctx, g, a_trans != 0, b_trans != 0, epi));
+    {
+        StageScope s(ctx, "debug_gemm");
+        GPRY_TRY(gemm_f64_launch(ctx, g, a_trans != 0, b_trans != 0, epi));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(C, dC, sizeof(double) * crow * N, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     GPRY_TRY(dev_free(ctx, dA)); GPRY_TRY(dev_free(ctx, dB)); GPRY_TRY(dev_free(ctx, dC));
