@@ -49,7 +49,7 @@ struct gpry_ctx {
 
     // training set (transformed space)
     int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
-    int d = 0, dpad = 0;
+    int d = 0, dpad = 0, dp_cap = 0;   // dp_cap: row width the X buffers were allocated for
     int kernel_id = GPRY_RBF;
     bool have_theta = false, factor_valid = false;
     double theta[1 + GPRY_MAX_DIM] = {0};

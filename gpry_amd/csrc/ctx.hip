@@ -73,11 +73,14 @@ int ensure_pinned(gpry_ctx* ctx, int64_t bytes) {
 int ensure_capacity(gpry_ctx* ctx, int64_t N, int d) {
     int64_t Np = round_up(N > 0 ? N : 1, GPRY_TILE);
     int dpad = (d + 1) & ~1;
-    if (Np > ctx->cap || dpad > ctx->dpad) {
-        int64_t cap = Np;
-        // grow geometrically: the training set gains d points per iteration
-        if (ctx->cap > 0 && cap < ctx->cap + ctx->cap / 8) cap = round_up(ctx->cap + ctx->cap / 8, GPRY_TILE);
-        int dp = dpad > ctx->dpad ? dpad : ctx->dpad;
+    if (Np > ctx->cap || dpad > ctx->dp_cap) {
+        int64_t cap = ctx->cap;
+        if (Np > cap) {
+            cap = Np;
+            // grow geometrically: the training set gains d points per iteration
+            if (ctx->cap > 0 && cap < ctx->cap + ctx->cap / 8) cap = round_up(ctx->cap + ctx->cap / 8, GPRY_TILE);
+        }
+        int dp = dpad > ctx->dp_cap ? dpad : ctx->dp_cap;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         double** bufs[] = {&ctx->dX, &ctx->dXs, &ctx->dy, &ctx->dnoise, &ctx->dA, &ctx->dV, &ctx->dW,
                            &ctx->dW2, &ctx->dW3, &ctx->dalpha_, &ctx->dvec};
@@ -94,6 +97,7 @@ int ensure_capacity(gpry_ctx* ctx, int64_t N, int d) {
         GPRY_TRY(dev_alloc(ctx, &ctx->dalpha_, cap));
         GPRY_TRY(dev_alloc(ctx, &ctx->dvec, 8 * cap + 4096));
         ctx->cap = cap;
+        ctx->dp_cap = dp;
         ctx->kst_cap = 0; if (ctx->dKst) { GPRY_TRY(dev_free(ctx, ctx->dKst)); ctx->dKst = nullptr; }
         ctx->kb_cap = 0; ctx->kb_n = 0;
         if (ctx->dU) { GPRY_TRY(dev_free(ctx, ctx->dU)); ctx->dU = nullptr; }

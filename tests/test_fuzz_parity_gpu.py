@@ -1,0 +1,18 @@
+"""Randomised parity sweep (tools/fuzz_parity.py): random N (around the 64/128 padding quanta), d in
+1..32, M across the small-batch / panel path boundaries, all four kernels, masks, chunk sizes."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_configurations_against_the_oracle(seed):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    bad, worst = fuzz_parity.run(n_cases=25, seed=seed)
+    assert bad == 0, worst
+    assert worst["mean"] < 1e-8 and worst["var"] < 1e-9

@@ -449,3 +449,17 @@ def test_small_batch_paths_agree_with_the_panel_path(dev, M):
     assert np.max(np.abs(std_s[mask != _lib.MASK_CLASSIFIED_INF] ** 2 - rs[mask != _lib.MASK_CLASSIFIED_INF] ** 2)) <= 1e-9 * C
     if M > 2:
         assert std_s[1] == 0.0 and std_s[2] > 0.0
+
+
+def test_capacity_does_not_grow_when_only_the_dimension_changes(dev):
+    """Regression (found by tools/fuzz_parity.py): alternating small / large d used to enlarge the
+    N x N buffers by 12.5 % each time until the device ran out of memory."""
+    rng = np.random.default_rng(0)
+    for it in range(80):
+        d = 32 if it % 2 else 3
+        X = rng.uniform(0, 1, (200, d))
+        dev.set_train(X, rng.standard_normal(200), np.full(200, 1e-3))
+        dev.set_theta(3, np.log(np.array([2.0] + [0.5] * d)))
+    assert dev.factorize() == 0
+    m = dev.predict(rng.uniform(0, 1, (5, 3)))
+    assert np.all(np.isfinite(m))

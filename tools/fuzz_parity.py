@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the device path against the oracle: random N, d, M, kernel, theta,
+noise, masks, chunk sizes, small-batch paths.  Prints the worst deviations; exits 1 on a violation
+of the test-suite tolerances."""
+import os
+import sys
+import time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpry_amd import _lib  # noqa: E402
+from oracle import gpry_oracle as orc  # noqa: E402
+
+
+
+def run(n_cases=60, seed=0, dev=None):
+    """Returns (number of violations, worst deviations)."""
+    rng = np.random.default_rng(seed)
+    dev = dev or _lib.Device(0)
+    worst = {"mean": 0.0, "var": 0.0, "lml": 0.0, "grad": 0.0, "acq": 0.0, "kgrad": 0.0}
+    bad = 0
+    for case in range(n_cases):
+        bad += _one_case(case, rng, dev, worst)
+    return bad, worst
+
+
+def _one_case(case, rng, dev, worst):
+    bad = 0
+    if True:
+        N = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 383, 500, 640, 777]))
+        d = int(rng.integers(1, 33))
+        M = int(rng.choice([1, 2, 15, 16, 17, 100, 128, 129, 1000, 3000]))
+        kid = int(rng.integers(0, 4))
+        bounds = np.stack([-rng.uniform(1, 6, d), rng.uniform(1, 6, d)], axis=1)
+        X = rng.uniform(bounds[:, 0], bounds[:, 1], (N, d))
+        Xc = rng.uniform(bounds[:, 0] - 0.2, bounds[:, 1] + 0.2, (M, d))
+        if N > 3 and M > 2:
+            Xc[1] = X[N // 2]                                   # a candidate on a training point
+        y = -0.5 * ((X / (bounds[:, 1] - bounds[:, 0])) ** 2).sum(1) * rng.uniform(1, 30) + rng.normal(0, 0.01, N)
+        m = orc.OracleGPR(bounds, kernel_id=kid, normalize_y=(N > 1), noise_level=float(10 ** rng.uniform(-3, -1)),
+                          clip_factor=float(rng.choice([1.0, 1.1, 2.0])))
+        m.theta = np.log(np.concatenate(([10 ** rng.uniform(-1, 2)], 10 ** rng.uniform(-0.7, 0.3, d))))
+        m.fitted = True
+        try:
+            m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+        except np.linalg.LinAlgError:
+            return bad
+        dev.set_train(m.X_train_, m.y_train_, m.alpha)
+        dev.set_theta(kid, m.theta)
+        dev.set_affine(m.pre_X.lo, m.pre_X.hi - m.pre_X.lo, m.pre_y.mean_, m.pre_y.std_, m.clip_hi())
+        if dev.factorize() != 0:
+            print(f"case {case}: device says not PD, oracle factorised (N={N} d={d} kid={kid})")
+            bad += 1
+            return bad
+        mask = None
+        if rng.random() < 0.5:
+            mask = (rng.random(M) < 0.2).astype(np.uint8) * _lib.MASK_CLASSIFIED_INF
+            mask |= (rng.random(M) < 0.2).astype(np.uint8) * _lib.MASK_OUTSIDE_TRUST
+        rm, rs = m.predict(Xc, return_std=True)
+        rm, rs = rm.copy(), rs.copy()
+        if mask is not None:
+            rm[mask != 0] = -np.inf
+            rs[(mask & _lib.MASK_CLASSIFIED_INF) != 0] = 0.0
+        C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
+        scale = max(1.0, np.max(np.abs(m.y_train)))
+        chunk = int(rng.choice([1024, 2048, 32768]))
+        dev.set_option("sweep_chunk", chunk)
+        zeta = orc.auto_zeta(d)
+        out = dev.sweep_logexp(Xc, zeta, m.y_max, m.noise_level, mask=mask)
+        dev.set_option("sweep_chunk", 32768)
+        mean2, std2 = dev.predict(Xc, return_std=True, mask=mask)          # small / panel path by M
+        mean3 = dev.predict(Xc, mask=mask)
+        fin = np.isfinite(rm)
+        for got_m, got_s in ((out["y"], out["sigma"]), (mean2, std2), (mean3, None)):
+            if not np.array_equal(np.isneginf(got_m), ~fin):
+                print(f"case {case}: -inf pattern differs"); bad += 1
+            e = np.max(np.abs(got_m[fin] - rm[fin])) / scale if fin.any() else 0.0
+            worst["mean"] = max(worst["mean"], e)
+            if e > 1e-7:
+                print(f"case {case}: mean err {e:.2e} (N={N} d={d} M={M} kid={kid})"); bad += 1
+            if got_s is not None:
+                e = np.max(np.abs(got_s ** 2 - rs ** 2)) / C
+                worst["var"] = max(worst["var"], e)
+                if e > 1e-8:
+                    print(f"case {case}: var err {e:.2e} (N={N} d={d} M={M} kid={kid})"); bad += 1
+        racq = orc.logexp_f(rm, rs, m.y_max, m.noise_level, zeta)
+        okm = np.isfinite(racq) & (rs ** 2 - m.noise_level ** 2 > 1e-6 * C)
+        if okm.any():
+            e = np.max(np.abs(out["acq"][okm] - racq[okm]))
+            worst["acq"] = max(worst["acq"], e)
+            if e > 1e-4:
+                print(f"case {case}: acq err {e:.2e}"); bad += 1
+        th = m.theta + rng.normal(0, 0.05, d + 1)
+        lml, grad, info = dev.lml(th, True)
+        rl, rg = orc.log_marginal_likelihood(m.X_train_, m.y_train_, m.alpha, th, kid, True)
+        if np.isfinite(rl):
+            e = abs(lml - rl) / max(1.0, abs(rl))
+            worst["lml"] = max(worst["lml"], e)
+            eg = np.max(np.abs(grad - rg)) / max(1.0, np.max(np.abs(rg)))
+            worst["grad"] = max(worst["grad"], eg)
+            # conditioning-aware: log det and y^T K^-1 y lose ~cond(K) * eps (the reference's own
+            # noise floor; RBF with long length scales reaches cond 1e12 here)
+            Ld = np.diag(m.L_)
+            cond = (Ld.max() / Ld.min()) ** 2
+            # (the diagonal ratio underestimates cond(K): two-dimensional RBF / Matern cases reach 2e-8)
+            if e > max(1e-7, 1e-15 * cond) or eg > max(1e-6, 1e-12 * cond):
+                print(f"case {case}: lml err {e:.2e} grad err {eg:.2e} (N={N} d={d} kid={kid})"); bad += 1
+        x0 = Xc[0]
+        mg, kg, G = dev.predict_grad(x0, want_kinv=True, want_kgrad=True)
+        Gr = orc.kernel_gradient_x(m.pre_X.transform(x0[None, :])[0], m.X_train_, m.theta, kid)
+        e = np.max(np.abs(G - Gr)) / max(1e-300, np.max(np.abs(Gr)), 1e-12)
+        worst["kgrad"] = max(worst["kgrad"], e)
+        if e > 1e-10:
+            print(f"case {case}: kernel x-gradient err {e:.2e} (N={N} d={d} kid={kid})"); bad += 1
+        K = min(M, 40)
+        top, bound = dev.sweep_topk(K)
+        order = np.lexsort((-np.arange(M), -out["acq"]))
+        valid = ~np.isnan(out["acq"][order])
+        if not np.array_equal(top["idx"], order[valid][:K][:len(top)]):
+            print(f"case {case}: top-k order differs"); bad += 1
+    return bad
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time()
+    bad, worst = run(n_cases, seed)
+    print(f"{n_cases} cases in {time.time() - t0:.1f} s; worst relative deviations: " +
+          ", ".join(f"{k} {v:.2e}" for k, v in worst.items()) + f"; violations: {bad}")
+    sys.exit(1 if bad else 0)
