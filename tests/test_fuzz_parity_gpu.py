@@ -16,3 +16,12 @@ def test_random_configurations_against_the_oracle(seed):
     bad, worst = fuzz_parity.run(n_cases=25, seed=seed)
     assert bad == 0, worst
     assert worst["mean"] < 1e-8 and worst["var"] < 1e-9
+
+
+def test_random_operation_sequences_on_the_host_mirror():
+    """tools/fuzz_mirror.py: appends, predictions, conditioned models, copies / pickles and NORA
+    proposals of the mirror classes on the GPU against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_mirror
+    bad, worst = fuzz_mirror.run(n_seq=12, seed=42)
+    assert bad == 0, worst
