@@ -69,24 +69,25 @@ def _worker(rank, world, port, tag, shortlist, q, gather="auto"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tag,shortlist,gather", [("a", 8, "auto"), ("b", 64, "auto"), ("b", 64, False)])
-def test_two_rank_sharded_multi_add_equals_single_rank_reference(tag, shortlist, gather):
+@pytest.mark.parametrize("tag,shortlist,gather,world", [("a", 8, "auto", 2), ("b", 64, "auto", 2),
+                                                        ("b", 64, False, 2), ("a", 16, "auto", 3)])
+def test_two_rank_sharded_multi_add_equals_single_rank_reference(tag, shortlist, gather, world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, tag, shortlist, q, gather)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, shortlist, q, gather)) for r in range(world)]
     for pr in procs:
         pr.start()
-    res = [q.get(timeout=300) for _ in range(2)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
     res.sort()
     shards = [r[4] for r in res]
-    assert shards[0][0] == 0 and shards[0][1] == shards[1][0]     # contiguous, disjoint shards
+    assert shards[0][0] == 0 and all(shards[i][1] == shards[i + 1][0] for i in range(world - 1))   # contiguous
     for rank, ok, ok2, n_ag, _ in res:
         assert ok, f"rank {rank}: first multi_add differs from the single-rank reference"
         assert ok2, f"rank {rank}: second (reweighted) multi_add differs"
