@@ -31,12 +31,6 @@ import numpy as np
 import gpry_amd.acquisition_functions as gpryacqfuncs
 from gpry_amd.tools import get_Xnumber, get_random_generator, is_in_bounds, remove_0_weight_samples
 
-try:
-    from sklearn.base import is_regressor
-except Exception:  # pragma: no cover
-    def is_regressor(obj):
-        return hasattr(obj, "predict")
-
 
 def builtin_names():
     return [name for name, obj in inspect.getmembers(sys.modules[__name__])

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from oracle_device import OracleDevice, attach
+from oracle_device import attach
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SPEC = {0: "RBF", 1: {"Matern": {"nu": 0.5}}, 2: {"Matern": {"nu": 1.5}},

@@ -4,7 +4,6 @@ farm (4 restarts, the first from the current theta) through gpry_amd.parallel.fi
 import os
 import sys
 import time
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from gpry_amd.gpr import GaussianProcessRegressor  # noqa: E402
