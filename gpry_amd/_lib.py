@@ -61,6 +61,7 @@ SIGNATURES = {
     "gpry_set_gates": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_int, _vp]),
     "gpry_sweep_logexp": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_double, C.c_double,
                                     C.c_double, _vp, _vp, _vp, _P(C.c_int64)]),
+    "gpry_sweep_fetch": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     "gpry_sweep_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _P(C.c_int64),
                                   _P(C.c_double)]),
     "gpry_kb_reset": (C.c_int, [_vp]),
@@ -292,6 +293,16 @@ class Device:
             _ptr(out["y"]), _ptr(out["sigma"]), _ptr(out["acq"]), C.byref(n_nan)),
             "gpry_sweep_logexp")
         out["n_nan"] = n_nan.value
+        self.sweep_epoch = getattr(self, "sweep_epoch", 0) + 1    # the resident arrays changed
+        self._sweep_M = M
+        return out
+
+    def sweep_fetch(self, want=("y", "sigma")):
+        """Arrays of the last sweep that are still resident on the device."""
+        M = self._sweep_M
+        out = {k: (np.empty(M) if k in want else None) for k in ("y", "sigma", "acq")}
+        self._check(self._lib.gpry_sweep_fetch(self._h, M, _ptr(out["y"]), _ptr(out["sigma"]),
+                                               _ptr(out["acq"])), "gpry_sweep_fetch")
         return out
 
     def sweep_topk(self, Kp, exclude=None):

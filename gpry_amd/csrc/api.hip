@@ -476,6 +476,17 @@ int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgr
     return 0;
 }
 
+int gpry_sweep_fetch(gpry_ctx* ctx, int64_t M, double* y_all, double* sigma_all, double* acq_all) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (M <= 0 || M != ctx->sw_M) return gpry_fail(ctx, -1, "sweep_fetch: the resident sweep has %lld candidates, not %lld",
+                                                  (long long)ctx->sw_M, (long long)M);
+    if (y_all) HIP_TRY(ctx, hipMemcpyAsync(y_all, ctx->dy_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
+    if (sigma_all) HIP_TRY(ctx, hipMemcpyAsync(sigma_all, ctx->dsig_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
+    if (acq_all) HIP_TRY(ctx, hipMemcpyAsync(acq_all, ctx->dacq_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int gpry_set_gates(gpry_ctx* ctx, const double* sv, const double* coef, int64_t n_sv, double gamma,
                    double intercept, int positive_is_finite, const double* trust_bounds) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));

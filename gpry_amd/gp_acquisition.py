@@ -175,7 +175,7 @@ class NORA(GenericGPAcquisition):
         per = -(-M // w)
         return min(r * per, M), min((r + 1) * per, M)
 
-    def _device_sweep(self, gpr, X):
+    def _device_sweep(self, gpr, X, need_arrays=False):
         """Mean, std and LogExp acquisition of every row of X (this rank's shard on the
         device; y and sigma all-gathered so that every rank holds the full arrays)."""
         t0 = time()
@@ -197,7 +197,11 @@ class NORA(GenericGPAcquisition):
                     and (lo, hi) == (self._sweep_lo, self._sweep_hi))
         sharded = self.comm is not None and self.comm.world > 1
         gather = (self.mc_every > 1) if self.gather_y == "auto" else bool(self.gather_y)
-        want = ("y", "sigma") if (gather or not sharded) else ()
+        # one rank: y / sigma stay on the device and are fetched when somebody asks for them
+        # (last_MC_sample, a later reweighting) -- 16 MB of copies per 1e6 candidates otherwise
+        lazy = (not sharded and not need_arrays and self.gather_y == "auto"
+                and hasattr(gpr.device, "sweep_fetch"))
+        want = ("y", "sigma") if ((gather and sharded) or (not sharded and not lazy)) else ()
         out = gpr.device.sweep_logexp(None if resident else X[lo:hi], self.acq_func.zeta, gpr.y_max,
                                       noise, mask=mask, M=hi - lo, want=want)
         self._sweep_dev = gpr.device
@@ -215,6 +219,7 @@ class NORA(GenericGPAcquisition):
             else:
                 y = np.concatenate([allb[r, 0, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
                 s = np.concatenate([allb[r, 1, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
+        self._lazy = (gpr.device, gpr.device.sweep_epoch) if lazy else None
         self._sweep_X, self._sweep_lo, self._sweep_hi = X, lo, hi
         self.stats["sweep_s"] = time() - t0
         self.stats["sweep_M"] = M
@@ -255,6 +260,19 @@ class NORA(GenericGPAcquisition):
             valid[:] = True
         return merged[valid], (gbound if not exhausted else -np.inf), exhausted
 
+    def _fetch_lazy(self):
+        """Materialise ``_y_mc`` / ``_sigma_y_mc`` of the last (un-reweighted) sweep if they were
+        left on the device and are still there."""
+        lazy = getattr(self, "_lazy", None)
+        if lazy is None or self._y_mc is not None:
+            return
+        dev, epoch = lazy
+        if dev.sweep_epoch != epoch:
+            raise RuntimeError("the sweep arrays of the last MC sample are no longer on the device")
+        out = dev.sweep_fetch(("y", "sigma"))
+        self._y_mc, self._sigma_y_mc = out["y"], out["sigma"]
+        self._lazy = None
+
     def _set_MC_sample(self, X, y, sigma_y, w, ensure_y_sigma_y=False, gpr=None):
         """gp_acquisition.py:858-873; the (y, sigma) evaluation is the device sweep."""
         self.is_last_MC_reweighted = False
@@ -269,6 +287,8 @@ class NORA(GenericGPAcquisition):
 
     def _reweight_last_MC_sample(self, gpr, bounds=None, ensure_sigma_y=False):
         """gp_acquisition.py:875-919."""
+        if not self.is_last_MC_reweighted:
+            self._fetch_lazy()          # the old y is needed below; the new sweep overwrites it
         self.is_last_MC_reweighted = True
         if self._X_mc is None:
             raise ValueError("No samples yet!")
@@ -279,7 +299,7 @@ class NORA(GenericGPAcquisition):
         if bounds is not None:
             within = is_in_bounds(Xr, bounds, check_shape=False)
             Xr = Xr[within]
-        yr, sr = self._device_sweep(gpr, Xr)
+        yr, sr = self._device_sweep(gpr, Xr, need_arrays=True)
         with np.errstate(all="ignore"):
             y_old, w_old = self._y_mc, self._w_mc
             if within is not None:
@@ -301,6 +321,7 @@ class NORA(GenericGPAcquisition):
             vals = (self._X_mc_reweight, self._y_mc_reweight, self._sigma_y_mc_reweight,
                     self._w_mc_reweight)
         else:
+            self._fetch_lazy()
             vals = (self._X_mc, self._y_mc, self._sigma_y_mc, self._w_mc)
         if copy:
             vals = tuple(None if v is None else np.copy(v) for v in vals)

@@ -145,6 +145,10 @@ int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* 
                       double zeta, double baseline, double sigma_n,
                       double* y_all, double* sigma_all, double* acq_all,
                       int64_t* n_nan);
+/* Host copies of the arrays of the last gpry_sweep_logexp that are still resident on the device
+ * (any pointer may be NULL; M must be the size of that sweep).  Lets a caller skip the copies in
+ * gpry_sweep_logexp and fetch them only if somebody asks (NORA.last_MC_sample). */
+int gpry_sweep_fetch(gpry_ctx* ctx, int64_t M, double* y_all, double* sigma_all, double* acq_all);
 /* Shortlist of the last sweep: the Kp candidates with the largest acq in the total
  * order (acq desc, idx desc) -- the order of np.argsort(acq)[::-1] on distinct values
  * (gpry/gp_acquisition.py:1328-1329).  exclude (nullable, n_exclude sorted indices):

@@ -137,7 +137,15 @@ class OracleDevice:
         else:
             y, s = np.empty(0), np.empty(0)
         self.acq, self.y, self.s = orc.logexp_f(y, s, baseline, sigma_n, zeta), y, s
-        return {"y": y, "sigma": s, "acq": self.acq, "n_nan": int(np.isnan(self.acq).sum())}
+        self.sweep_epoch = getattr(self, "sweep_epoch", 0) + 1
+        self.n_fetch = getattr(self, "n_fetch", 0)
+        return {"y": y if "y" in want else None, "sigma": s if "sigma" in want else None,
+                "acq": self.acq if "acq" in want else None, "n_nan": int(np.isnan(self.acq).sum())}
+
+    def sweep_fetch(self, want=("y", "sigma")):
+        self.n_fetch += 1
+        src = {"y": self.y, "sigma": self.s, "acq": self.acq}
+        return {k: (src[k].copy() if k in want else None) for k in src}
 
     # -- Kriging believer (u(x) = V k*(x) kept per registered candidate) -------------------
     def kb_reset(self):

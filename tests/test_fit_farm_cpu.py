@@ -245,8 +245,51 @@ def test_nora_with_device_gates_equals_host_masks():
         acq = NORA(bounds, sampler="uniform", verbose=0)
         acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
         Xp, yp, ap = acq.multi_add(gpr, n_points=3, bounds=gpr.trust_bounds, rng=np.random.default_rng(0))
-        res.append((Xp, yp, ap, acq._y_mc.copy(), acq._sigma_y_mc.copy(), gpr.device))
+        _, y_mc, s_mc, _ = acq.last_MC_sample()
+        res.append((Xp, yp, ap, y_mc.copy(), s_mc.copy(), gpr.device))
     assert res[0][5].gates is not None and getattr(res[1][5], "gates", None) is None
     for a, b in zip(res[0][:5], res[1][:5]):
         np.testing.assert_array_equal(a, b)
     assert np.isneginf(res[0][3]).sum() > 0 and np.all(np.isfinite(res[0][1]))
+
+
+def test_pool_arrays_are_fetched_from_the_device_only_on_demand():
+    """One rank: NORA leaves y / sigma of the sweep on the device; ``last_MC_sample`` and a later
+    reweighting fetch them (gpry/gp_acquisition.py:875-919 needs the old y)."""
+    from gpry_amd.kernels import clone
+    from gpry_amd.gp_acquisition import NORA
+    from oracle import gpry_oracle as orc
+    bounds, X, y, Xc = orc.synthetic_like_goldens(80, 3, 600, seed=5)
+    gpr = make_gpr(bounds, 3)
+    k = clone(gpr.kernel)
+    k.theta = np.log(np.array([4.0, 0.3, 0.3, 0.3]))
+    gpr.kernel_, gpr._fitted = k, True
+    gpr.append_to_data(X, y, fit_gpr=False)
+    acq = NORA(bounds, sampler="uniform", mc_every=2, verbose=0)
+    acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+    Xp, yp, ap = acq.multi_add(gpr, n_points=2, rng=np.random.default_rng(0))
+    dev = gpr.device
+    assert dev.n_fetch == 0 and acq._y_mc is None                 # nothing copied so far
+    ref_y, ref_s = dev.y.copy(), dev.s.copy()
+    Xs, ys, ss, ws = acq.last_MC_sample()
+    assert dev.n_fetch == 1 and np.array_equal(ys, ref_y) and np.array_equal(ss, ref_s) and Xs is Xc
+    acq.last_MC_sample()
+    assert dev.n_fetch == 1                                         # cached after the first fetch
+    # same thing when the first consumer is the reweighting of the next call
+    acq2 = NORA(bounds, sampler="uniform", mc_every=2, verbose=0)
+    acq2.do_MC_sample = acq.do_MC_sample
+    acq2.multi_add(gpr, n_points=2, rng=np.random.default_rng(0))
+    n0 = dev.n_fetch
+    gpr.append_to_data(Xp, yp, fit_gpr=False)
+    acq2.multi_add(gpr, n_points=2, rng=np.random.default_rng(0))   # reweights: needs the old y
+    assert dev.n_fetch == n0 + 1 and acq2.is_last_MC_reweighted
+    ref = NORA(bounds, sampler="uniform", mc_every=2, verbose=0, gather_y=True)     # eager copies
+    ref.do_MC_sample = acq.do_MC_sample
+    gpr3 = make_gpr(bounds, 3)
+    gpr3.kernel_, gpr3._fitted = clone(k), True
+    gpr3.append_to_data(X, y, fit_gpr=False)
+    a1 = ref.multi_add(gpr3, n_points=2, rng=np.random.default_rng(0))
+    gpr3.append_to_data(a1[0], a1[1], fit_gpr=False)
+    a2 = ref.multi_add(gpr3, n_points=2, rng=np.random.default_rng(0))
+    np.testing.assert_array_equal(a1[0], Xp)
+    np.testing.assert_array_equal(a2[0], acq2._X_already_proposed[-2:])
