@@ -169,18 +169,19 @@ struct TrtriPlan {
     std::vector<GemmBatchItem*> d_t, d_v;   // per level
     std::vector<int> count, maxM, maxN;
 };
-static std::map<gpry_ctx*, TrtriPlan> g_plans;
-
+// the plan lives in its context (ctx->trtri_plan): distinct contexts may be driven from distinct threads
 void trtri_plan_free(gpry_ctx* ctx) {
-    auto it = g_plans.find(ctx);
-    if (it == g_plans.end()) return;
-    for (auto p : it->second.d_t) if (p) (void)hipFree(p);
-    for (auto p : it->second.d_v) if (p) (void)hipFree(p);
-    g_plans.erase(it);
+    TrtriPlan* pl = static_cast<TrtriPlan*>(ctx->trtri_plan);
+    if (!pl) return;
+    for (auto p : pl->d_t) if (p) (void)hipFree(p);
+    for (auto p : pl->d_v) if (p) (void)hipFree(p);
+    delete pl;
+    ctx->trtri_plan = nullptr;
 }
 
 static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
-    TrtriPlan& pl = g_plans[ctx];
+    if (!ctx->trtri_plan) ctx->trtri_plan = new TrtriPlan();
+    TrtriPlan& pl = *static_cast<TrtriPlan*>(ctx->trtri_plan);
     if (pl.Np == Np) { *out = &pl; return 0; }
     for (auto p : pl.d_t) if (p) (void)hipFree(p);
     for (auto p : pl.d_v) if (p) (void)hipFree(p);

@@ -110,6 +110,8 @@ struct gpry_ctx {
     double* dXkb = nullptr;    // kb_cap x dpad scaled candidate rows
     double* dkbout = nullptr;  // 2 * kb_cap
 
+    void* trtri_plan = nullptr;   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
+
     // host pinned staging
     void* hpin = nullptr; int64_t hpin_cap = 0;
 
