@@ -48,10 +48,11 @@ class LogExp(AcquisitionFunction):
 
     @staticmethod
     def f(mu, std, baseline, noise_level, zeta):
-        """Same operation order as the reference (square, subtract, clip, sqrt, log)."""
+        """Same operation order as the reference (square, subtract, clip at 0, sqrt, log);
+        ``np.maximum(x, 0.)`` is ``np.clip(x, 0., None)`` without its Python-level overhead."""
         with np.errstate(divide="ignore", invalid="ignore"):
             return (2 * zeta * (mu - baseline) +
-                    np.log(np.sqrt(np.clip(std ** 2. - noise_level ** 2., 0., None))))
+                    np.log(np.sqrt(np.maximum(std ** 2. - noise_level ** 2., 0.))))
 
     def __call__(self, X, gp, eval_gradient=False):
         """Value (and x-gradient, gpry/acquisition_functions.py:937-1009) at ``X``."""

@@ -576,7 +576,7 @@ class RankedPool:
             end = int(empties[0]) if len(empties) else len(self) + 1
             s_cond = upper.predict_std(self.X[slot:end], validate=False)
             ceiling = np.inf if slot == 0 else self.acq_cond[slot - 1]
-            a_cond = np.clip(self._acq_func(self.y[slot:end], s_cond), None, ceiling)
+            a_cond = np.minimum(self._acq_func(self.y[slot:end], s_cond), ceiling)
             rank = np.argsort(-a_cond)
             if a_cond[rank[0]] == -np.inf:
                 self.acq_cond[slot:end] = -np.inf

@@ -14,3 +14,4 @@ bench.main()
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats(45)
+st.sort_stats("tottime").print_stats("gpry_amd|numpy", 30)
