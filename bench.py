@@ -97,6 +97,32 @@ def cpu_baseline(N, d, M, n_points, lml_evals, cache_models, budget_s=40.0):
     }
 
 
+class _GlooComm:
+    """Same interface as gpry_amd._lib.RcclComm over torch.distributed/gloo: used by the bench only
+    if the RCCL communicator cannot be created (the exchanged shortlists are a few KB)."""
+
+    def __init__(self, dist, dev):
+        self._dist, self._dev = dist, dev
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def allgather(self, arr):
+        import torch
+        arr = np.ascontiguousarray(arr)
+        t = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy())
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(outs, t)
+        return np.stack([o.numpy().view(arr.dtype).reshape(arr.shape) for o in outs])
+
+    def allreduce_max(self, arr):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).copy())
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return t.numpy()
+
+    def barrier(self):
+        self._dist.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,12 +165,25 @@ def main():
     dev = gpr.device
     comm = None
     dist = None
+    comm_kind = "none"
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
         import torch.distributed as dist   # rendezvous only (CPU/gloo); the data path is RCCL
         dist.init_process_group("gloo")
-        box = [_lib.RcclComm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        comm = _lib.RcclComm(dev, world, rank, box[0])
+        comm_kind = "rccl"
+        try:
+            box = [_lib.RcclComm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = _lib.RcclComm(dev, world, rank, box[0])
+            ok = 1.0
+        except Exception as e:      # keep the run alive: the exchange is a few KB per cycle
+            print(f"bench.py[{rank}]: RCCL communicator failed ({e!r}); using gloo for the shortlist "
+                  f"exchange", file=sys.stderr)
+            ok = 0.0
+        import torch
+        flag = torch.tensor([ok])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks must agree on the transport
+        if float(flag[0]) < 1.0:
+            comm, comm_kind = _GlooComm(dist, dev), "gloo-fallback"
 
     acq = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=comm)
     acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
@@ -224,7 +263,8 @@ def main():
         "config": {"workload": "BASELINE configs[2]: 16-d correlated-Gaussian posterior, N_train=4096, "
                                "Matern-5/2, LogExp NORA sweep M=1e6, n_points=16, fit_gpr='simple'",
                    "N_train": N, "d": d, "M_total": M_total, "M_per_gpu": M_rank, "n_points": npts,
-                   "kernel": "ConstantKernel*Matern(nu=2.5)", "sharding": f"candidates x{world}"},
+                   "kernel": "ConstantKernel*Matern(nu=2.5)", "sharding": f"candidates x{world}",
+                   "comm": comm_kind},
         "cycle": {"refit_plus_acq_ms": ms_per_step, "refit_ms": host_t["refit"] / K * 1e3,
                   "acquisition_ms": host_t["acq"] / K * 1e3,
                   "one_lml_grad_call_ms": (per_step_ms["kernel_build"] + per_step_ms["potrf"] + per_step_ms["trtri"] +
