@@ -43,6 +43,26 @@ __device__ __forceinline__ void tile_store(double* T, v4d v, int lane) {
     for (int q = 0; q < 4; q++) T[(g + 4 * q) * PLD + r] = v[q];
 }
 
+// broadcast of a double from a lane known at compile time: two v_readlane_b32 (a few cycles)
+// instead of a ds_bpermute round trip through the LDS crossbar
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(x) for a positive, normal x: v_rsq_f64 (~26 good bits) + two Newton steps.  The libm
+// rsqrt is a sqrt followed by a division -- ~250 cycles on the 16-step pivot chain.
+__device__ __forceinline__ double pivot_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+    e = fma(-x * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+    return r;
+}
+
 // Cholesky of the 16x16 block at S (LDS, stride PLD) by one full wave: lane (i, cq) keeps
 // S[i][4cq .. 4cq+3] in registers; column j is finished with three shuffles per lane.
 // Writes L (lower, zeros above).  Returns the first failing column + 1 (0 if ok).
@@ -55,18 +75,26 @@ __device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int jq = j >> 2, jj = j & 3;
-        double sij = __shfl(x[jj], i + 16 * jq);      // S[i][j]
-        double djj = __shfl(x[jj], j + 16 * jq);      // S[j][j]
+        // Per column the dependency chain is: pivot (v_readlane, a few cycles) -> 1/sqrt (v_rsq + 2
+        // Newton steps, ~90 cycles) running next to ONE round of five independent ds_bpermute
+        // broadcasts of the raw column (their scaling by the reciprocal pivot happens afterwards).
+        // Section stamps (tools/panel_sections.py): the version with the pivot through a shuffle
+        // and libm's rsqrt (= sqrt + divide) on the chain took 6.7k cycles per 16x16 block.
+        const double djj = readlane_f64(x[jj], j + 16 * jq);   // S[j][j]
+        const double sij = __shfl(x[jj], i + 16 * jq);         // S[i][j]
+        double scj[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) scj[cc] = __shfl(x[jj], cq * 4 + cc + 16 * jq);   // S[c][j]
         if (!(djj > 0.0) && bad == 0) bad = j + 1;    // dpotf2: ajj <= 0 or NaN
-        // reciprocal pivot first (one rsqrt instead of sqrt + divide on the critical path);
-        // dpotf2 likewise scales the column by 1/ajj
-        double rinv = rsqrt(djj);
+        // reciprocal pivot (dpotf2 likewise scales the column by 1/ajj)
+        const double rinv = pivot_rsqrt(djj);
         double piv = djj * rinv;
-        double lij = sij * rinv;
+        piv = fma(fma(-piv, piv, djj), 0.5 * rinv, piv);   // one Newton step: sqrt to the last bit (off the chain)
+        const double lij = sij * rinv;
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
             const int c = cq * 4 + cc;
-            double lcj = __shfl(x[jj], c + 16 * jq) * rinv;   // L[c][j]
+            const double lcj = scj[cc] * rinv;         // L[c][j]
             if (c > j) x[cc] = fma(-lij, lcj, x[cc]);
         }
         if (cq == jq) x[jj] = (i == j) ? piv : (i > j ? lij : 0.0);
@@ -84,12 +112,39 @@ __device__ __forceinline__ void trsm16_rows(double* Xr, const double* L, const d
     double x[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = Xr[i * PLD + c];
+    // The factor entries are the same for every lane (broadcast LDS reads) and do not depend on x:
+    // they are fetched in two batches (columns 0..7: 92 values, columns 8..15: 28 values) BEFORE
+    // the substitution steps that use them, so the 16-step dependency chain is mul + fma only
+    // (with the reads inside the chain every step paid an LDS round trip: 3.0k cycles per call).
+    {
+        double l[8][16], r8[8];
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-        // axpy form: the 15-c updates of a step are independent (short dependency chain)
-        x[c] = x[c] * rd[c];
+        for (int c = 0; c < 8; c++) {
+            r8[c] = rd[c];
 #pragma unroll
-        for (int c2 = c + 1; c2 < 16; c2++) x[c2] = fma(-x[c], L[c2 * PLD + c], x[c2]);
+            for (int c2 = c + 1; c2 < 16; c2++) l[c][c2] = L[c2 * PLD + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            x[c] = x[c] * r8[c];
+#pragma unroll
+            for (int c2 = c + 1; c2 < 16; c2++) x[c2] = fma(-x[c], l[c][c2], x[c2]);
+        }
+    }
+    {
+        double l[8][16], r8[8];
+#pragma unroll
+        for (int c = 8; c < 16; c++) {
+            r8[c - 8] = rd[c];
+#pragma unroll
+            for (int c2 = c + 1; c2 < 16; c2++) l[c - 8][c2] = L[c2 * PLD + c];
+        }
+#pragma unroll
+        for (int c = 8; c < 16; c++) {
+            x[c] = x[c] * r8[c - 8];
+#pragma unroll
+            for (int c2 = c + 1; c2 < 16; c2++) x[c2] = fma(-x[c], l[c - 8][c2], x[c2]);
+        }
     }
     if (lane < 16) {
 #pragma unroll
@@ -122,7 +177,8 @@ __device__ __forceinline__ void store_block(double* __restrict__ G, int64_t ld, 
 // starting before the first one finishes -- not true when another stream shares the GPU.
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int64_t ld, int64_t j0,
                                                          int64_t K0, int64_t n_real, int* info,
-                                                         int* arrive, int target) {
+                                                         int* arrive, int target,
+                                                         unsigned long long* dbg, int dbg_block) {
     __shared__ __attribute__((aligned(16))) double sD[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sB[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sPt[64 * PLD];
@@ -132,6 +188,10 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
     if (*info != 0) return;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const bool is_diag = blockIdx.x == 0;
+    // optional section stamps of one workgroup (dbg != NULL): loads, update, factor, solve, store
+    const bool stamp = dbg != nullptr && (int)blockIdx.x == dbg_block && t == 0;
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if (stamp) ts[0] = __builtin_amdgcn_s_memtime();
     const int64_t R = j0 + 64 * (int64_t)blockIdx.x;
     const int kprev = (int)(j0 - K0);          // 0 or 64
     if (t == 0) s_bad = 0;
@@ -142,6 +202,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
         if (!is_diag) load_block(A + R * ld + K0, ld, sPo, t);
     }
     __syncthreads();
+    if (stamp) ts[1] = __builtin_amdgcn_s_memtime();
     if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- left-looking update with the previous 64 columns of the outer panel
     if (kprev) {
@@ -160,16 +221,25 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
         }
     }
     __syncthreads();
+    if (stamp) ts[2] = __builtin_amdgcn_s_memtime();
     // ---- Cholesky of the 64x64 diagonal block, blocked by 16 (wave w owns row strip w)
+    // dbg_block == -2: stamps inside the factor (thread 0 of the diagonal workgroup): time from the
+    // loop top to the barrier after chol16 / after the solves / after the MFMA updates
+    const bool stamp2 = dbg != nullptr && dbg_block == -2 && blockIdx.x == 0 && t == 0;
+    unsigned long long f_chol = 0, f_trsm = 0, f_upd = 0;
     for (int cb = 0; cb < 4; cb++) {
+        unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (stamp2) q0 = __builtin_amdgcn_s_memtime();
         if (w == cb) {
             int bad = chol16_wave(sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
             if (bad && lane == 0) s_bad = cb * 16 + bad;
         }
         __syncthreads();
+        if (stamp2) q1 = __builtin_amdgcn_s_memtime();
         if (s_bad) break;
         if (w > cb) trsm16_rows(sD + (w * 16) * PLD + cb * 16, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
         __syncthreads();
+        if (stamp2) q2 = __builtin_amdgcn_s_memtime();
         if (w > cb) {
             for (int cc = cb + 1; cc <= w; cc++) {
                 double* T = sD + (w * 16) * PLD + cc * 16;
@@ -179,6 +249,15 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
             }
             wave_fence();
         }
+        if (dbg != nullptr && dbg_block == -2) __syncthreads();   // uniform: measurement build only
+        if (stamp2) {
+            q3 = __builtin_amdgcn_s_memtime();
+            f_chol += q1 - q0; f_trsm += q2 - q1; f_upd += q3 - q2;
+        }
+    }
+    if (stamp2) {
+        atomicAdd(&dbg[0], f_chol); atomicAdd(&dbg[1], f_trsm); atomicAdd(&dbg[2], f_upd);
+        atomicAdd(&dbg[5], 1ull);
     }
     if (s_bad) {
         if (is_diag && t == 0) {
@@ -187,12 +266,19 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
         }
         return;
     }
+    if (stamp) ts[3] = __builtin_amdgcn_s_memtime();
     if (is_diag) {
         if (t == 0)
             while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
                 __builtin_amdgcn_s_sleep(8);
         __syncthreads();
+        if (stamp) ts[4] = __builtin_amdgcn_s_memtime();
         store_block(A + j0 * ld + j0, ld, sD, t, true);
+        if (stamp) {
+            ts[5] = __builtin_amdgcn_s_memtime();
+            for (int i = 0; i < 5; i++) atomicAdd(&dbg[i], ts[i + 1] - ts[i]);
+            atomicAdd(&dbg[5], 1ull);
+        }
         return;
     }
     // ---- X = B Lkk^-T, wave w solves its own 16-row strip (no workgroup barriers needed)
@@ -208,7 +294,13 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
         wave_fence();
     }
     __syncthreads();
+    if (stamp) ts[4] = __builtin_amdgcn_s_memtime();
     store_block(A + R * ld + j0, ld, sB, t, false);
+    if (stamp) {
+        ts[5] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 5; i++) atomicAdd(&dbg[i], ts[i + 1] - ts[i]);
+        atomicAdd(&dbg[5], 1ull);
+    }
 }
 
 // A = L L^T in place (lower; the strict upper triangle is left untouched).  Outer blocks of
@@ -251,8 +343,10 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
         for (int64_t j0 = K0; j0 < K0 + 128; j0 += 64) {
             unsigned nblk = (unsigned)((Np - j0) / 64);
             arrivals += (int)nblk;
+            unsigned long long* dbg = nullptr;
+            if (ctx->opt_chol_dbg) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); dbg = ctx->dsel + 16; }
             hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), 0, st, A, Np, j0, K0, ctx->N, ctx->dinfo,
-                               ctx->dinfo + 2, arrivals);
+                               ctx->dinfo + 2, arrivals, dbg, ctx->opt_chol_dbg - 1);
         }
         const int64_t r0 = K0 + 128;
         if (r0 >= Np) break;
