@@ -25,3 +25,12 @@ def test_random_operation_sequences_on_the_host_mirror():
     import fuzz_mirror
     bad, worst = fuzz_mirror.run(n_seq=12, seed=42)
     assert bad == 0, worst
+
+
+def test_random_gated_models_device_gates_equal_host_masks():
+    """tools/fuzz_gates.py: random -inf half-spaces (SVM) and trust regions; NORA with the gates on
+    the device equals NORA with libsvm + numpy masks."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_gates
+    bad, n_inf = fuzz_gates.run(n_cases=20, seed=5)
+    assert bad == 0 and n_inf > 1000
