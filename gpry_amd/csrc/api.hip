@@ -884,7 +884,12 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
     g.A = dA; g.lda = a_trans ? M : K;
     g.B = dB; g.ldb = b_trans ? K : N;
     g.C = dC; g.ldc = N;
-    g.M = M; g.N = N; g.K = K; g.kmode = kmode; g.lower_only = lower_only; g.tile_map = tile_map;
+    g.M = M; g.N = N; g.K = K; g.kmode = kmode; g.lower_only = lower_only; g.tile_map = tile_map & 0xff;
+    const int nsplit = (tile_map >> 8) & 15;      // test hook: bits 8..11 of tile_map = split-K factor
+    if (nsplit > 1) {
+        GPRY_TRY(gemm_split_scratch(ctx, nsplit, (int64_t)crow * N, &g.split_buf));
+        g.nsplit = nsplit; g.split_stride = (int64_t)crow * N;
+    }
     {
         StageScope s(ctx, "debug_gemm");
         GPRY_TRY(gemm_f64_launch(ctx, g, a_trans != 0, b_trans != 0, epi));

@@ -97,6 +97,9 @@ struct gpry_ctx {
     int64_t kst_cap = 0;       // doubles allocated
     double* dG = nullptr;      // Np x dpad: d k(x, X_j)/dx of the last gpry_predict_grad
     int64_t g_cap = 0;
+    double* dsplit = nullptr;  // split-K partial products of the factor GEMMs
+    int64_t split_cap = 0;
+    int opt_split_k = 1;       // split-K for launches with fewer tiles than slots (trtri top levels, lauum)
     double* dpart = nullptr;   // partial sums (sumsq per i-tile, mean per j-chunk)
     int64_t part_cap = 0;
     // top-k scratch
@@ -181,9 +184,12 @@ struct GemmArgs {
     int* sched;            // persistent sweep kernel: one ticket counter per XCD
     int persist;           // sweep_gemm_dma_sp: resident workgroups pulling tiles from g.sched
     hipStream_t stream;    // null: ctx->stream
+    int nsplit;            // > 1: split-K over grid.y into split_buf (store epilogues only), then reduced
+    double* split_buf; int64_t split_stride;
 };
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
+int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
 int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g);   // sweep_gemm.hip (LDS-DMA staging)
 int sweep_gemm_dma256_launch(gpry_ctx* ctx, const GemmArgs& g);  // 128x256 tile, 8 waves, 3-stage ring
 int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g);  // variant 1 + explicit software pipeline

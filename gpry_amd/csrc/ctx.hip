@@ -165,7 +165,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
                     ctx->dsig_all, ctx->dacq_all, ctx->dKst, ctx->dpart, ctx->dkeys, ctx->dhist,
                     ctx->dcand, ctx->dsel, ctx->dU, ctx->dXkb, ctx->dkbout, ctx->pr.dXc, ctx->pr.dmask,
                     ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq, ctx->dsched, ctx->dG,
-                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust};
+                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     (void)hipStreamDestroy(ctx->stream);
@@ -196,6 +196,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "sweep_overlap")) { ctx->opt_sweep_overlap = (int)value; return 0; }
     if (!strcmp(key, "chol_lookahead")) { ctx->opt_chol_lookahead = (int)value; return 0; }
     if (!strcmp(key, "chol_dbg")) { ctx->opt_chol_dbg = (int)value; return 0; }
+    if (!strcmp(key, "split_k")) { ctx->opt_split_k = (int)value; return 0; }
     if (!strcmp(key, "predict_small")) { ctx->opt_predict_small = (int64_t)value; return 0; }
     if (!strcmp(key, "lml_cache")) { ctx->opt_lml_cache = (int)value; ctx->lml_cache = false; return 0; }
     if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }

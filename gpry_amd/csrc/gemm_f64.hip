@@ -111,7 +111,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     else if (g.kmode == KM_B_LOWER) kbeg = min(K, col0);
     else if (g.kmode == KM_AT_LOWER_B_LOWER) kbeg = min(K, max(row0, col0));
     else if (g.kmode == KM_B_UPPER) kend = min(K, col0 + BN);
-    const int nslab = (kend - kbeg + BK - 1) / BK;
+    // split-K (grid.y = g.nsplit > 1): this workgroup takes a contiguous share of the tile's slabs and
+    // stores its partial product (EPI_STORE) into slice blockIdx.y of g.split_buf; the reduce kernel
+    // below adds the slices in a fixed order and applies the sign.  Shortens the critical path of
+    // launches that have fewer tiles than the GPU has slots (V = L^-1 top levels, K^-1 = V^T V).
+    if (g.nsplit > 1) {
+        const int all = (kend - kbeg + BK - 1) / BK;
+        const int per = (all + g.nsplit - 1) / g.nsplit;
+        const int lo = min(all, (int)blockIdx.y * per), hi = min(all, lo + per);
+        kend = min(kend, kbeg + hi * BK);
+        kbeg = kbeg + lo * BK;
+        C = g.split_buf + (int64_t)blockIdx.y * g.split_stride + (C - g.C);
+    }
+    const int nslab = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
     // Tiles that share a V row-panel or a K* column-panel start at different slabs so that
     // one of them fetches a line and the others find it in L2 (simultaneous misses are not merged).
     const int krot = (g.kskew > 0 && nslab > 0) ? (((tc.ti + tc.tj) & 7) * g.kskew) % nslab : 0;
@@ -239,11 +251,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 if (row < M && col < N) {
                     double* p = C + (int64_t)row * g.ldc + col;
                     double v = acc[mi][ni][q];
-                    if (EPI == EPI_STORE) *p = v;
+                    if (EPI == EPI_STORE || g.nsplit > 1) *p = v;
                     else if (EPI == EPI_STORE_NEG) *p = -v;
                     else *p = *p - v;
                 }
             }
+}
+
+// C = sign * sum over the split-K slices, same tile map / batch / lower_only logic as the product
+// kernel (one workgroup per output tile, 256 threads, 16-byte accesses).
+__global__ __launch_bounds__(256) void gemm_split_reduce_kernel(GemmArgs g, double sign) {
+    if (g.info != nullptr && *g.info != 0) return;
+    double* C = g.C;
+    int M = g.M, N = g.N;
+    int64_t coff = 0;
+    if (g.batch != nullptr) {
+        GemmBatchItem it = g.batch[blockIdx.z];
+        coff = it.c_off; M = it.M; N = it.N;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    TileCoord tc = map_tile(g, tiles_m, tiles_n);
+    if (!tc.valid) return;
+    const int row0 = tc.ti * BM, col0 = tc.tj * BN;
+    for (int e = threadIdx.x; e < BM * (BN / 2); e += 256) {
+        const int rr = e / (BN / 2), cc = (e - rr * (BN / 2)) * 2;
+        const int row = row0 + rr, col = col0 + cc;
+        if (row >= M || col >= N) continue;
+        const int64_t off = coff + (int64_t)row * g.ldc + col;
+        double2 acc = make_double2(0.0, 0.0);
+        for (int sidx = 0; sidx < g.nsplit; sidx++) {
+            const double2 v = *reinterpret_cast<const double2*>(g.split_buf + (int64_t)sidx * g.split_stride + off);
+            acc.x += v.x; acc.y += v.y;
+        }
+        *reinterpret_cast<double2*>(C + off) = make_double2(sign * acc.x, sign * acc.y);
+    }
 }
 
 template <bool AT, bool BT>
@@ -276,9 +317,31 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
     } else {
         nblk = (int64_t)tiles_m * tiles_n;
     }
-    dim3 grid((unsigned)nblk, 1, g.batch ? (unsigned)g.n_batch : 1u);
-    if (!a_trans && !b_trans) return launch_epi<false, false>(ctx, g, epi, grid);
-    if (!a_trans && b_trans) return launch_epi<false, true>(ctx, g, epi, grid);
-    if (a_trans && !b_trans) return launch_epi<true, false>(ctx, g, epi, grid);
-    return launch_epi<true, true>(ctx, g, epi, grid);
+    dim3 grid((unsigned)nblk, (unsigned)(g.nsplit > 1 ? g.nsplit : 1), g.batch ? (unsigned)g.n_batch : 1u);
+    if (g.nsplit > 1 && !(epi == EPI_STORE || epi == EPI_STORE_NEG))
+        return gpry_fail(ctx, -1, "gemm: split-K only with the store epilogues");
+    int rc;
+    if (!a_trans && !b_trans) rc = launch_epi<false, false>(ctx, g, epi, grid);
+    else if (!a_trans && b_trans) rc = launch_epi<false, true>(ctx, g, epi, grid);
+    else if (a_trans && !b_trans) rc = launch_epi<true, false>(ctx, g, epi, grid);
+    else rc = launch_epi<true, true>(ctx, g, epi, grid);
+    if (rc != 0 || g.nsplit <= 1) return rc;
+    dim3 rgrid((unsigned)nblk, 1, g.batch ? (unsigned)g.n_batch : 1u);
+    hipLaunchKernelGGL(gemm_split_reduce_kernel, rgrid, dim3(256), 0, g.stream ? g.stream : ctx->stream, g,
+                       epi == EPI_STORE_NEG ? -1.0 : 1.0);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// scratch for split-K partial products: nsplit slices of `slice` doubles each
+int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf) {
+    const int64_t need = (int64_t)nsplit * slice;
+    if (need > ctx->split_cap) {
+        if (ctx->dsplit) GPRY_TRY(dev_free(ctx, ctx->dsplit));
+        ctx->dsplit = nullptr; ctx->split_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dsplit, need));
+        ctx->split_cap = need;
+    }
+    *buf = ctx->dsplit;
+    return 0;
 }
