@@ -26,7 +26,7 @@ def run(n_cases=60, seed=0, dev=None):
 def _one_case(case, rng, dev, worst):
     bad = 0
     if True:
-        N = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 383, 500, 640, 777]))
+        N = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 383, 500, 640, 777, 1024, 1300, 2048]))
         d = int(rng.integers(1, 33))
         M = int(rng.choice([1, 2, 15, 16, 17, 100, 128, 129, 1000, 3000]))
         kid = int(rng.integers(0, 4))
