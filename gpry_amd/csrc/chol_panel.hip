@@ -152,11 +152,21 @@ __device__ __forceinline__ void trsm16_rows(double* Xr, const double* L, const d
     }
 }
 
-__device__ __forceinline__ void load_block(const double* __restrict__ G, int64_t ld, double* S, int t) {
-    for (int e = t; e < 64 * 32; e += 256) {
-        int row = e >> 5, c2 = (e & 31) * 2;
-        double2 v = *reinterpret_cast<const double2*>(G + (int64_t)row * ld + c2);
-        *reinterpret_cast<double2*>(S + row * PLD + c2) = v;
+// 64x64 block global -> LDS in two phases: all eight 16-byte loads of a thread are in flight before
+// the first LDS store (a load/store pair per iteration paid one memory round trip each: the four
+// blocks of a panel step cost 13k cycles that way)
+__device__ __forceinline__ void load_block_issue(const double* __restrict__ G, int64_t ld, int t, double2 (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int e = t + 256 * i, row = e >> 5, c2 = (e & 31) * 2;
+        r[i] = *reinterpret_cast<const double2*>(G + (int64_t)row * ld + c2);
+    }
+}
+__device__ __forceinline__ void load_block_commit(double* S, int t, const double2 (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int e = t + 256 * i, row = e >> 5, c2 = (e & 31) * 2;
+        *reinterpret_cast<double2*>(S + row * PLD + c2) = r[i];
     }
 }
 __device__ __forceinline__ void store_block(double* __restrict__ G, int64_t ld, const double* S, int t,
@@ -195,11 +205,20 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
     const int64_t R = j0 + 64 * (int64_t)blockIdx.x;
     const int kprev = (int)(j0 - K0);          // 0 or 64
     if (t == 0) s_bad = 0;
-    load_block(A + j0 * ld + j0, ld, sD, t);
-    if (!is_diag) load_block(A + R * ld + j0, ld, sB, t);
-    if (kprev) {
-        load_block(A + j0 * ld + K0, ld, sPt, t);
-        if (!is_diag) load_block(A + R * ld + K0, ld, sPo, t);
+    {
+        double2 rD[8], rB[8], rPt[8], rPo[8];
+        load_block_issue(A + j0 * ld + j0, ld, t, rD);
+        if (!is_diag) load_block_issue(A + R * ld + j0, ld, t, rB);
+        if (kprev) {
+            load_block_issue(A + j0 * ld + K0, ld, t, rPt);
+            if (!is_diag) load_block_issue(A + R * ld + K0, ld, t, rPo);
+        }
+        load_block_commit(sD, t, rD);
+        if (!is_diag) load_block_commit(sB, t, rB);
+        if (kprev) {
+            load_block_commit(sPt, t, rPt);
+            if (!is_diag) load_block_commit(sPo, t, rPo);
+        }
     }
     __syncthreads();
     if (stamp) ts[1] = __builtin_amdgcn_s_memtime();
