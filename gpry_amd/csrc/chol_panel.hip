@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
     if (stamp) ts[0] = __builtin_amdgcn_s_memtime();
     const int64_t R = j0 + 64 * (int64_t)blockIdx.x;
-    const int kprev = (int)(j0 - K0);          // 0 or 64
+    const int kprev = (int)(j0 - K0);          // columns of the outer block already factorised: 0, 64, 128, ...
     if (t == 0) s_bad = 0;
     {
         double2 rD[8], rB[8], rPt[8], rPo[8];
@@ -222,9 +222,18 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
     }
     __syncthreads();
     if (stamp) ts[1] = __builtin_amdgcn_s_memtime();
-    if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- left-looking update with the previous 64 columns of the outer panel
-    if (kprev) {
+    // ---- left-looking update with the previous columns of the outer block, 64 at a time (the first
+    // chunk came in with the loads above; an outer block of 256 columns has up to three)
+    for (int c0 = 0; c0 < kprev; c0 += 64) {
+        if (c0) {
+            __syncthreads();                       // everybody is done with the previous chunk
+            double2 rPt[8], rPo[8];
+            load_block_issue(A + j0 * ld + K0 + c0, ld, t, rPt);
+            if (!is_diag) load_block_issue(A + R * ld + K0 + c0, ld, t, rPo);
+            load_block_commit(sPt, t, rPt);
+            if (!is_diag) load_block_commit(sPo, t, rPo);
+            __syncthreads();
+        }
 #pragma unroll
         for (int n = 0; n < 4; n++) {
             double* T = sD + (w * 16) * PLD + n * 16;
@@ -239,6 +248,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
             }
         }
     }
+    if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (stamp) ts[2] = __builtin_amdgcn_s_memtime();
     // ---- Cholesky of the 64x64 diagonal block, blocked by 16 (wave w owns row strip w)
@@ -327,13 +337,13 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
 // Trailing update C -= P P^T (lower tiles only) of the rows/cols [r0, Np) x [c0, c0 + nc) with the
 // 128-column panel P = A[:, K0:K0+128].
 static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int64_t r0, int64_t c0,
-                           int64_t nc, hipStream_t st) {
+                           int64_t nc, hipStream_t st, int kdepth = 128) {
     if (r0 >= Np || nc <= 0) return 0;
     GemmArgs g = {};
     g.A = A + r0 * Np + K0; g.lda = Np;
     g.B = A + c0 * Np + K0; g.ldb = Np;
     g.C = A + r0 * Np + c0; g.ldc = Np;
-    g.M = (int)(Np - r0); g.N = (int)nc; g.K = 128;
+    g.M = (int)(Np - r0); g.N = (int)nc; g.K = kdepth;
     g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo; g.stream = st;
     return gemm_f64_launch(ctx, g, false, true, EPI_SUB);
 }
@@ -346,7 +356,12 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
     // updated on the main stream; the rest of the update runs on stream2 underneath panel k+1
     // (the panel chain is latency-bound and leaves the machine empty).  Every element still
     // receives its rank-128 updates in the same order from the same kernel: bit-identical.
+    // Outer block: the trailing matrix is read and written once per outer block, and a trailing update
+    // costs >= 40 us however small it is, so wider blocks halve both; the panel steps pay for it with
+    // up to three extra 64-column chunks in their left-looking update.  256 from Np = 1024 on
+    // (measured, tools/prof_factor.py); the look-ahead schedule keeps 128.
     const bool la = ctx->opt_chol_lookahead && ctx->stream2 != nullptr && Np > 512;
+    const int64_t OB = la ? 128 : (ctx->opt_chol_outer > 0 ? ctx->opt_chol_outer : (Np >= 1024 ? 256 : 128));
     bool rest_pending = false;
     if (la) {
         const size_t need = 2 * (size_t)(Np / 128);
@@ -358,8 +373,9 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
     }
     int step = 0;
     hipEvent_t ev_rest_prev = nullptr;
-    for (int64_t K0 = 0; K0 < Np; K0 += 128, step++) {
-        for (int64_t j0 = K0; j0 < K0 + 128; j0 += 64) {
+    for (int64_t K0 = 0; K0 < Np; K0 += OB, step++) {
+        const int64_t ob = (Np - K0 < OB) ? Np - K0 : OB;
+        for (int64_t j0 = K0; j0 < K0 + ob; j0 += 64) {
             unsigned nblk = (unsigned)((Np - j0) / 64);
             arrivals += (int)nblk;
             unsigned long long* dbg = nullptr;
@@ -367,10 +383,10 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
             hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), 0, st, A, Np, j0, K0, ctx->N, ctx->dinfo,
                                ctx->dinfo + 2, arrivals, dbg, ctx->opt_chol_dbg - 1);
         }
-        const int64_t r0 = K0 + 128;
+        const int64_t r0 = K0 + ob;
         if (r0 >= Np) break;
         if (!la) {
-            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0, r0, Np - r0, st));
+            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0, r0, Np - r0, st, (int)ob));
             continue;
         }
         hipEvent_t ev_panel = ctx->ev_pool[2 * step], ev_rest = ctx->ev_pool[2 * step + 1];

@@ -44,6 +44,7 @@ struct gpry_ctx {
     int opt_sweep_overlap = 0;   // 1: build the panel of chunk c+1 on a second stream while chunk c is contracted (measured: slower, the co-running cross_build costs the contraction +10 %)
     int opt_sweep_persist = 0;   // 1: persistent workgroups + per-XCD tile tickets (sweep_dma=3 only)
     int64_t opt_predict_small = 2048;  // mean-only gpry_predict of at most this many points: one fused launch
+    int opt_chol_outer = 0;      // outer block of the fused Cholesky (0: automatic, else 128 / 256 / ...)
     int opt_chol_dbg = 0;        // k > 0: section stamps of workgroup k-1 of every panel step (read_diag)
     int opt_chol_lookahead = 0;  // 1: trailing update of the next panel's columns first, the rest on stream2
                                  // (bit-identical; 4.50 vs 4.14 ms at N=4096: cross-stream events cost more than the overlap saves)

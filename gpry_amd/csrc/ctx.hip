@@ -196,6 +196,10 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "sweep_overlap")) { ctx->opt_sweep_overlap = (int)value; return 0; }
     if (!strcmp(key, "chol_lookahead")) { ctx->opt_chol_lookahead = (int)value; return 0; }
     if (!strcmp(key, "chol_dbg")) { ctx->opt_chol_dbg = (int)value; return 0; }
+    if (!strcmp(key, "chol_outer")) {
+        if (value != 0 && (value < 128 || ((int)value % 64))) return gpry_fail(ctx, -1, "chol_outer must be 0 or a multiple of 64 >= 128");
+        ctx->opt_chol_outer = (int)value; return 0;
+    }
     if (!strcmp(key, "split_k")) { ctx->opt_split_k = (int)value; return 0; }
     if (!strcmp(key, "predict_small")) { ctx->opt_predict_small = (int64_t)value; return 0; }
     if (!strcmp(key, "lml_cache")) { ctx->opt_lml_cache = (int)value; ctx->lml_cache = false; return 0; }

@@ -324,6 +324,7 @@ def test_cholesky_with_concurrent_trailing_update_is_bit_identical(dev):
     dev.set_train(X, rng.standard_normal(N), np.full(N, 1e-4))
     dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
     try:
+        dev.set_option("chol_outer", 128)          # same blocking on both sides (the default is 256 here)
         dev.set_option("chol_lookahead", 0)
         assert dev.factorize() == 0
         L0 = np.tril(dev.get_factor(want_V=False, want_alpha=False)[0])
@@ -334,6 +335,7 @@ def test_cholesky_with_concurrent_trailing_update_is_bit_identical(dev):
             assert np.array_equal(L0, L1)
     finally:
         dev.set_option("chol_lookahead", 0)
+        dev.set_option("chol_outer", 0)
 
 
 def test_factorize_adopts_the_factor_of_the_last_lml_evaluation(dev):
