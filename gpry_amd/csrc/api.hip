@@ -386,9 +386,10 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         const int64_t xb = round_up(sizeof(double) * M * ctx->d, 256);
         GPRY_TRY(ensure_pinned(ctx, xb + sizeof(double) * M * nsplit));
         char* h = (char*)ctx->hpin;
+        char* hd = (char*)ctx->hpin_dev;           // the same buffer as the device sees it
         memcpy(h, X, sizeof(double) * M * ctx->d);
         double* hp = (double*)(h + xb);
-        GPRY_TRY(launch_predict_mean_small(ctx, (const double*)h, M, nsplit, hp));
+        GPRY_TRY(launch_predict_mean_small(ctx, (const double*)hd, M, nsplit, (double*)(hd + xb)));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         for (int64_t m = 0; m < M; m++) {
             double mu_ = 0.0;
@@ -412,10 +413,12 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
             ctx->g_cap = 16 * Np;
         }
         char* h = (char*)ctx->hpin;
+        char* hd = (char*)ctx->hpin_dev;           // the same buffer as the device sees it
         memcpy(h, X, sizeof(double) * M * ctx->d);
         double* hm = (double*)(h + xb);
         double* hs = hm + M * nmb;
-        GPRY_TRY(launch_predict_small_std(ctx, (const double*)h, (int)M, ctx->dG, hm, hs));
+        GPRY_TRY(launch_predict_small_std(ctx, (const double*)hd, (int)M, ctx->dG, (double*)(hd + xb),
+                                          (double*)(hd + xb) + M * nmb));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const double C = exp(ctx->theta[0]);
         for (int64_t m = 0; m < M; m++) {

@@ -118,7 +118,7 @@ struct gpry_ctx {
     void* trtri_plan = nullptr;   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
 
     // host pinned staging
-    void* hpin = nullptr; int64_t hpin_cap = 0;
+    void* hpin = nullptr; void* hpin_dev = nullptr; int64_t hpin_cap = 0;   // host / device view of the same buffer
 
     std::map<std::string, StageTimer> timers;
 };

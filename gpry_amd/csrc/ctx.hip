@@ -64,8 +64,10 @@ void timers_collect(gpry_ctx* ctx) {
 int ensure_pinned(gpry_ctx* ctx, int64_t bytes) {
     if (bytes <= ctx->hpin_cap) return 0;
     if (ctx->hpin) HIP_TRY(ctx, hipHostFree(ctx->hpin));
-    ctx->hpin = nullptr; ctx->hpin_cap = 0;
-    HIP_TRY(ctx, hipHostMalloc(&ctx->hpin, (size_t)bytes, hipHostMallocDefault));
+    ctx->hpin = nullptr; ctx->hpin_dev = nullptr; ctx->hpin_cap = 0;
+    // mapped: the small-batch predict kernels read and write this buffer directly
+    HIP_TRY(ctx, hipHostMalloc(&ctx->hpin, (size_t)bytes, hipHostMallocMapped | hipHostMallocPortable));
+    HIP_TRY(ctx, hipHostGetDevicePointer(&ctx->hpin_dev, ctx->hpin, 0));
     ctx->hpin_cap = bytes;
     return 0;
 }
