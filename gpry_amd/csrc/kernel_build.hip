@@ -162,7 +162,7 @@ __device__ __forceinline__ void nt_store2(double2* p, double a, double b) {
 }
 
 template <int KID, int TS>
-__global__ __launch_bounds__((TS / 4) * (TS / 4)) void kernel_train_kernel(
+__global__ __launch_bounds__((TS / 4) * (TS / 4), 5) void kernel_train_kernel(
     const double* __restrict__ Xs, const double* __restrict__ noise, double* __restrict__ K,
     int64_t ld, KernParams kp, int add_noise) {
     constexpr int NT = (TS / 4) * (TS / 4), TQ = TS / 4, TP = TS + 2;
@@ -216,20 +216,31 @@ __global__ __launch_bounds__((TS / 4) * (TS / 4)) void kernel_train_kernel(
         nt_store2(p + TS / 4, val[a][2], val[a][3]);
     }
     if (bi == bj) return;
-    __syncthreads();            // X tiles no longer needed: reuse LDS as a [TS][TS+2] transpose pad
+    // Mirror image through an LDS transpose, one half of the tile's columns at a time: the pad is
+    // [TS/2][TS+2] doubles (16.9 KB at TS = 64 instead of 33.8 KB), so that five workgroups fit a CU
+    // and the 2080 tiles of N = 4096 run in two rounds instead of two and a bit.
     double* T = sm;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int h = 0; h < 2; h++) {
+        __syncthreads();        // X tiles (h = 0) / the previous half (h = 1) are no longer needed
 #pragma unroll
-        for (int b = 0; b < 4; b++) T[((b >> 1) * (TS / 2) + tx * 2 + (b & 1)) * TP + ty * 4 + a] = val[a][b];
-    __syncthreads();
+        for (int a = 0; a < 4; a++) {
+            T[(tx * 2 + 0) * TP + ty * 4 + a] = val[a][2 * h + 0];
+            T[(tx * 2 + 1) * TP + ty * 4 + a] = val[a][2 * h + 1];
+        }
+        __syncthreads();
+        // mirrored rows jr = h*TS/2 + 0..TS/2-1 of TS values: every store instruction writes whole
+        // rows (TS/2 lanes x 16 B contiguous), RPI rows per instruction
+        constexpr int LPR = TS / 2;                  // lanes per row (32 at TS = 64)
+        constexpr int RPI = NT / LPR;                // rows per instruction (8 at TS = 64)
+        const int c0 = (t % LPR) * 2;
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        int jr = ty * 4 + a;   // row of the mirrored tile (a column index j of K)
-        double2* p = reinterpret_cast<double2*>(K + ((int64_t)bj * TS + jr) * ld + (int64_t)bi * TS + tx * 2);
-        const double2* q = reinterpret_cast<const double2*>(T + jr * TP + tx * 2);
-        nt_store2(p, q[0].x, q[0].y);
-        nt_store2(p + TS / 4, q[TS / 4].x, q[TS / 4].y);
+        for (int v = 0; v < (TS / 2) / RPI; v++) {
+            const int jl = v * RPI + t / LPR;
+            double2* p = reinterpret_cast<double2*>(K + ((int64_t)bj * TS + h * (TS / 2) + jl) * ld + (int64_t)bi * TS + c0);
+            const double2 q = *reinterpret_cast<const double2*>(T + jl * TP + c0);
+            nt_store2(p, q.x, q.y);
+        }
     }
 }
 
@@ -238,7 +249,8 @@ int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
     const int TS = ctx->opt_kb_tile == 64 ? 64 : 32;
     int64_t nb = ctx->Np / TS;
     int64_t ntile = nb * (nb + 1) / 2;
-    size_t smem = sizeof(double) * (size_t)((2 * ctx->dpad * TS > TS * (TS + 2)) ? 2 * ctx->dpad * TS : TS * (TS + 2));
+    const int pad = (TS / 2) * (TS + 2);
+    size_t smem = sizeof(double) * (size_t)((2 * ctx->dpad * TS > pad) ? 2 * ctx->dpad * TS : pad);
 #define KT(KID)                                                                                        \
     if (TS == 64) hipLaunchKernelGGL((kernel_train_kernel<KID, 64>), dim3((unsigned)ntile), dim3(256), smem, \
                                      ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise);  \
