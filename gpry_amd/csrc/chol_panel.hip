@@ -107,8 +107,9 @@ __device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
 
 // x <- x * L^-T for the 16 rows at Xr against the 16x16 lower factor at L (both LDS):
 // lanes 0..15 take one row each (forward substitution, reciprocal-pivot scaling)
+template <int ROWS = 16>
 __device__ __forceinline__ void trsm16_rows(double* Xr, const double* L, const double* rd, int lane) {
-    const int i = lane & 15;
+    const int i = ROWS == 64 ? lane : (lane & 15);    // 64: one row per lane; 16: four copies
     double x[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = Xr[i * PLD + c];
@@ -146,10 +147,28 @@ __device__ __forceinline__ void trsm16_rows(double* Xr, const double* L, const d
             for (int c2 = c + 1; c2 < 16; c2++) x[c2] = fma(-x[c], l[c - 8][c2], x[c2]);
         }
     }
-    if (lane < 16) {
+    if (lane < ROWS) {
 #pragma unroll
         for (int c = 0; c < 16; c++) Xr[i * PLD + c] = x[c];
     }
+}
+
+// X[:, 16c .. 16c+15] of the 64-row block sB against the factor in sD, by ONE wave: the update with
+// the columns solved so far (MFMA) and the 16-wide substitution with one row per lane.  Runs on a
+// wave that would otherwise idle while another wave factors the next 16x16 diagonal block.
+__device__ __forceinline__ void solve_block_cols(double* sB, const double* sD, const double* sRd, int c, int lane) {
+    if (c) {
+#pragma unroll 1
+        for (int rt = 0; rt < 4; rt++) {
+            double* T = sB + (rt * 16) * PLD + c * 16;
+            v4d acc = tile_load(T, lane);
+            acc = mfma_nt16<true>(acc, sB + (rt * 16) * PLD, sD + (c * 16) * PLD, c * 16, lane);
+            tile_store(T, acc, lane);
+        }
+        wave_fence();
+    }
+    trsm16_rows<64>(sB + c * 16, sD + (c * 16) * PLD + c * 16, sRd + c * 16, lane);
+    wave_fence();
 }
 
 // 64x64 block global -> LDS in two phases: all eight 16-byte loads of a thread are in flight before
@@ -262,6 +281,10 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
         if (w == cb) {
             int bad = chol16_wave(sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
             if (bad && lane == 0) s_bad = cb * 16 + bad;
+        } else if (!is_diag && cb > 0 && w == ((cb + 1) & 3)) {
+            // three waves idle while wave cb factors its 16x16 block: one of them solves the
+            // workgroup's own rows against the PREVIOUS diagonal block (final since the last barrier)
+            solve_block_cols(sB, sD, sRd, cb - 1, lane);
         }
         __syncthreads();
         if (stamp2) q1 = __builtin_amdgcn_s_memtime();
@@ -310,15 +333,15 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
         }
         return;
     }
-    // ---- X = B Lkk^-T, wave w solves its own 16-row strip (no workgroup barriers needed)
-    for (int cb = 0; cb < 4; cb++) {
+    // ---- X = B Lkk^-T: the column blocks 0..2 were solved inside the factor loop (by the waves
+    // idling there); the last one is done here, wave w on its own 16-row strip
+    {
+        const int cb = 3;
         double* T = sB + (w * 16) * PLD + cb * 16;
-        if (cb) {
-            v4d acc = tile_load(T, lane);
-            acc = mfma_nt16<true>(acc, sB + (w * 16) * PLD, sD + (cb * 16) * PLD, cb * 16, lane);
-            tile_store(T, acc, lane);
-            wave_fence();
-        }
+        v4d acc = tile_load(T, lane);
+        acc = mfma_nt16<true>(acc, sB + (w * 16) * PLD, sD + (cb * 16) * PLD, cb * 16, lane);
+        tile_store(T, acc, lane);
+        wave_fence();
         trsm16_rows(T, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
         wave_fence();
     }
