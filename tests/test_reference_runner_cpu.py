@@ -155,3 +155,68 @@ def test_reference_batch_optimizer_runs_on_the_mirror_gpr(monkeypatch):
     Xt = rv.rvs(30, random_state=3)
     truth = np.array([loglike(*x) for x in Xt]) - np.log(100.0)
     assert np.max(np.abs(r.gpr.predict(Xt) - truth)) < 0.1
+
+
+def test_reference_checkpoint_is_light_and_resumes_on_the_mirror_classes(monkeypatch, tmp_path):
+    """SURVEY.md 8(f)4, second half: the reference's own checkpoint (``gpry/io.py:110-151``, dill
+    pickles written by ``Runner.save_checkpoint``, ``run.py:736``) of a mirror GPR holds the training
+    set and theta only -- no ``L_`` / ``V_`` / device handles -- and ``load_checkpoint="resume"``
+    (``run.py:231-262``) rebuilds the device state and carries the run on to convergence."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_goldens import import_reference
+    import_reference()
+    import dill
+    import scipy.stats as st
+    import gpry.run
+    import gpry.gp_acquisition
+    rv = st.multivariate_normal([0.5, -0.3], [[1.0, 0.6], [0.6, 0.8]])
+
+    def loglike(x, y):
+        return rv.logpdf([x, y])
+
+    from oracle_device import OracleDevice
+    from gpry_amd import _lib
+    import gpry_amd.gpr as mirror_gpr
+    saved = {k: getattr(gpry.run, k) for k in ("GaussianProcessRegressor", "GenericGPAcquisition",
+                                                "Normalize_bounds", "Normalize_y")}
+    saved_nora, saved_gpr = gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor
+    monkeypatch.setattr(_lib, "Device", lambda index=0: OracleDevice())
+
+    def make(load, max_total):
+        r = gpry.run.Runner(loglike, [[-5, 5], [-5, 5]], gpr={"kernel": {"Matern": {"nu": 2.5}}},
+                            gp_acquisition={"NORA": {"sampler": "uniform", "mc_every": 2}},
+                            options={"max_total": max_total, "max_finite": max_total, "n_initial": 6,
+                                     "max_initial": 12},
+                            checkpoint=str(tmp_path), load_checkpoint=load, verbose=0, seed=1)
+        r.generate_mc_sample = lambda *a, **k: None
+        r.diagnose_last_mc_sample = lambda *a, **k: True
+        return r
+
+    try:
+        from gpry_amd.integration import patch_gpry
+        patch_gpry()
+        first = make("overwrite", 12)           # budget exhausted after the initial set: not converged
+        first.run()
+        assert not first.has_converged and first.gpr.n_total == 12
+        size = os.path.getsize(tmp_path / "gpr.pkl")
+        assert size < 20_000, size               # training set + theta + bookkeeping only
+        with open(tmp_path / "gpr.pkl", "rb") as f:
+            state = dill.load(f).__dict__
+        assert state["_dev"] is None and state["_kb"] is None and not state["_host_factor"]
+        assert not state["_dev_factor_ok"] and not {"L_", "V_", "alpha_"} & set(state)
+        resumed = make("resume", 12)
+        assert resumed.loaded_from_checkpoint
+        assert isinstance(resumed.gpr, mirror_gpr.GaussianProcessRegressor) and resumed.gpr.n_total == 12
+        np.testing.assert_array_equal(resumed.gpr.X_train, first.gpr.X_train)
+        Xt = rv.rvs(20, random_state=5)
+        np.testing.assert_allclose(resumed.gpr.predict(Xt), first.gpr.predict(Xt), rtol=1e-12)
+        resumed.max_total = resumed.max_finite = 120      # the loaded options carry the old budget
+        resumed._mc_options = None                        # the reference does not restore it on resume
+        resumed.run()
+    finally:
+        for k, v in saved.items():
+            setattr(gpry.run, k, v)
+        gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor = saved_nora, saved_gpr
+    assert resumed.has_converged and resumed.gpr.n_total > 12
+    truth = np.array([loglike(*x) for x in Xt]) - np.log(100.0)
+    assert np.max(np.abs(resumed.gpr.predict(Xt) - truth)) < 0.1
