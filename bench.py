@@ -284,6 +284,16 @@ def main():
                          "bytes_per_launch": 8.0 * N * N + 8.0 * N * d},
     }
     if rank == 0:
+        # the build is one 40-us launch per LML evaluation: two events around a single launch also
+        # time the dispatch gap, so quote the steady-state duration (50 launches back to back) too
+        try:
+            us = dev.microbench(6, 50)
+            result["kernel_build"].update({
+                "avg_launch_ms_back_to_back": us * 1e-3,
+                "achieved_back_to_back": (8.0 * N * N + 8.0 * N * d) / (us * 1e-6) / 1e9,
+                "frac_back_to_back": (8.0 * N * N + 8.0 * N * d) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS})
+        except Exception as e:
+            result["kernel_build"]["back_to_back_error"] = repr(e)
         # measured ceilings of this very GPU, quoted beside the spec peaks used for `frac`
         try:
             result["measured_peaks"] = {

@@ -64,6 +64,7 @@ __global__ void zero_upper_copy_kernel(const double* __restrict__ src, double* _
 extern "C" {
 
 int gpry_kernel_train(gpry_ctx* ctx, int add_alpha, double* K_out) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_kernel_train: ctx is NULL");
     GPRY_TRY(require_model(ctx, false));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(launch_scale_train(ctx));
@@ -78,6 +79,7 @@ int gpry_kernel_train(gpry_ctx* ctx, int add_alpha, double* K_out) {
 }
 
 int gpry_kernel_cross(gpry_ctx* ctx, const double* Xc_, int64_t M, double* K_out) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_kernel_cross: ctx is NULL");
     GPRY_TRY(require_model(ctx, false));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return 0;
@@ -101,6 +103,7 @@ int gpry_kernel_cross(gpry_ctx* ctx, const double* Xc_, int64_t M, double* K_out
 }
 
 int gpry_factorize(gpry_ctx* ctx, int* info) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_factorize: ctx is NULL");
     GPRY_TRY(require_model(ctx, false));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->factor_valid = false;
@@ -129,6 +132,7 @@ int gpry_factorize(gpry_ctx* ctx, int* info) {
 }
 
 int gpry_get_factor(gpry_ctx* ctx, double* L, double* V, double* alpha_) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_get_factor: ctx is NULL");
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int64_t N = ctx->N;
@@ -150,16 +154,17 @@ int gpry_get_factor(gpry_ctx* ctx, double* L, double* V, double* alpha_) {
 }
 
 int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, double* grad, int* info) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_lml: ctx is NULL");
     if (ctx->N <= 0) return gpry_fail(ctx, -1, "no training set (call gpry_set_train)");
+    if (!theta || !lml || (want_grad && !grad)) return gpry_fail(ctx, -1, "lml: theta, lml and (with want_grad) grad must not be NULL");
+    for (int k = 0; k <= ctx->d; k++)
+        if (!isfinite(theta[k])) return gpry_fail(ctx, -1, "theta[%d] is not finite", k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // evaluate at `theta` without disturbing the prediction factor (dA, dV, dalpha_)
     double saved[1 + GPRY_MAX_DIM];
     bool had = ctx->have_theta;
     memcpy(saved, ctx->theta, sizeof(saved));
-    for (int k = 0; k <= ctx->d; k++) {
-        if (!isfinite(theta[k])) return gpry_fail(ctx, -1, "theta[%d] is not finite", k);
-        ctx->theta[k] = theta[k];
-    }
+    for (int k = 0; k <= ctx->d; k++) ctx->theta[k] = theta[k];
     ctx->have_theta = true;
     int inf = 0;
     int rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, &inf);
@@ -370,6 +375,7 @@ __global__ void count_nan_kernel(const double* __restrict__ a, int64_t n, unsign
 extern "C" {
 
 int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask, double* mean, double* std) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_predict: ctx is NULL");
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return 0;
@@ -448,6 +454,7 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
 
 int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgrad, double* mean_grad,
                       double* kinvk_grad) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_predict_grad: ctx is NULL");
     GPRY_TRY(require_model(ctx, want_kinv || mean_grad != nullptr));   // kgrad alone needs no factor
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!x) return gpry_fail(ctx, -1, "predict_grad: x is NULL");
@@ -480,6 +487,7 @@ int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgr
 }
 
 int gpry_sweep_fetch(gpry_ctx* ctx, int64_t M, double* y_all, double* sigma_all, double* acq_all) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_sweep_fetch: ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0 || M != ctx->sw_M) return gpry_fail(ctx, -1, "sweep_fetch: the resident sweep has %lld candidates, not %lld",
                                                   (long long)ctx->sw_M, (long long)M);
@@ -492,6 +500,7 @@ int gpry_sweep_fetch(gpry_ctx* ctx, int64_t M, double* y_all, double* sigma_all,
 
 int gpry_set_gates(gpry_ctx* ctx, const double* sv, const double* coef, int64_t n_sv, double gamma,
                    double intercept, int positive_is_finite, const double* trust_bounds) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_set_gates: ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->d <= 0) return gpry_fail(ctx, -1, "set_gates before set_train");
     if (n_sv < 0 || (n_sv > 0 && (!sv || !coef))) return gpry_fail(ctx, -1, "set_gates: bad support vectors");
@@ -521,6 +530,7 @@ int gpry_set_gates(gpry_ctx* ctx, const double* sv, const double* coef, int64_t 
 int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask, double zeta,
                       double baseline, double sigma_n, double* y_all, double* sigma_all, double* acq_all,
                       int64_t* n_nan) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_sweep_logexp: ctx is NULL");
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return gpry_fail(ctx, -1, "sweep: M must be > 0");
@@ -777,12 +787,14 @@ __global__ __launch_bounds__(256) void kb_var0_kernel(const double* __restrict__
 extern "C" {
 
 int gpry_kb_reset(gpry_ctx* ctx) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_kb_reset: ctx is NULL");
     GPRY_TRY(require_model(ctx, true));
     ctx->kb_n = 0;
     return 0;
 }
 
 int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, double* var0) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_kb_register: ctx is NULL");
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (m <= 0) { if (first) *first = ctx->kb_n; return 0; }
@@ -851,6 +863,7 @@ int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, 
 }
 
 int gpry_kb_gram(gpry_ctx* ctx, int64_t p, double* G, double* kvec, int64_t* n) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_kb_gram: ctx is NULL");
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (p < 0 || p >= ctx->kb_n) return gpry_fail(ctx, -1, "kb_gram: index %lld out of range [0, %lld)", (long long)p, (long long)ctx->kb_n);

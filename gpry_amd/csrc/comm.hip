@@ -46,7 +46,10 @@ int gpry_comm_unique_id(uint8_t id[128]) {
 }
 
 int gpry_comm_init(gpry_ctx* ctx, int world, int rank, const uint8_t id[128], gpry_comm** out) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_comm_init: ctx is NULL");
+    if (!out || !id) return gpry_fail(ctx, -1, "comm_init: id and out must not be NULL");
     *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return gpry_fail(ctx, -1, "comm_init: rank %d outside world of %d", rank, world);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     gpry_comm* c = new gpry_comm();
     c->ctx = ctx; c->world = world; c->rank = rank;
@@ -68,6 +71,7 @@ int gpry_comm_destroy(gpry_comm* c) {
 }
 
 int gpry_comm_allgather(gpry_comm* c, const void* send, int64_t bytes, void* recv) {
+    if (!c) return gpry_fail(nullptr, -1, "gpry_comm_allgather: communicator is NULL");
     gpry_ctx* ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(comm_buffers(c, bytes, bytes * c->world));
@@ -80,6 +84,7 @@ int gpry_comm_allgather(gpry_comm* c, const void* send, int64_t bytes, void* rec
 }
 
 int gpry_comm_allreduce_max(gpry_comm* c, double* inout, int64_t n) {
+    if (!c) return gpry_fail(nullptr, -1, "gpry_comm_allreduce_max: communicator is NULL");
     gpry_ctx* ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(comm_buffers(c, n * 8, n * 8));
@@ -92,6 +97,7 @@ int gpry_comm_allreduce_max(gpry_comm* c, double* inout, int64_t n) {
 }
 
 int gpry_comm_barrier(gpry_comm* c) {
+    if (!c) return gpry_fail(nullptr, -1, "gpry_comm_barrier: communicator is NULL");
     double x = 0.0;
     return gpry_comm_allreduce_max(c, &x, 1);
 }

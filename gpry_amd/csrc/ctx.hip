@@ -135,6 +135,7 @@ int gpry_device_info(int device, char* name, int name_len, int64_t* hbm_bytes, i
 }
 
 int gpry_ctx_create(int device, gpry_ctx** out) {
+    if (!out) return gpry_fail(nullptr, -1, "gpry_ctx_create: out is NULL");
     *out = nullptr;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return gpry_fail(nullptr, -2, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
@@ -182,11 +183,13 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
 const char* gpry_last_error(gpry_ctx* ctx) { return ctx ? ctx->err : g_last_error; }
 
 int gpry_ctx_sync(gpry_ctx* ctx) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_ctx_sync: ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
 int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_ctx_set_option: ctx is NULL");
     if (!strcmp(key, "chol")) { ctx->opt_chol = (int)value; return 0; }
     if (!strcmp(key, "sweep_chunk")) {
         if (value < 128) return gpry_fail(ctx, -1, "sweep_chunk must be >= 128");
@@ -219,8 +222,10 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
 
 int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const double* alpha,
                    int64_t N, int d) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_set_train: ctx is NULL");
     if (N <= 0 || d <= 0) return gpry_fail(ctx, -1, "set_train: need N > 0 and d > 0 (got %lld, %d)", (long long)N, d);
     if (d > 32) return gpry_fail(ctx, -1, "set_train: d=%d > 32 is not supported by this build", d);
+    if (!X_ || !y_ || !alpha) return gpry_fail(ctx, -1, "set_train: X_, y_ and alpha must not be NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(ensure_capacity(ctx, N, d));
     hipStream_t st = ctx->stream;
@@ -237,8 +242,10 @@ int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const doub
 }
 
 int gpry_set_theta(gpry_ctx* ctx, int kernel_id, const double* theta) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_set_theta: ctx is NULL");
     if (kernel_id < 0 || kernel_id > 3) return gpry_fail(ctx, -1, "unknown kernel id %d", kernel_id);
     if (ctx->d <= 0) return gpry_fail(ctx, -1, "set_theta before set_train");
+    if (!theta) return gpry_fail(ctx, -1, "set_theta: theta is NULL");
     ctx->kernel_id = kernel_id;
     for (int k = 0; k <= ctx->d; k++) {
         if (!isfinite(theta[k])) return gpry_fail(ctx, -1, "theta[%d] is not finite", k);
@@ -251,12 +258,14 @@ int gpry_set_theta(gpry_ctx* ctx, int kernel_id, const double* theta) {
 }
 
 int gpry_set_affine(gpry_ctx* ctx, const gpry_affine* tf) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_set_affine: ctx is NULL");
     if (!tf) return gpry_fail(ctx, -1, "set_affine: null");
     ctx->tf = *tf;
     return 0;
 }
 
 int gpry_timing_reset(gpry_ctx* ctx) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_timing_reset: ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     timers_collect(ctx);
     for (auto& kv : ctx->timers) { kv.second.total_ms = 0.0; kv.second.count = 0; }
@@ -264,6 +273,7 @@ int gpry_timing_reset(gpry_ctx* ctx) {
 }
 
 int gpry_timing_get(gpry_ctx* ctx, const char* name, double* total_ms, int64_t* count) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_timing_get: ctx is NULL");
     timers_collect(ctx);
     auto it = ctx->timers.find(name);
     if (it == ctx->timers.end()) { if (total_ms) *total_ms = 0.0; if (count) *count = 0; return -1; }
@@ -384,6 +394,18 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
         HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
         *value = (double)reps * 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9;
         (void)hipFree(src); (void)hipFree(dst);
+    } else if (kind == 6) {   // covariance build of the resident model, `bytes` launches back to back: us per launch
+        if (ctx->N <= 0 || !ctx->have_theta) return gpry_fail(ctx, -1, "microbench 6 needs set_train + set_theta");
+        const int reps = bytes >= 1 ? (int)bytes : 20;
+        ctx->lml_cache = false;   // dW is the scratch target
+        GPRY_TRY(launch_scale_train(ctx));
+        GPRY_TRY(launch_kernel_train(ctx, ctx->dW, 1));
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        for (int r = 0; r < reps; r++) GPRY_TRY(launch_kernel_train(ctx, ctx->dW, 1));
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(e1));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        *value = (double)ms * 1e3 / reps;
     } else if (kind == 4) {   // dispatch probe: fraction of blocks b that run on XCC (b % 8 + c) % 8
         const int nblk = 4096;
         int* d = nullptr;

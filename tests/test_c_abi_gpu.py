@@ -50,3 +50,56 @@ def test_plain_c_client_of_the_shared_library(tmp_path):
     np.testing.assert_allclose(pred[:, 2], acq, rtol=1e-6, atol=1e-6)
     order = np.lexsort((-np.arange(M), -pred[:, 2]))
     assert [t[0] for t in top] == list(order[:5])
+
+
+def test_error_returns_of_the_c_abi():
+    """Status-code contract of include/gpry_hip.h (SURVEY.md 8b "Errors"): misuse comes back as a
+    negative status plus a message from gpry_last_error, never as a crash, and a rejected call
+    leaves the context usable."""
+    import ctypes as C
+    from gpry_amd import _lib
+    lib = _lib.load_library()
+    dev = _lib.Device(0)
+    h = dev._h
+    vp = C.c_void_p
+
+    def err():
+        return lib.gpry_last_error(h).decode()
+
+    def ptr(a):
+        return a.ctypes.data_as(vp)
+
+    info, lml = C.c_int(0), C.c_double(0.0)
+    # a NULL handle is refused by every entry point; destroy(NULL) is a no-op like free(NULL)
+    assert lib.gpry_factorize(None, C.byref(info)) == -1
+    assert b"ctx is NULL" in lib.gpry_last_error(None)
+    assert lib.gpry_ctx_sync(None) == -1 and lib.gpry_ctx_destroy(None) == 0
+    assert lib.gpry_comm_barrier(None) == -1 and lib.gpry_comm_destroy(None) == 0
+    # calls out of order
+    assert lib.gpry_factorize(h, C.byref(info)) == -1 and "gpry_set_train" in err()
+    th = np.zeros(4)
+    assert lib.gpry_set_theta(h, 3, ptr(th)) == -1 and "before set_train" in err()
+    # bad sizes / pointers
+    X = np.random.default_rng(0).uniform(0, 1, (40, 3))
+    y, a = X.sum(1), np.full(40, 1e-6)
+    assert lib.gpry_set_train(h, ptr(X), ptr(y), ptr(a), 0, 3) == -1
+    assert lib.gpry_set_train(h, ptr(X), ptr(y), ptr(a), 40, 33) == -1 and "d=33" in err()
+    assert lib.gpry_set_train(h, None, ptr(y), ptr(a), 40, 3) == -1 and "NULL" in err()
+    assert lib.gpry_set_train(h, ptr(X), ptr(y), ptr(a), 40, 3) == 0
+    assert lib.gpry_set_theta(h, 7, ptr(th)) == -1 and "kernel id" in err()
+    bad = np.array([0.0, np.nan, 0.0, 0.0])
+    assert lib.gpry_set_theta(h, 3, ptr(bad)) == -1 and "theta[1]" in err()
+    assert lib.gpry_set_theta(h, 3, ptr(th)) == 0
+    assert lib.gpry_lml(h, ptr(bad), 0, C.byref(lml), None, C.byref(info)) == -1 and "theta[1]" in err()
+    assert lib.gpry_lml(h, ptr(th), 1, C.byref(lml), None, C.byref(info)) == -1 and "grad" in err()
+    mean = np.zeros(5)
+    assert lib.gpry_predict(h, ptr(X), 5, None, ptr(mean), None) == -1 and "not factorised" in err()
+    assert lib.gpry_ctx_set_option(h, b"no_such_option", 1) == -1 and "unknown option" in err()
+    # ... and the context still works after all the refusals (theta kept, not half-overwritten)
+    assert lib.gpry_lml(h, ptr(th), 0, C.byref(lml), None, C.byref(info)) == 0 and info.value == 0
+    ref = orc.log_marginal_likelihood(X, y, a, th, 3)
+    assert abs(lml.value - ref) <= 1e-9 * abs(ref)
+    assert lib.gpry_factorize(h, C.byref(info)) == 0 and info.value == 0
+    assert lib.gpry_predict(h, ptr(X), 5, None, ptr(mean), None) == 0
+    np.testing.assert_allclose(mean, y[:5], atol=1e-3)
+    dev.close()
