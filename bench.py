@@ -26,6 +26,10 @@ import time
 
 import numpy as np
 
+# the host driver of the MI355X pool supports dmabuf IPC only (RCCL peer access over xGMI needs it);
+# set before anything initialises HIP
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -170,15 +174,38 @@ def main():
         import torch.distributed as dist   # rendezvous only (CPU/gloo); the data path is RCCL
         dist.init_process_group("gloo")
         comm_kind = "rccl"
+        box = [None]
         try:
             box = [_lib.RcclComm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            comm = _lib.RcclComm(dev, world, rank, box[0])
-            ok = 1.0
-        except Exception as e:      # keep the run alive: the exchange is a few KB per cycle
-            print(f"bench.py[{rank}]: RCCL communicator failed ({e!r}); using gloo for the shortlist "
-                  f"exchange", file=sys.stderr)
-            ok = 0.0
+        except Exception as e:
+            print(f"bench.py[{rank}]: {e!r}", file=sys.stderr)
+        dist.broadcast_object_list(box, src=0)
+        # communicator + one verified exchange under a watchdog: a bootstrap that fails or hangs on
+        # this node must not take the run down (the exchange is a few KB per cycle)
+        made = {}
+
+        def _connect():
+            try:
+                c = _lib.RcclComm(dev, world, rank, box[0])
+                got = c.allgather(np.array([rank], dtype=np.int64))
+                if list(got.ravel()) != list(range(world)):
+                    raise RuntimeError(f"allgather self-test returned {got.ravel()}")
+                made["comm"] = c
+            except Exception as e:
+                made["error"] = e
+
+        ok = 0.0
+        if box[0] is not None:
+            import threading
+            th = threading.Thread(target=_connect, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("GPRY_BENCH_RCCL_TIMEOUT", "120")))
+            if "comm" in made:
+                comm, ok = made["comm"], 1.0
+            else:
+                why = repr(made.get("error", "timed out"))
+                print(f"bench.py[{rank}]: RCCL communicator failed ({why}); using gloo for the "
+                      f"shortlist exchange", file=sys.stderr)
         import torch
         flag = torch.tensor([ok])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks must agree on the transport
