@@ -315,6 +315,43 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_vgpr_kernel(double* out, in
     for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) out[0] = s;
 }
+// Do the matrix pipe and the vector ALU run FP64 work side by side?  Waves 0-3 of a workgroup (one per
+// SIMD) loop over v_mfma_f64_16x16x4_f64, waves 4-7 (their SIMD neighbours) over v_fma_f64 with one
+// wave-uniform (SGPR) factor -- the operand pattern of a contraction whose V entries come through the
+// scalar cache.  mode bit 0: matrix waves run, bit 1: vector waves run.
+__global__ __launch_bounds__(512) void mixed_f64_peak_kernel(double* out, int iters_mfma, int iters_valu,
+                                                             int mode, double u) {
+    const int wave = threadIdx.x >> 6;
+    double s = 0.0;
+    if (wave < 4) {
+        if (!(mode & 1)) return;
+        v4d acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+        double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+        for (int it = 0; it < iters_mfma; it++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        if (!(mode & 2)) return;
+        double acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 1e-9 * i;
+        double b = 1.0 - 1e-9 * threadIdx.x;
+        for (int it = 0; it < iters_valu; it++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "s"(u), "v"(b));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) s += acc[i];
+    }
+    if (s == 12345.678) out[0] = s;
+}
 __global__ __launch_bounds__(256) void stream_copy_kernel(const double2* __restrict__ src,
                                                           double2* __restrict__ dst, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,6 +431,23 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
         HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
         *value = (double)reps * 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9;
         (void)hipFree(src); (void)hipFree(dst);
+    } else if (kind == 7) {   // matrix + vector FP64 side by side; bytes = mode (1 matrix, 2 vector, 3 both) + 16 * workgroups per CU
+        double* out = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&out, 64));
+        const int mode = (int)(bytes & 3), wpc = (bytes >> 4) >= 1 ? (int)(bytes >> 4) : 1;
+        const int im = 4000, iv = 16 * im, nblk = 256 * wpc;
+        hipLaunchKernelGGL(mixed_f64_peak_kernel, dim3(nblk), dim3(512), 0, ctx->stream, out, 10, 160, mode, 0.999999);
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(mixed_f64_peak_kernel, dim3(nblk), dim3(512), 0, ctx->stream, out, im, iv, mode, 0.999999);
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(e1));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        double flops = 0.0;
+        if (mode & 1) flops += (double)nblk * 4.0 * im * 16.0 * 2048.0;
+        if (mode & 2) flops += (double)nblk * 4.0 * iv * 16.0 * 128.0;
+        *value = flops / (ms * 1e-3) / 1e12;
+        fprintf(stderr, "mixed_f64 mode %d, %d wg/CU: %.3f ms, %.2f TFLOP/s\n", mode, wpc, ms, *value);
+        (void)hipFree(out);
     } else if (kind == 6) {   // covariance build of the resident model, `bytes` launches back to back: us per launch
         if (ctx->N <= 0 || !ctx->have_theta) return gpry_fail(ctx, -1, "microbench 6 needs set_train + set_theta");
         const int reps = bytes >= 1 ? (int)bytes : 20;
