@@ -78,17 +78,17 @@ __device__ __forceinline__ double corr_r2_fast(double r2) {
 // returns k(r) in *kval and h with d k / d log l_k = h * D_k   (both without the factor C)
 template <int KID>
 __device__ __forceinline__ double corr_and_h(double r2, double* kval) {
-    if (KID == GPRY_RBF) { double e = exp(-0.5 * r2); *kval = e; return e; }
+    if (KID == GPRY_RBF) { double e = fast_exp_neg(0.5 * r2); *kval = e; return e; }
     if (KID == GPRY_MATERN12) {
-        double r = sqrt(r2); double e = exp(-r); *kval = e;
+        double r = fast_sqrt_pos(r2); double e = fast_exp_neg(r); *kval = e;
         return r != 0.0 ? e / r : 0.0;
     }
     if (KID == GPRY_MATERN32) {
-        double t = sqrt(r2) * SQRT3; double e = exp(-t);
+        double t = fast_sqrt_pos(r2) * SQRT3; double e = fast_exp_neg(t);
         *kval = (1.0 + t) * e;
         return 3.0 * e;
     }
-    double t = sqrt(r2) * SQRT5; double e = exp(-t);
+    double t = fast_sqrt_pos(r2) * SQRT5; double e = fast_exp_neg(t);
     *kval = (1.0 + t + t * t * (1.0 / 3.0)) * e;
     return (5.0 / 3.0) * (t + 1.0) * e;
 }
@@ -353,7 +353,7 @@ int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, 
 #define CB2(DP, KID) hipLaunchKernelGGL((cross_build_kernel<DP, KID>), grid, dim3(256), 0, st, Xc, M, \
                                         m0, mc, ctx->dXs, ctx->dalpha_, Kst, ldk, mean_part, kp, ap)
 #define CB4(KID) { if (ctx->d <= 4) CB2(4, KID); else if (ctx->d <= 8) CB2(8, KID); \
-                   else if (ctx->d <= 16) CB2(16, KID); else CB2(32, KID); }
+                   else if (ctx->d <= 16) CB2(16, KID); else if (ctx->d <= 24) CB2(24, KID); else CB2(32, KID); }
     DISPATCH_KID(ctx->kernel_id, CB4)
 #undef CB4
 #undef CB2
@@ -396,34 +396,46 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
         const int il = ty * 4 + a;
         const int64_t i = (int64_t)bi * 64 + il;
         double r2[4] = {0.0, 0.0, 0.0, 0.0};
+        // The column coordinates do not depend on `a`: the offset is laundered per iteration so that the
+        // compiler does not keep 4 DP of them in registers across this loop (with the second pass below:
+        // 256 VGPRs + AGPRs at DP >= 16, one wave per SIMD, where the FP64 vector pipe runs at a third of
+        // its rate).
+        int cj = tx * 4;
+        asm volatile("" : "+v"(cj));
 #pragma unroll
         for (int k = 0; k < DP; k++) {
             double xi = Xi[k * 64 + il];
-            const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + tx * 4);
+            const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + cj);
             double2 j0 = pj[0], j1 = pj[1];
             double xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
             for (int b = 0; b < 4; b++) { double df = xi - xj[b]; r2[b] = fma(df, df, r2[b]); }
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // no more than 4 coordinates' loads in flight
         }
         double wh[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const int jl = tx * 4 + b;
             const int64_t j = (int64_t)bj * 64 + jl;
-            double w = 0.0, kv = 1.0, h = 0.0;
-            if (i < kp.N && j < kp.N) {
-                int64_t hi = i > j ? i : j, lo = i > j ? j : i;
-                w = ai[il] * aj[jl] - Kinv[hi * ld + lo];
-                h = corr_and_h<KID>(r2[b], &kv);
-                if (i == j) kv = 1.0;
-            }
+            // branch-free (the buffers are padded to Np, padding rows are zero): behind a branch the
+            // distance arithmetic sinks into it and every coordinate read above stays live until here
+            const int64_t hi = i > j ? i : j, lo = i > j ? j : i;
+            double w = ai[il] * aj[jl] - Kinv[hi * ld + lo];
+            double kv;
+            const double h = corr_and_h<KID>(r2[b], &kv);
+            if (i == j) kv = 1.0;
+            if (i >= kp.N || j >= kp.N) w = 0.0;
             g[0] = fma(w, kp.C * kv, g[0]);
             wh[b] = w * kp.C * h;
         }
+        // second pass over the coordinates: laundered again, or the values of the first pass (5 DP
+        // doubles) stay live across the kernel evaluation to be reused here
+        int ci = il;
+        asm volatile("" : "+v"(cj), "+v"(ci));
 #pragma unroll
         for (int k = 0; k < DP; k++) {
-            double xi = Xi[k * 64 + il];
-            const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + tx * 4);
+            double xi = Xi[k * 64 + ci];
+            const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + cj);
             double2 j0 = pj[0], j1 = pj[1];
             double xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
@@ -431,6 +443,7 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
                 double df = xi - xj[b];
                 g[1 + k] = fma(wh[b], df * df, g[1 + k]);
             }
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
     const int lane = t & 63, wave = t >> 6;
@@ -470,7 +483,7 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, do
     int64_t nb = ctx->Np / 64;
     int64_t ntile = nb * (nb + 1) / 2;
     if (ctx->d > 32) return gpry_fail(ctx, -1, "d > 32 is not supported");
-    int DPsel = ctx->d <= 4 ? 4 : ctx->d <= 8 ? 8 : ctx->d <= 16 ? 16 : 32;
+    int DPsel = ctx->d <= 4 ? 4 : ctx->d <= 8 ? 8 : ctx->d <= 16 ? 16 : ctx->d <= 24 ? 24 : 32;
     int64_t need = ntile * (DPsel + 1);
     if (need > ctx->part_cap) {
         if (ctx->dpart) dev_free(ctx, ctx->dpart);
@@ -480,7 +493,7 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, do
 #define LT2(DP, KID) hipLaunchKernelGGL((lml_traces_kernel<DP, KID>), dim3((unsigned)ntile), dim3(256), 0, \
                                         ctx->stream, ctx->dXs, Kinv, ctx->Np, alpha, ctx->dpart, kp)
 #define LT4(KID) { if (DPsel == 4) LT2(4, KID); else if (DPsel == 8) LT2(8, KID); \
-                   else if (DPsel == 16) LT2(16, KID); else LT2(32, KID); }
+                   else if (DPsel == 16) LT2(16, KID); else if (DPsel == 24) LT2(24, KID); else LT2(32, KID); }
     DISPATCH_KID(ctx->kernel_id, LT4)
 #undef LT4
 #undef LT2
