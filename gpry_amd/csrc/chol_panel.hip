@@ -225,19 +225,18 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
     const int kprev = (int)(j0 - K0);          // columns of the outer block already factorised: 0, 64, 128, ...
     if (t == 0) s_bad = 0;
     {
+        // all four blocks unconditionally (the diagonal workgroup has R == j0 and the first step of an
+        // outer block K0 == j0: those loads repeat D and land in buffers nobody reads): with the loads
+        // behind branches the 3 x 128-byte register sets went through scratch memory
         double2 rD[8], rB[8], rPt[8], rPo[8];
         load_block_issue(A + j0 * ld + j0, ld, t, rD);
-        if (!is_diag) load_block_issue(A + R * ld + j0, ld, t, rB);
-        if (kprev) {
-            load_block_issue(A + j0 * ld + K0, ld, t, rPt);
-            if (!is_diag) load_block_issue(A + R * ld + K0, ld, t, rPo);
-        }
+        load_block_issue(A + R * ld + j0, ld, t, rB);
+        load_block_issue(A + j0 * ld + K0, ld, t, rPt);
+        load_block_issue(A + R * ld + K0, ld, t, rPo);
         load_block_commit(sD, t, rD);
-        if (!is_diag) load_block_commit(sB, t, rB);
-        if (kprev) {
-            load_block_commit(sPt, t, rPt);
-            if (!is_diag) load_block_commit(sPo, t, rPo);
-        }
+        load_block_commit(sB, t, rB);
+        load_block_commit(sPt, t, rPt);
+        load_block_commit(sPo, t, rPo);
     }
     __syncthreads();
     if (stamp) ts[1] = __builtin_amdgcn_s_memtime();

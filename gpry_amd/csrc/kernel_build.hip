@@ -520,14 +520,20 @@ __global__ __launch_bounds__(256) void gradx_kernel(const double* __restrict__ x
                                                     int64_t Np, KernParams kp, AffParams ap) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= Np) return;
-    double diff[GPRY_MAX_DIM];
+    // fully unrolled over the maximum dimension with guards: run-time indices into `diff` and into the
+    // by-value parameter arrays would put both in scratch memory
+    double diff[32];      // set_train refuses d > 32
     double r2 = 0.0;
-    for (int k = 0; k < kp.d; k++) {
-        double v = x[k];
-        if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
-        v = v / ap.ls[k];
-        diff[k] = v - Xs[j * kp.dpad + k];
-        r2 = fma(diff[k], diff[k], r2);
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        diff[k] = 0.0;
+        if (k < kp.d) {
+            double v = x[k];
+            if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
+            v = v / ap.ls[k];
+            diff[k] = v - Xs[j * kp.dpad + k];
+            r2 = fma(diff[k], diff[k], r2);
+        }
     }
     const bool real = j < kp.N;
     double kv, coef;      // k(r) and the factor of diff/l
@@ -536,13 +542,16 @@ __global__ __launch_bounds__(256) void gradx_kernel(const double* __restrict__ x
     else if (KID == GPRY_MATERN32) { double t = sqrt(r2) * SQRT3; double e = exp(-t); kv = (1.0 + t) * e; coef = -3.0 * e; }
     else { double t = sqrt(r2) * SQRT5; double e = exp(-t); kv = (1.0 + t + t * t * (1.0 / 3.0)) * e; coef = -(5.0 / 3.0) * (1.0 + t) * e; }
     kstar[j] = real ? kp.C * kv : 0.0;
-    for (int k = 0; k < kp.dpad; k++) {
-        double g = 0.0;
-        if (real && k < kp.d) {
-            g = kp.C * coef * diff[k] / ap.ls[k];
-            if (KID == GPRY_MATERN12 && r2 == 0.0) g = -kp.C / ap.ls[k];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if (k < kp.dpad) {
+            double g = 0.0;
+            if (real && k < kp.d) {
+                g = kp.C * coef * diff[k] / ap.ls[k];
+                if (KID == GPRY_MATERN12 && r2 == 0.0) g = -kp.C / ap.ls[k];
+            }
+            G[j * kp.dpad + k] = g;
         }
-        G[j * kp.dpad + k] = g;
     }
 }
 
