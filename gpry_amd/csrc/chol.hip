@@ -168,6 +168,7 @@ struct TrtriPlan {
     int64_t Np = 0;
     std::vector<GemmBatchItem*> d_t, d_v;   // per level
     std::vector<int> count, maxM, maxN;
+    std::vector<int> aligned;               // per level: every item is a multiple of 128 in M, N and K
 };
 // the plan lives in its context (ctx->trtri_plan): distinct contexts may be driven from distinct threads
 void trtri_plan_free(gpry_ctx* ctx) {
@@ -191,7 +192,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
     int nlev = build_tree(0, (int)(Np / 64), nodes);
     for (int lev = 1; lev <= nlev; lev++) {
         std::vector<GemmBatchItem> bt, bv;
-        int mM = 0, mN = 0;
+        int mM = 0, mN = 0, al = 1;
         for (auto& nd : nodes) {
             if (nd.level != lev) continue;
             int64_t lo = nd.lo * 64, mid = nd.mid * 64, hi = nd.hi * 64;
@@ -206,6 +207,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
             bv.push_back(b);
             if (m > mM) mM = m;
             if (n > mN) mN = n;
+            if (m % 128 || n % 128) al = 0;
         }
         GemmBatchItem *dt = nullptr, *dv = nullptr;
         size_t bytes = bt.size() * sizeof(GemmBatchItem);
@@ -215,6 +217,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
         HIP_TRY(ctx, hipMemcpy(dv, bv.data(), bytes, hipMemcpyHostToDevice));
         pl.d_t.push_back(dt); pl.d_v.push_back(dv);
         pl.count.push_back((int)bt.size()); pl.maxM.push_back(mM); pl.maxN.push_back(mN);
+        pl.aligned.push_back(al);
     }
     *out = &pl;
     return 0;
@@ -245,14 +248,14 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
         g.M = pl->maxM[lev]; g.N = pl->maxN[lev]; g.K = 0;
         g.kmode = KM_B_LOWER; g.lower_only = 0; g.tile_map = TM_ROWMAJOR;
         g.batch = pl->d_t[lev]; g.n_batch = pl->count[lev]; g.info = ctx->dinfo;
-        g.nsplit = nsplit; g.split_buf = sbuf; g.split_stride = Np * Np;
+        g.nsplit = nsplit; g.split_buf = sbuf; g.split_stride = Np * Np; g.dma_ok = pl->aligned[lev];
         GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_STORE));
         GemmArgs h = {};
         h.A = V; h.lda = Np; h.B = T; h.ldb = Np; h.C = V; h.ldc = Np;
         h.M = pl->maxM[lev]; h.N = pl->maxN[lev]; h.K = 0;
         h.kmode = KM_A_LOWER; h.lower_only = 0; h.tile_map = TM_ROWMAJOR;
         h.batch = pl->d_v[lev]; h.n_batch = pl->count[lev]; h.info = ctx->dinfo;
-        h.nsplit = nsplit; h.split_buf = sbuf; h.split_stride = Np * Np;
+        h.nsplit = nsplit; h.split_buf = sbuf; h.split_stride = Np * Np; h.dma_ok = pl->aligned[lev];
         GPRY_TRY(gemm_f64_launch(ctx, h, false, false, EPI_STORE_NEG));
     }
     return 0;

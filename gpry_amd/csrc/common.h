@@ -101,6 +101,7 @@ struct gpry_ctx {
     double* dsplit = nullptr;  // split-K partial products of the factor GEMMs
     int64_t split_cap = 0;
     int opt_split_k = 1;       // split-K for launches with fewer tiles than slots (trtri top levels, lauum)
+    int opt_gemm_dma = 1;         // 128-aligned factor-chain products through gemm_dma_kernel
     double* dpart = nullptr;   // partial sums (sumsq per i-tile, mean per j-chunk)
     int64_t part_cap = 0;
     // top-k scratch
@@ -187,10 +188,14 @@ struct GemmArgs {
     hipStream_t stream;    // null: ctx->stream
     int nsplit;            // > 1: split-K over grid.y into split_buf (store epilogues only), then reduced
     double* split_buf; int64_t split_stride;
+    int dma_ok;            // batched launches: 1 = every item meets gemm_dma_usable (checked by the caller)
 };
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
 int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
+// gemm_dma.hip: LDS-DMA staged, software-pipelined variant for 128-aligned products (NN, NT, TN)
+bool gemm_dma_usable(const GemmArgs& g, int M, int N, int K);
+int gemm_dma_launch_product(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi, dim3 grid);
 int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g);   // sweep_gemm.hip (LDS-DMA staging)
 int sweep_gemm_dma256_launch(gpry_ctx* ctx, const GemmArgs& g);  // 128x256 tile, 8 waves, 3-stage ring
 int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g);  // variant 1 + explicit software pipeline

@@ -240,8 +240,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
         return;
     }
+    // read-modify-write: the 16 old values of a 16-row block are fetched before the first store (the
+    // compiler cannot exclude aliasing and would otherwise wait for every load in turn)
 #pragma unroll
-    for (int mi = 0; mi < 4; mi++)
+    for (int mi = 0; mi < 4; mi++) {
+        double old[4][4];
+        if (EPI == EPI_SUB && g.nsplit <= 1) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int row = row0 + wr * 64 + mi * 16 + gq + 4 * q;
+                    int col = col0 + wc * 64 + ni * 16 + r;
+                    old[ni][q] = (row < M && col < N) ? C[(int64_t)row * g.ldc + col] : 0.0;
+                }
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ni++)
 #pragma unroll
@@ -253,9 +266,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     double v = acc[mi][ni][q];
                     if (EPI == EPI_STORE || g.nsplit > 1) *p = v;
                     else if (EPI == EPI_STORE_NEG) *p = -v;
-                    else *p = *p - v;
+                    else *p = old[ni][q] - v;
                 }
             }
+    }
 }
 
 // C = sign * sum over the split-K slices, same tile map / batch / lower_only logic as the product
@@ -321,7 +335,10 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
     if (g.nsplit > 1 && !(epi == EPI_STORE || epi == EPI_STORE_NEG))
         return gpry_fail(ctx, -1, "gemm: split-K only with the store epilogues");
     int rc;
-    if (!a_trans && !b_trans) rc = launch_epi<false, false>(ctx, g, epi, grid);
+    bool dma = ctx->opt_gemm_dma && epi != EPI_SUMSQ && !(a_trans && b_trans) && g.extra_lds == 0;
+    if (dma) dma = g.batch ? (g.dma_ok == 1 && gemm_dma_usable(g, BM, BN, 32)) : gemm_dma_usable(g, M, N, g.K);
+    if (dma) rc = gemm_dma_launch_product(ctx, g, a_trans, b_trans, epi, grid);
+    else if (!a_trans && !b_trans) rc = launch_epi<false, false>(ctx, g, epi, grid);
     else if (!a_trans && b_trans) rc = launch_epi<false, true>(ctx, g, epi, grid);
     else if (a_trans && !b_trans) rc = launch_epi<true, false>(ctx, g, epi, grid);
     else rc = launch_epi<true, true>(ctx, g, epi, grid);
