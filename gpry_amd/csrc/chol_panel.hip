@@ -367,6 +367,7 @@ static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int
     g.C = A + r0 * Np + c0; g.ldc = Np;
     g.M = (int)(Np - r0); g.N = (int)nc; g.K = kdepth;
     g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo; g.stream = st;
+    g.extra_lds = ctx->opt_syrk_lds;
     return gemm_f64_launch(ctx, g, false, true, EPI_SUB);
 }
 

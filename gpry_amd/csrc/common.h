@@ -101,6 +101,7 @@ struct gpry_ctx {
     double* dsplit = nullptr;  // split-K partial products of the factor GEMMs
     int64_t split_cap = 0;
     int opt_split_k = 1;       // split-K for launches with fewer tiles than slots (trtri top levels, lauum)
+    int opt_syrk_lds = 0;         // extra dynamic LDS of the trailing update (32768: one workgroup per CU)
     int opt_gemm_dma = 1;         // 128-aligned factor-chain products through gemm_dma_kernel
     double* dpart = nullptr;   // partial sums (sumsq per i-tile, mean per j-chunk)
     int64_t part_cap = 0;

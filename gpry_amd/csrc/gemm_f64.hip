@@ -335,7 +335,7 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
     if (g.nsplit > 1 && !(epi == EPI_STORE || epi == EPI_STORE_NEG))
         return gpry_fail(ctx, -1, "gemm: split-K only with the store epilogues");
     int rc;
-    bool dma = ctx->opt_gemm_dma && epi != EPI_SUMSQ && !(a_trans && b_trans) && g.extra_lds == 0;
+    bool dma = ctx->opt_gemm_dma && epi != EPI_SUMSQ && !(a_trans && b_trans);
     if (dma) dma = g.batch ? (g.dma_ok == 1 && gemm_dma_usable(g, BM, BN, 32)) : gemm_dma_usable(g, M, N, g.K);
     if (dma) rc = gemm_dma_launch_product(ctx, g, a_trans, b_trans, epi, grid);
     else if (!a_trans && !b_trans) rc = launch_epi<false, false>(ctx, g, epi, grid);
