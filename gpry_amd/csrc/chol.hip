@@ -273,11 +273,13 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
     const int64_t tiles = (Np / 128) * (Np / 128 + 1) / 2;
     int nsplit = 1;
     if (ctx->opt_split_k) while (nsplit < 4 && tiles * nsplit * 2 <= 600 && Np / (nsplit * 2) >= 256) nsplit *= 2;
+    if (ctx->opt_lauum_split > 0) nsplit = ctx->opt_lauum_split;
     if (nsplit > 1) {
         double* sbuf = nullptr;
         GPRY_TRY(gemm_split_scratch(ctx, nsplit, Np * Np, &sbuf));
         g.nsplit = nsplit; g.split_buf = sbuf; g.split_stride = Np * Np;
     }
+    g.extra_lds = ctx->opt_lauum_lds;
     return gemm_f64_launch(ctx, g, true, false, EPI_STORE);
 }
 

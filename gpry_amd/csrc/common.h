@@ -102,6 +102,8 @@ struct gpry_ctx {
     int64_t split_cap = 0;
     int opt_split_k = 1;       // split-K for launches with fewer tiles than slots (trtri top levels, lauum)
     int opt_syrk_lds = 0;         // extra dynamic LDS of the trailing update (32768: one workgroup per CU)
+    int opt_lauum_lds = 0;        // extra dynamic LDS of K^-1 = V^T V (32768: one workgroup per CU)
+    int opt_lauum_split = 0;      // > 0: force the split-K factor of K^-1 = V^T V (A/B)
     int opt_gemm_dma = 1;         // 128-aligned factor-chain products through gemm_dma_kernel
     double* dpart = nullptr;   // partial sums (sumsq per i-tile, mean per j-chunk)
     int64_t part_cap = 0;
@@ -166,7 +168,10 @@ enum GemmKMode {
     KM_B_UPPER = 4    // B upper triangular (rows k, cols j): k < (tj+1)*TILE
 };
 enum GemmEpi { EPI_STORE = 0, EPI_STORE_NEG = 1, EPI_SUB = 2, EPI_SUMSQ = 3 };
-enum GemmTileMap { TM_ROWMAJOR = 0, TM_SWEEP = 1 };
+// TM_BALANCED (gemm_dma.hip): workgroups go to the XCDs round-robin by block index, so the enumeration
+// decides the balance: tiles of equal k-length are neighbours (row-wise triangular order for lower-only
+// square outputs, column-major where the length depends on the tile column), longest first
+enum GemmTileMap { TM_ROWMAJOR = 0, TM_SWEEP = 1, TM_BALANCED = 2 };
 
 struct GemmBatchItem { int64_t a_off, b_off, c_off; int M, N, K, pad; };
 

@@ -114,11 +114,30 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs g) {
             const int si = nsi - 1 - s / nsj, sj = s % nsj;
             ti = (si << a) + (within >> c);
             tj = (sj << c) + (within & ((1 << c) - 1));
+        } else if ((g.tile_map & 15) == TM_BALANCED) {
+            // With the row-major map XCD = tj mod 8 (tiles_n is a multiple of 8 at the sizes that matter):
+            // in K^-1 = V^T V (k-length (tiles - ti) * 8 slabs, lower tiles only) XCD 0 then holds twice the
+            // work of XCD 7 and, worse, its longest tiles in pairs on the same CUs.
+            if (g.lower_only && tiles_m == tiles_n) {
+                int i = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);       // b = i (i + 1) / 2 + j, j <= i
+                while ((i + 1) * (i + 2) / 2 <= b) i++;
+                while (i * (i + 1) / 2 > b) i--;
+                ti = i; tj = b - i * (i + 1) / 2;
+                if (ti >= tiles_m) return;
+            } else if (g.kmode == KM_B_LOWER || g.kmode == KM_B_UPPER) {
+                tj = b / tiles_m;
+                ti = b - tj * tiles_m;
+                if (g.kmode == KM_B_UPPER) tj = tiles_n - 1 - tj;
+            } else {
+                ti = b / tiles_n;
+                tj = b - ti * tiles_n;
+                if (g.kmode == KM_A_LOWER) ti = tiles_m - 1 - ti;
+            }
         } else {
             ti = b / tiles_n;
             tj = b - ti * tiles_n;
         }
-        if (ti >= tiles_m || tj >= tiles_n) return;
+        if (ti < 0 || tj < 0 || ti >= tiles_m || tj >= tiles_n) return;
         if (g.lower_only && tj > ti) return;
     }
     const int row0 = ti * BM, col0 = tj * BN;
@@ -301,7 +320,13 @@ static int gd_launch_epi(gpry_ctx* ctx, const GemmArgs& g, int epi, dim3 grid) {
 }
 
 // the product only (same grid as gemm_f64_launch); the caller runs the split-K reduce
-int gemm_dma_launch_product(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi, dim3 grid) {
+int gemm_dma_launch_product(gpry_ctx* ctx, const GemmArgs& g0, bool a_trans, bool b_trans, int epi, dim3 grid) {
+    GemmArgs g = g0;
+    if ((g.tile_map & 15) == TM_ROWMAJOR) {
+        g.tile_map = TM_BALANCED;
+        const int tm = g.M / BM, tn = g.N / BN;      // batched launches: the largest item
+        if (g.lower_only && tm == tn && g.batch == nullptr) grid.x = (unsigned)(tm * (tm + 1) / 2);
+    }
     if (!a_trans && !b_trans) return gd_launch_epi<false, false>(ctx, g, epi, grid);
     if (!a_trans && b_trans) return gd_launch_epi<false, true>(ctx, g, epi, grid);
     if (a_trans && !b_trans) return gd_launch_epi<true, false>(ctx, g, epi, grid);

@@ -287,8 +287,11 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(GemmArgs g, doub
     TileCoord tc = map_tile(g, tiles_m, tiles_n);
     if (!tc.valid) return;
     const int row0 = tc.ti * BM, col0 = tc.tj * BN;
-    for (int e = threadIdx.x; e < BM * (BN / 2); e += 256) {
-        const int rr = e / (BN / 2), cc = (e - rr * (BN / 2)) * 2;
+    // grid.y = 8 row slices of 16 rows per tile: one workgroup per tile left the launch at ~1 TB/s
+    // (a few hundred workgroups, each walking 32 dependent iterations)
+    const int rbeg = (int)blockIdx.y * (BM / 8);
+    for (int e = threadIdx.x; e < (BM / 8) * (BN / 2); e += 256) {
+        const int rr = rbeg + e / (BN / 2), cc = (e % (BN / 2)) * 2;
         const int row = row0 + rr, col = col0 + cc;
         if (row >= M || col >= N) continue;
         const int64_t off = coff + (int64_t)row * g.ldc + col;
@@ -343,7 +346,7 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
     else if (a_trans && !b_trans) rc = launch_epi<true, false>(ctx, g, epi, grid);
     else rc = launch_epi<true, true>(ctx, g, epi, grid);
     if (rc != 0 || g.nsplit <= 1) return rc;
-    dim3 rgrid((unsigned)nblk, 1, g.batch ? (unsigned)g.n_batch : 1u);
+    dim3 rgrid((unsigned)nblk, 8, g.batch ? (unsigned)g.n_batch : 1u);
     hipLaunchKernelGGL(gemm_split_reduce_kernel, rgrid, dim3(256), 0, g.stream ? g.stream : ctx->stream, g,
                        epi == EPI_STORE_NEG ? -1.0 : 1.0);
     HIP_TRY(ctx, hipGetLastError());
