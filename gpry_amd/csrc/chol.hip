@@ -239,8 +239,9 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
         const int64_t tiles = (int64_t)tm * tn * pl->count[lev];
         int nsplit = 1;
         if (ctx->opt_split_k && pl->maxN[lev] >= 512) {
-            while (nsplit < 8 && tiles * nsplit * 2 <= 1024 && pl->maxN[lev] / (nsplit * 2) >= 128) nsplit *= 2;
+            while (nsplit < 4 && tiles * nsplit * 2 <= 1024 && pl->maxN[lev] / (nsplit * 2) >= 128) nsplit *= 2;
         }
+        if (ctx->opt_trtri_split_cap > 0 && nsplit > ctx->opt_trtri_split_cap) nsplit = ctx->opt_trtri_split_cap;
         double* sbuf = nullptr;
         if (nsplit > 1) GPRY_TRY(gemm_split_scratch(ctx, nsplit, Np * Np, &sbuf));
         GemmArgs g = {};
@@ -267,12 +268,13 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
     g.A = V; g.lda = Np; g.B = V; g.ldb = Np; g.C = Kinv; g.ldc = Np;
     g.M = (int)Np; g.N = (int)Np; g.K = (int)Np;
     g.kmode = KM_AT_LOWER_B_LOWER; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
-    // tile (i, j) sums over k >= max(i, j) * 128: the first tiles run the whole K.  Splitting them
-    // pays while the launch has fewer tiles than the GPU has slots (Np <= 2048: 332 -> 269 us); at
-    // Np = 4096 (528 tiles) it costs 8 % (measured), so it is not used there.
+    // tile (i, j) sums over k >= max(i, j) * 128: the first tiles run the whole K and are the critical
+    // path of the launch.  Splitting them pays up to about two rounds of workgroups (Np = 2048: x4,
+    // 332 -> 130 us with the balanced tile map; Np = 4096, 528 tiles: x2, 0.63 -> 0.51 ms); at
+    // Np = 8192 (2080 tiles) it costs 5 %.
     const int64_t tiles = (Np / 128) * (Np / 128 + 1) / 2;
     int nsplit = 1;
-    if (ctx->opt_split_k) while (nsplit < 4 && tiles * nsplit * 2 <= 600 && Np / (nsplit * 2) >= 256) nsplit *= 2;
+    if (ctx->opt_split_k) while (nsplit < 4 && tiles * nsplit * 2 <= 1100 && Np / (nsplit * 2) >= 256) nsplit *= 2;
     if (ctx->opt_lauum_split > 0) nsplit = ctx->opt_lauum_split;
     if (nsplit > 1) {
         double* sbuf = nullptr;
