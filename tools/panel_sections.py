@@ -20,13 +20,5 @@ for blk, label in ((1, "diagonal workgroup"), (2, "first off-diagonal workgroup"
     assert dev.factorize() == 0
     dg = dev.read_diag(True).astype(float)
     dev.set_option("chol_dbg", 0)
-    print(f"{label}: " + ", ".join(f"{n} {dg[i] / dg[5] / 100.0:.2f} us" for i, n in enumerate(names)) +
-          f"  (s_memtime ticks of 10 ns; {int(dg[5])} panel steps)")
-
-dev.set_option("chol_dbg", -1)      # dbg_block = -2: inside the 64x64 factor of the diagonal workgroup
-dev.read_diag(True)
-assert dev.factorize() == 0
-dg = dev.read_diag(True).astype(float)
-dev.set_option("chol_dbg", 0)
-print(f"inside the 64x64 factor (cycles per panel step): chol16 x4 {dg[0] / dg[5]:.0f}, row solves x3 {dg[1] / dg[5]:.0f}, "
-      f"MFMA updates x3 {dg[2] / dg[5]:.0f}")
+    print(f"{label}: " + ", ".join(f"{n} {dg[i] / dg[5]:.0f}" for i, n in enumerate(names)) +
+          f"  (s_memtime cycles per panel step; {int(dg[5])} steps)")
