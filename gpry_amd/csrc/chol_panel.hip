@@ -253,13 +253,20 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
             if (!is_diag) load_block_commit(sPo, t, rPo);
             __syncthreads();
         }
-#pragma unroll
-        for (int n = 0; n < 4; n++) {
-            double* T = sD + (w * 16) * PLD + n * 16;
+        // D: only the ten 16x16 tiles on and below the diagonal are ever read (the factor works on the
+        // lower triangle); they are dealt round-robin to the waves (3, 3, 2, 2) instead of a full row each
+#pragma unroll 1
+        for (int tl = w; tl < 10; tl += 4) {
+            const int rw = tl < 1 ? 0 : tl < 3 ? 1 : tl < 6 ? 2 : 3;
+            const int n = tl - rw * (rw + 1) / 2;
+            double* T = sD + (rw * 16) * PLD + n * 16;
             v4d acc = tile_load(T, lane);
-            acc = mfma_nt16<true>(acc, sPt + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+            acc = mfma_nt16<true>(acc, sPt + (rw * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
             tile_store(T, acc, lane);
-            if (!is_diag) {
+        }
+        if (!is_diag) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
                 double* U = sB + (w * 16) * PLD + n * 16;
                 v4d acb = tile_load(U, lane);
                 acb = mfma_nt16<true>(acb, sPo + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
