@@ -70,7 +70,12 @@ int gpry_ctx_destroy(gpry_ctx* ctx);
 const char* gpry_last_error(gpry_ctx* ctx); /* ctx may be NULL: last global error */
 int gpry_ctx_sync(gpry_ctx* ctx);
 /* option keys: "chol" = 0 hand-written MFMA Cholesky (default), 1 rocSOLVER dpotrf/dtrtri
- *              "sweep_chunk" = candidates per sweep chunk (default 32768) */
+ *              "sweep_chunk" = candidates per sweep chunk (default 32768)
+ *              "timing" = 0/1 per-stage HIP-event timers (gpry_timing_get)
+ * Everything else is an A/B switch of the measurements quoted in DESIGN.md (defaults are the
+ * measured best): "sweep_dma" 0..3, "sweep_persist", "sweep_overlap", "sweep_tilemap", "chol_outer",
+ * "chol_lookahead", "split_k", "gemm_dma", "syrk_lds", "lauum_lds", "lauum_split",
+ * "trtri_split_cap", "kb_tile", "predict_small", "lml_cache".  Unknown keys return -1. */
 int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value);
 
 /* ---- model state ------------------------------------------------------------------ */
