@@ -1,4 +1,4 @@
-"""Randomised parity sweep (tools/fuzz_parity.py): random N (around the 64/128 padding quanta), d in
+"""Randomised parity sweep (tests/tools/fuzz_parity.py): random N (around the 64/128 padding quanta), d in
 1..32, M across the small-batch / panel path boundaries, all four kernels, masks, chunk sizes."""
 import os
 import sys
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_configurations_against_the_oracle(seed):
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import fuzz_parity
     bad, worst = fuzz_parity.run(n_cases=25, seed=seed)
     assert bad == 0, worst
@@ -19,18 +19,18 @@ def test_random_configurations_against_the_oracle(seed):
 
 
 def test_random_operation_sequences_on_the_host_mirror():
-    """tools/fuzz_mirror.py: appends, predictions, conditioned models, copies / pickles and NORA
+    """tests/tools/fuzz_mirror.py: appends, predictions, conditioned models, copies / pickles and NORA
     proposals of the mirror classes on the GPU against the oracle."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import fuzz_mirror
     bad, worst = fuzz_mirror.run(n_seq=12, seed=42)
     assert bad == 0, worst
 
 
 def test_random_gated_models_device_gates_equal_host_masks():
-    """tools/fuzz_gates.py: random -inf half-spaces (SVM) and trust regions; NORA with the gates on
+    """tests/tools/fuzz_gates.py: random -inf half-spaces (SVM) and trust regions; NORA with the gates on
     the device equals NORA with libsvm + numpy masks."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import fuzz_gates
     bad, n_inf = fuzz_gates.run(n_cases=20, seed=5)
     assert bad == 0 and n_inf > 1000

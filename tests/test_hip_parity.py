@@ -498,7 +498,7 @@ def test_small_batch_paths_agree_with_the_panel_path(dev, M):
 
 
 def test_capacity_does_not_grow_when_only_the_dimension_changes(dev):
-    """Regression (found by tools/fuzz_parity.py): alternating small / large d used to enlarge the
+    """Regression (found by tests/tools/fuzz_parity.py): alternating small / large d used to enlarge the
     N x N buffers by 12.5 % each time until the device ran out of memory."""
     rng = np.random.default_rng(0)
     for it in range(80):

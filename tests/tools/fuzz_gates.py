@@ -6,7 +6,7 @@ import os
 import sys
 import time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 KSPEC = {0: "RBF", 2: {"Matern": {"nu": 1.5}}, 3: {"Matern": {"nu": 2.5}}}
 

@@ -8,7 +8,7 @@ import pickle
 import sys
 import time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import gpry_oracle as orc  # noqa: E402
 
 KSPEC = {0: "RBF", 1: {"Matern": {"nu": 0.5}}, 2: {"Matern": {"nu": 1.5}}, 3: {"Matern": {"nu": 2.5}}}

@@ -6,7 +6,7 @@ import os
 import sys
 import time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gpry_amd import _lib  # noqa: E402
 from oracle import gpry_oracle as orc  # noqa: E402
 

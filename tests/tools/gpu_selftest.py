@@ -13,7 +13,7 @@ import traceback
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from gpry_amd import _lib  # noqa: E402
 from oracle import gpry_oracle as orc  # noqa: E402
