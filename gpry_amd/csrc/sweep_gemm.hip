@@ -406,7 +406,14 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
     bool valid;
     {
         const int s = (q >> 6) * 8 + vx, within = q & 63;
-        const int si = nsi - 1 - s / nsj, sj = s % nsj;
+        // tile_map bit 8: candidate super-column outermost (the K*^T columns of a super-column stay in
+        // the Infinity Cache while the nsi row super-tiles that need them run back to back)
+        // (needs nsi | 8: a round of 8 super-tiles, one per XCD, then covers 8/nsi super-columns; the row
+        // index rotates with the round so that every XCD sees every row length)
+        const bool col_outer = ((g.tile_map >> 8) & 1) && nsi <= 8 && 8 % nsi == 0;
+        const int rnd = s >> 3;
+        const int si = col_outer ? nsi - 1 - ((vx % nsi + rnd) % nsi) : nsi - 1 - s / nsj;
+        const int sj = col_outer ? rnd * (8 / nsi) + vx / nsi : s % nsj;
         ti = (si << ta) + (within >> tc);
         tj = (sj << tc) + (within & ((1 << tc) - 1));
         valid = s < nsi * nsj && ti < tiles_m && tj < tiles_n;
