@@ -341,6 +341,45 @@ def test_full_size_properties(dev, N, d, kid):
         assert abs(fd - grad[k]) <= 1e-5 * max(1.0, abs(grad[k]))
 
 
+@pytest.mark.parametrize("N", [1100, 1250, 1500, 1600, 2100, 2400, 3100])
+def test_factor_chain_at_ragged_block_counts(dev, N):
+    """Padded sizes that are not powers of two (Np = 1152 ... 3200): the last outer block of the Cholesky
+    is narrower than the others, the V = L^-1 tree has ragged nodes (levels that mix the DMA-pipelined
+    and the register-staged GEMM), split-K factors change from level to level.  Size-independent
+    properties, and the gradient traces (which read K^-1) against finite differences of the LML."""
+    d = 5
+    rng = np.random.default_rng(N)
+    X = rng.uniform(0, 1, (N, d))
+    y = np.sin(4 * X).sum(1) + 0.1 * rng.standard_normal(N)
+    alpha = np.full(N, 1e-4)
+    theta = np.log(np.array([3.0, 0.3, 0.4, 0.5, 0.6, 0.7]))
+    dev.set_train(X, y, alpha)
+    dev.set_theta(3, theta)
+    assert dev.factorize() == 0
+    L, V, a = dev.get_factor()
+    K = dev.kernel_train(add_alpha=True)
+    assert relmax(L @ L.T, K) < 1e-13
+    assert np.max(np.abs(V @ L - np.eye(N))) < 1e-8
+    assert np.all(np.triu(V, 1) == 0.0) and np.all(np.triu(L, 1) == 0.0)
+    assert relmax(K @ a, y) < 1e-7
+    lml, grad, info = dev.lml(theta, True)
+    assert info == 0
+    sign, logdet = np.linalg.slogdet(K)
+    ref = -0.5 * y @ a - 0.5 * logdet - 0.5 * N * np.log(2 * np.pi)
+    assert abs(lml - ref) <= 1e-10 * abs(ref)
+    for k in (0, 2, d):
+        e = np.zeros(d + 1)
+        e[k] = 1e-5
+        fd = (dev.lml(theta + e, False)[0] - dev.lml(theta - e, False)[0]) / 2e-5
+        assert abs(fd - grad[k]) <= 2e-5 * max(1.0, abs(grad[k]))
+    # the register-staged engine gives the same factor bit for bit (same accumulation order)
+    dev.set_option("gemm_dma", 0)
+    assert dev.factorize() == 0
+    L0, V0, _ = dev.get_factor()
+    dev.set_option("gemm_dma", 1)
+    assert np.array_equal(L0, L) and np.array_equal(V0, V)
+
+
 def test_rccl_communicator_single_rank(dev):
     """RCCL entry points on a 1-rank communicator (the multi-rank merge logic is covered by
     tests/test_multirank_cpu.py; 8-GPU runs are the driver's)."""
