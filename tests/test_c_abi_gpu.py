@@ -103,3 +103,48 @@ def test_error_returns_of_the_c_abi():
     assert lib.gpry_predict(h, ptr(X), 5, None, ptr(mean), None) == 0
     np.testing.assert_allclose(mean, y[:5], atol=1e-3)
     dev.close()
+
+
+def test_two_contexts_driven_from_two_threads():
+    """SURVEY.md 8b "Threading": a context is not re-entrant, but distinct contexts may be driven from
+    distinct threads (ctypes releases the GIL).  Two models on one device, worked concurrently, give
+    bit for bit what each gives alone."""
+    import threading
+    from gpry_amd import _lib
+
+    def work(dev, seed, out):
+        rng = np.random.default_rng(seed)
+        N, d, M = 700 + 100 * seed, 4 + seed, 5000
+        X = rng.uniform(0, 1, (N, d))
+        y = np.sin(3 * X).sum(1)
+        Xc = rng.uniform(0, 1, (M, d))
+        theta = np.log(np.array([2.0] + [0.3 + 0.05 * k for k in range(d)]))
+        res = []
+        for _ in range(3):
+            dev.set_train(X, y, np.full(N, 1e-6))
+            dev.set_theta(3, theta)
+            assert dev.factorize() == 0
+            lml, grad, info = dev.lml(theta, True)
+            sw = dev.sweep_logexp(Xc, 0.2, float(y.max()), 1e-3)
+            top, bound = dev.sweep_topk(8)
+            res.append((lml, grad.copy(), sw["acq"].copy(), top["idx"].copy(), bound))
+        out[seed] = res
+
+    devs = [_lib.Device(0), _lib.Device(0)]
+    alone, together = {}, {}
+    for s in (0, 1):
+        work(devs[s], s, alone)
+    threads = [threading.Thread(target=work, args=(devs[s], s, together)) for s in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for s in (0, 1):
+        assert len(together[s]) == 3
+        for (l0, g0, a0, i0, b0), (l1, g1, a1, i1, b1) in zip(alone[s], together[s]):
+            assert l0 == l1 and b0 == b1
+            np.testing.assert_array_equal(g0, g1)
+            np.testing.assert_array_equal(a0, a1)
+            np.testing.assert_array_equal(i0, i1)
+    for dv in devs:
+        dv.close()
