@@ -48,6 +48,27 @@ def test_host_fit_logic_reproduces_reference_fits(kid, N):
     np.testing.assert_allclose(s, g[p + "std_simple"], rtol=1e-3, atol=1e-4)
 
 
+def test_concurrent_restarts_select_the_sequential_optimum(monkeypatch):
+    """The optimiser runs of a fit are shared by several device contexts / host threads
+    (GaussianProcessRegressor._concurrent_restarts); the start points, every run and the selected
+    optimum are those of the reference's sequential loop (GPRY_HIP_FIT_CONTEXTS=1)."""
+    g = load_golden("fit")
+    p = "f6_k3_"
+    X, y = g[p + "X"], g[p + "y"]
+    out = {}
+    for n_ctx in ("1", "3", "2"):
+        monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", n_ctx)
+        gpr = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=5, random_state=7)
+        gpr.append_to_data(X[:60], y[:60], fit_gpr=True)
+        assert len(gpr._fit_devs) == int(n_ctx) - 1
+        out[n_ctx] = (gpr.kernel_.theta.copy(), gpr.log_marginal_likelihood_value_, gpr.n_eval_loglike,
+                      gpr.predict(g[p + "Xc"]))
+    for n_ctx in ("3", "2"):
+        np.testing.assert_array_equal(out[n_ctx][0], out["1"][0])
+        assert out[n_ctx][1] == out["1"][1] and out[n_ctx][2] == out["1"][2]
+        np.testing.assert_array_equal(out[n_ctx][3], out["1"][3])
+
+
 def test_host_append_fixed_theta_reproduces_reference_factor():
     """F8 through the host mirror: frozen theta, re-fitted pre-processors, lazy factor."""
     from gpry_amd.kernels import clone

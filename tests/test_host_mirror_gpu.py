@@ -53,6 +53,24 @@ def test_f6_fit_full_and_simple_vs_reference(kid, N):
     assert gpr.n_eval == 2 * len(Xc) and gpr.n_eval_loglike > 10
 
 
+def test_concurrent_restarts_select_the_sequential_optimum_on_the_device(monkeypatch):
+    """Three device contexts driven from three host threads share the restarts of one fit: same
+    hyper-parameters, LML and evaluation count as the sequential loop, bit for bit."""
+    g = load_golden("fit")
+    p = "f6_k3_"
+    X, y = g[p + "X"], g[p + "y"]
+    out = {}
+    for n_ctx in ("1", "3"):
+        monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", n_ctx)
+        gpr = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=6, random_state=11)
+        gpr.append_to_data(X[:60], y[:60], fit_gpr=True)
+        out[n_ctx] = (gpr.kernel_.theta.copy(), gpr.log_marginal_likelihood_value_, gpr.n_eval_loglike,
+                      gpr.predict(g[p + "Xc"]))
+    np.testing.assert_array_equal(out["3"][0], out["1"][0])
+    assert out["3"][1] == out["1"][1] and out["3"][2] == out["1"][2]
+    np.testing.assert_array_equal(out["3"][3], out["1"][3])
+
+
 def test_f9_config1_curved_degeneracy():
     """Config 1 (N=64, 2-d curved degeneracy, plumbing).  The multi-restart optimum of this
     multi-modal LML depends on 1e-13 objective differences, so the fit is

@@ -19,14 +19,20 @@ gpr = GaussianProcessRegressor(kernel={"Matern": {"nu": 2.5}}, bounds=bounds, no
                                account_for_inf=None, random_state=3, n_restarts_optimizer=total, verbose=0)
 gpr.append_to_data(X[:-d], y[:-d], fit_gpr="simple")          # a fitted model to start from
 share = int(split_number_for_parallel_processes(total, world)[0])
-gpr.device.timing_reset()
-n0 = gpr.n_eval_loglike
-t0 = time.perf_counter()
-lml, best, _ = fit_gpr_parallel(gpr, X[-d:], y[-d:], comm=None, fit="full", n_restarts=share)
-dt = time.perf_counter() - t0
-ne = gpr.n_eval_loglike - n0
-print(f"N={N} d={d}: {share} restarts (1/{world} of {total}) in {dt:.2f} s, {ne} LML+grad evaluations, "
-      f"{dt / ne * 1e3:.1f} ms each; best lml {lml:.3f}")
-for k in ("potrf", "trtri", "lauum", "lml_traces", "kernel_build"):
-    ms, n = gpr.device.timing(k)
-    print(f"  {k}: {ms / max(n, 1):.2f} ms avg over {n}")
+import copy  # noqa: E402
+for n_ctx in ("1", "2", "3"):       # device contexts (host threads) sharing the restarts of this rank
+    os.environ["GPRY_HIP_FIT_CONTEXTS"] = n_ctx
+    g2 = copy.deepcopy(gpr)
+    g2.predict(X[:2])                                            # factor in place, as in a running loop
+    g2.device.timing_reset()
+    n0 = g2.n_eval_loglike
+    t0 = time.perf_counter()
+    lml, best, _ = fit_gpr_parallel(g2, X[-d:], y[-d:], comm=None, fit="full", n_restarts=share)
+    dt = time.perf_counter() - t0
+    ne = g2.n_eval_loglike - n0
+    print(f"N={N} d={d}, {n_ctx} context(s): {share} restarts (1/{world} of {total}) in {dt:.2f} s, {ne} LML+grad "
+          f"evaluations, {dt / ne * 1e3:.1f} ms each (aggregate); best lml {lml:.6f}")
+    if n_ctx == "1":
+        for k in ("potrf", "trtri", "lauum", "lml_traces", "kernel_build"):
+            ms, n = g2.device.timing(k)
+            print(f"  {k}: {ms / max(n, 1):.2f} ms avg over {n}")
