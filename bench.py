@@ -310,6 +310,17 @@ def main():
                          "frac": kb_gbps / HBM_PEAK_GBPS, "avg_launch_ms": kb_ms / max(kb_n, 1),
                          "bytes_per_launch": 8.0 * N * N + 8.0 * N * d},
     }
+    # MFMA utilisation of the Cholesky (north_star): N^3/3 flop per factorisation over the average
+    # duration of the `potrf` stage (64 fused panel steps + 15 MFMA trailing updates at N=4096), and of
+    # the whole factor chain of one LML+gradient call (potrf + V = L^-1 + K^-1 = V^T V: N^3 flop)
+    po_ms, po_n = T["potrf"]
+    if po_n:
+        tf = (float(Np) ** 3 / 3.0) / (po_ms / po_n * 1e-3) / 1e12
+        chain_ms = sum(T[k][0] / max(T[k][1], 1) for k in ("potrf", "trtri", "lauum"))
+        result["cholesky"] = {"bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": tf / F64_MFMA_PEAK_TFLOPS, "avg_ms": po_ms / po_n, "calls": po_n,
+                              "flops_per_call": float(Np) ** 3 / 3.0,
+                              "factor_chain_tflops": float(Np) ** 3 / (chain_ms * 1e-3) / 1e12}
     if rank == 0:
         # the build is one 40-us launch per LML evaluation: two events around a single launch also
         # time the dispatch gap, so quote the steady-state duration (50 launches back to back) too
