@@ -39,6 +39,7 @@ class KBSession:
         self.masked = np.empty(0, bool)  # classifier says "infinite": std is 0
         self._index = {}
         self._gram = {}
+        self._last_cond = None           # most recent conditioned model (prefix re-use)
         self.C = float(np.exp(gpr._device_theta()[1][0]))
         self.std_y = gpr._y_affine()[1]
 
@@ -124,7 +125,17 @@ class ConditionedGPR:
         self.l = np.zeros(t_n)
         alpha = session.noise_alpha() if t_n else 0.0
         self._rows = []
+        # RankedPool asks for the models of pool[:1], pool[:2], ... in turn: border rows (and candidate
+        # weights) that the previous model already holds for a common prefix are copied, not recomputed
+        prev, t0 = session._last_cond, 0
+        if prev is not None and 0 < len(prev.idx) <= t_n and prev.idx == self.idx[:len(prev.idx)]:
+            t0 = len(prev.idx)
+            self.c[:t0, :t0] = prev.c
+            self.l[:t0] = prev.l
+            self._rows = list(prev._rows)
         for t, p in enumerate(self.idx):
+            if t < t0:
+                continue
             G, kv = session.gram(p)
             self._rows.append((G, kv))
             acc = 0.0
@@ -141,6 +152,15 @@ class ConditionedGPR:
                     "GaussianProcessRegressor estimator.")
             self.l[t] = np.sqrt(l2)
         self._W = np.zeros((t_n, 0))
+        if t0 and prev._W.shape[1]:
+            have = prev._W.shape[1]
+            W = np.zeros((t_n, have))
+            W[:t0] = prev._W
+            for t in range(t0, t_n):
+                G, kv = session.gram(self.idx[t])
+                W[t] = (kv[:have] - G[:have] - self.c[t, :t] @ W[:t]) / self.l[t]
+            self._W = W
+        session._last_cond = self
         self.n_eval = 0
 
     def _weights(self, n):
