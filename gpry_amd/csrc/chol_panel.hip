@@ -390,10 +390,12 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
     // receives its rank-128 updates in the same order from the same kernel: bit-identical.
     // Outer block: the trailing matrix is read and written once per outer block, and a trailing update
     // costs >= 40 us however small it is, so wider blocks halve both; the panel steps pay for it with
-    // up to three extra 64-column chunks in their left-looking update.  256 from Np = 1024 on
-    // (measured, tools/prof_factor.py); the look-ahead schedule keeps 128.
+    // up to three extra 64-column chunks in their left-looking update.  With the DMA-pipelined
+    // trailing update (36 us for a lone tile) the crossover is at Np ~ 6144 (tools/prof_factor.py N d reps ab:
+    // 128 / 256 columns: 1.16 / 1.23 ms at 2048, 2.61 / 2.71 at 4096, 4.80 / 4.80 at 6144, 8.12 / 7.84 at
+    // 8192); the look-ahead schedule keeps 128.
     const bool la = ctx->opt_chol_lookahead && ctx->stream2 != nullptr && Np > 512;
-    const int64_t OB = la ? 128 : (ctx->opt_chol_outer > 0 ? ctx->opt_chol_outer : (Np >= 1024 ? 256 : 128));
+    const int64_t OB = la ? 128 : (ctx->opt_chol_outer > 0 ? ctx->opt_chol_outer : (Np > 6144 ? 256 : 128));
     bool rest_pending = false;
     if (la) {
         const size_t need = 2 * (size_t)(Np / 128);
