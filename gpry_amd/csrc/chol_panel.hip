@@ -63,45 +63,40 @@ __device__ __forceinline__ double pivot_rsqrt(double x) {
     return r;
 }
 
-// Cholesky of the 16x16 block at S (LDS, stride PLD) by one full wave: lane (i, cq) keeps
-// S[i][4cq .. 4cq+3] in registers; column j is finished with three shuffles per lane.
-// Writes L (lower, zeros above).  Returns the first failing column + 1 (0 if ok).
+// Cholesky of the 16x16 block at S (LDS, stride PLD) by one wave, one ROW per lane (lanes 16..63 repeat
+// lanes 0..15): column j takes the pivot and the scaled column entries L[c][j] of the other rows through
+// v_readlane (they become SGPR operands of the rank-1 update), no LDS shuffles and no per-element selects.
+// A lone wave issues one FP64 instruction every ~12 cycles whatever its active lanes, so what counts is
+// the instruction count: per column 2 readlanes + 1/sqrt (9) + pivot (4) + scale (1) + (15 - j) x (2
+// readlanes + 1 fma) + 4 selects = ~38 on average instead of 64 in the 4-lanes-per-row layout with five
+// ds_bpermute broadcasts per column.  Same arithmetic per element (reciprocal-pivot scaling as dpotf2).
+// Writes L (lower, zeros above) and the reciprocal pivots.  Returns the first failing column + 1 (0 if ok).
 __device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
-    const int i = lane & 15, cq = lane >> 4;
-    double x[4];
+    const int i = lane & 15;
+    double x[16];
 #pragma unroll
-    for (int c = 0; c < 4; c++) x[c] = S[i * PLD + cq * 4 + c];
+    for (int c = 0; c < 16; c++) x[c] = S[i * PLD + c];
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const int jq = j >> 2, jj = j & 3;
-        // Per column the dependency chain is: pivot (v_readlane, a few cycles) -> 1/sqrt (v_rsq + 2
-        // Newton steps, ~90 cycles) running next to ONE round of five independent ds_bpermute
-        // broadcasts of the raw column (their scaling by the reciprocal pivot happens afterwards).
-        // Section stamps (tools/panel_sections.py): the version with the pivot through a shuffle
-        // and libm's rsqrt (= sqrt + divide) on the chain took 6.7k cycles per 16x16 block.
-        const double djj = readlane_f64(x[jj], j + 16 * jq);   // S[j][j]
-        const double sij = __shfl(x[jj], i + 16 * jq);         // S[i][j]
-        double scj[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; cc++) scj[cc] = __shfl(x[jj], cq * 4 + cc + 16 * jq);   // S[c][j]
-        if (!(djj > 0.0) && bad == 0) bad = j + 1;    // dpotf2: ajj <= 0 or NaN
-        // reciprocal pivot (dpotf2 likewise scales the column by 1/ajj)
+        const double djj = readlane_f64(x[j], j);              // S[j][j], wave-uniform
+        if (!(djj > 0.0) && bad == 0) bad = j + 1;              // dpotf2: ajj <= 0 or NaN
         const double rinv = pivot_rsqrt(djj);
         double piv = djj * rinv;
-        piv = fma(fma(-piv, piv, djj), 0.5 * rinv, piv);   // one Newton step: sqrt to the last bit (off the chain)
-        const double lij = sij * rinv;
+        piv = fma(fma(-piv, piv, djj), 0.5 * rinv, piv);        // one Newton step: sqrt to the last bit
+        const double lij = x[j] * rinv;                         // L[i][j] (rows i < j: unused values)
 #pragma unroll
-        for (int cc = 0; cc < 4; cc++) {
-            const int c = cq * 4 + cc;
-            const double lcj = scj[cc] * rinv;         // L[c][j]
-            if (c > j) x[cc] = fma(-lij, lcj, x[cc]);
+        for (int c = j + 1; c < 16; c++) {
+            const double lcj = readlane_f64(lij, c);            // L[c][j], wave-uniform
+            x[c] = fma(-lij, lcj, x[c]);                        // rows i < c update entries nobody reads
         }
-        if (cq == jq) x[jj] = (i == j) ? piv : (i > j ? lij : 0.0);
-        if (cq == jq && i == j) rd[j] = rinv;          // reciprocal pivots for the solves
+        x[j] = (i == j) ? piv : (i > j ? lij : 0.0);
+        if (lane == j) rd[j] = rinv;                            // reciprocal pivots for the solves
     }
+    if (lane < 16) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) S[i * PLD + cq * 4 + c] = x[c];
+        for (int c = 0; c < 16; c++) S[i * PLD + c] = x[c];
+    }
     return bad;
 }
 
