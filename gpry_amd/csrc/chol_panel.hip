@@ -52,24 +52,40 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(x) for a positive, normal x: v_rsq_f64 (~26 good bits) + two Newton steps.  The libm
-// rsqrt is a sqrt followed by a division -- ~250 cycles on the 16-step pivot chain.
+// 1/sqrt(x) for a positive, normal x: v_rsq_f64 (~26 good bits) + ONE third-order step
+//   e = 1 - x r^2,  r <- r + r e (1/2 + 3/8 e)          (error O(e^3): below the rounding of a double)
+// = four dependent FP64 operations on the 16-step pivot chain instead of the six of two Newton steps
+// (libm's rsqrt is a sqrt followed by a division -- ~250 cycles).
 __device__ __forceinline__ double pivot_rsqrt(double x) {
-    double r = __builtin_amdgcn_rsq(x);
-    double e = fma(-x * r, r, 1.0);
-    r = fma(0.5 * r, e, r);
-    e = fma(-x * r, r, 1.0);
-    r = fma(0.5 * r, e, r);
-    return r;
+    const double r = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * r, r, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    const double q = r * e;
+    return fma(q, p, r);
 }
 
+// acc += a[lane c of this lane's 16-lane row] * b   (v_fmac_f64 with a DPP row_newbcast source; c is a
+// constant after unrolling, the switch folds)
+#define FMAC_BCAST_CASE(C) case C: asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #C " row_mask:0xf bank_mask:0xf" \
+                                                : "+v"(acc) : "v"(a), "v"(b)); break;
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double a, double b, int c) {
+    switch (c) {
+        FMAC_BCAST_CASE(0) FMAC_BCAST_CASE(1) FMAC_BCAST_CASE(2) FMAC_BCAST_CASE(3) FMAC_BCAST_CASE(4) FMAC_BCAST_CASE(5)
+        FMAC_BCAST_CASE(6) FMAC_BCAST_CASE(7) FMAC_BCAST_CASE(8) FMAC_BCAST_CASE(9) FMAC_BCAST_CASE(10)
+        FMAC_BCAST_CASE(11) FMAC_BCAST_CASE(12) FMAC_BCAST_CASE(13) FMAC_BCAST_CASE(14) FMAC_BCAST_CASE(15)
+        default: break;
+    }
+}
+#undef FMAC_BCAST_CASE
+
 // Cholesky of the 16x16 block at S (LDS, stride PLD) by one wave, one ROW per lane (lanes 16..63 repeat
-// lanes 0..15): column j takes the pivot and the scaled column entries L[c][j] of the other rows through
-// v_readlane (they become SGPR operands of the rank-1 update), no LDS shuffles and no per-element selects.
-// A lone wave issues one FP64 instruction every ~12 cycles whatever its active lanes, so what counts is
-// the instruction count: per column 2 readlanes + 1/sqrt (9) + pivot (4) + scale (1) + (15 - j) x (2
-// readlanes + 1 fma) + 4 selects = ~38 on average instead of 64 in the 4-lanes-per-row layout with five
-// ds_bpermute broadcasts per column.  Same arithmetic per element (reciprocal-pivot scaling as dpotf2).
+// lanes 0..15): column j takes the pivot through v_readlane and the scaled column entries L[c][j] of the
+// other rows as DPP row broadcasts inside the multiply-add of the rank-1 update: no LDS shuffles, no
+// per-element selects.  A lone wave issues in order, one FP64 instruction every ~12 cycles whatever its
+// active lanes, so what counts is the instruction count: per column 2 readlanes + 1/sqrt (5) + pivot (4)
+// + scale (2) + (15 - j) fused multiply-adds + 4 selects = ~25 on average (64 in the 4-lanes-per-row
+// layout with five ds_bpermute broadcasts per column, 38 with v_readlane broadcasts).  Same arithmetic
+// per element (reciprocal-pivot scaling as dpotf2).
 // Writes L (lower, zeros above) and the reciprocal pivots.  Returns the first failing column + 1 (0 if ok).
 __device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
     const int i = lane & 15;
@@ -84,12 +100,13 @@ __device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
         const double rinv = pivot_rsqrt(djj);
         double piv = djj * rinv;
         piv = fma(fma(-piv, piv, djj), 0.5 * rinv, piv);        // one Newton step: sqrt to the last bit
-        const double lij = x[j] * rinv;                         // L[i][j] (rows i < j: unused values)
+        double lij = x[j] * rinv;                               // L[i][j] (rows i < j: unused values)
+        double nlij = -lij;
+        // x[c] -= L[i][j] * L[c][j]: the factor of row c is lane c of every 16-lane DPP row (the four
+        // rows of the wave are replicas), fused into the multiply-add as a row_newbcast operand
+        asm volatile("s_nop 1" : "+v"(lij), "+v"(nlij));        // VALU write -> DPP read of the same VGPR
 #pragma unroll
-        for (int c = j + 1; c < 16; c++) {
-            const double lcj = readlane_f64(lij, c);            // L[c][j], wave-uniform
-            x[c] = fma(-lij, lcj, x[c]);                        // rows i < c update entries nobody reads
-        }
+        for (int c = j + 1; c < 16; c++) fmac_row_bcast(x[c], lij, nlij, c);   // rows i < c: entries nobody reads
         x[j] = (i == j) ? piv : (i > j ? lij : 0.0);
         if (lane == j) rd[j] = rinv;                            // reciprocal pivots for the solves
     }
@@ -100,47 +117,30 @@ __device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
     return bad;
 }
 
-// x <- x * L^-T for the 16 rows at Xr against the 16x16 lower factor at L (both LDS):
-// lanes 0..15 take one row each (forward substitution, reciprocal-pivot scaling)
+// x <- x * L^-T for the rows at Xr against the 16x16 lower factor at L (both LDS): one row of X per lane
+// (ROWS = 16: lanes 0..15, the other three 16-lane rows repeat them; ROWS = 64: all lanes).  Forward
+// substitution with reciprocal-pivot scaling.  Lane l also holds row (l & 15) of the factor and its
+// reciprocal pivot: L[c2][c] and 1/L[c][c] reach the arithmetic as DPP row broadcasts inside the
+// multiply-adds -- 16 + 120 FP64 instructions and no LDS traffic in the 16-step chain (the version
+// with 152 broadcast LDS reads, even fetched ahead in two batches, took 3.0k cycles per call).
 template <int ROWS = 16>
 __device__ __forceinline__ void trsm16_rows(double* Xr, const double* L, const double* rd, int lane) {
     const int i = ROWS == 64 ? lane : (lane & 15);    // 64: one row per lane; 16: four copies
-    double x[16];
+    const int li = lane & 15;
+    double x[16], lr[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = Xr[i * PLD + c];
-    // The factor entries are the same for every lane (broadcast LDS reads) and do not depend on x:
-    // they are fetched in two batches (columns 0..7: 92 values, columns 8..15: 28 values) BEFORE
-    // the substitution steps that use them, so the 16-step dependency chain is mul + fma only
-    // (with the reads inside the chain every step paid an LDS round trip: 3.0k cycles per call).
-    {
-        double l[8][16], r8[8];
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            r8[c] = rd[c];
+    for (int c = 0; c < 16; c++) lr[c] = L[li * PLD + c];
+    const double myr = rd[li];
 #pragma unroll
-            for (int c2 = c + 1; c2 < 16; c2++) l[c][c2] = L[c2 * PLD + c];
-        }
+    for (int c = 0; c < 16; c++) {
+        double xc = 0.0;
+        fmac_row_bcast(xc, myr, x[c], c);                       // x[c] / L[c][c]  (v_mul_f64 has no DPP form)
+        x[c] = xc;
+        const double nx = -xc;
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            x[c] = x[c] * r8[c];
-#pragma unroll
-            for (int c2 = c + 1; c2 < 16; c2++) x[c2] = fma(-x[c], l[c][c2], x[c2]);
-        }
-    }
-    {
-        double l[8][16], r8[8];
-#pragma unroll
-        for (int c = 8; c < 16; c++) {
-            r8[c - 8] = rd[c];
-#pragma unroll
-            for (int c2 = c + 1; c2 < 16; c2++) l[c - 8][c2] = L[c2 * PLD + c];
-        }
-#pragma unroll
-        for (int c = 8; c < 16; c++) {
-            x[c] = x[c] * r8[c - 8];
-#pragma unroll
-            for (int c2 = c + 1; c2 < 16; c2++) x[c2] = fma(-x[c], l[c - 8][c2], x[c2]);
-        }
+        for (int c2 = c + 1; c2 < 16; c2++) fmac_row_bcast(x[c2], lr[c], nx, c2);   // x[c2] -= x[c] L[c2][c]
     }
     if (lane < ROWS) {
 #pragma unroll
