@@ -82,8 +82,8 @@ __device__ __forceinline__ void fmac_row_bcast(double& acc, double a, double b, 
 // lanes 0..15): column j takes the pivot through v_readlane and the scaled column entries L[c][j] of the
 // other rows as DPP row broadcasts inside the multiply-add of the rank-1 update: no LDS shuffles, no
 // per-element selects.  A lone wave issues in order, one FP64 instruction every ~12 cycles whatever its
-// active lanes, so what counts is the instruction count: per column 2 readlanes + 1/sqrt (5) + pivot (4)
-// + scale (2) + (15 - j) fused multiply-adds + 4 selects = ~25 on average (64 in the 4-lanes-per-row
+// active lanes, so what counts is the instruction count: per column 2 readlanes + 1/sqrt (5) + scale (2)
+// + (15 - j) fused multiply-adds + 6 selects = ~23 on average (64 in the 4-lanes-per-row
 // layout with five ds_bpermute broadcasts per column, 38 with v_readlane broadcasts).  Same arithmetic
 // per element (reciprocal-pivot scaling as dpotf2).
 // Writes L (lower, zeros above) and the reciprocal pivots.  Returns the first failing column + 1 (0 if ok).
@@ -93,13 +93,13 @@ __device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = S[i * PLD + c];
     int bad = 0;
+    double my_d = 1.0, my_r = 1.0;      // this lane's own pivot and its reciprocal root (row i = column i)
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const double djj = readlane_f64(x[j], j);              // S[j][j], wave-uniform
         if (!(djj > 0.0) && bad == 0) bad = j + 1;              // dpotf2: ajj <= 0 or NaN
         const double rinv = pivot_rsqrt(djj);
-        double piv = djj * rinv;
-        piv = fma(fma(-piv, piv, djj), 0.5 * rinv, piv);        // one Newton step: sqrt to the last bit
+        if (i == j) { my_d = djj; my_r = rinv; }
         double lij = x[j] * rinv;                               // L[i][j] (rows i < j: unused values)
         double nlij = -lij;
         // x[c] -= L[i][j] * L[c][j]: the factor of row c is lane c of every 16-lane DPP row (the four
@@ -107,12 +107,17 @@ __device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
         asm volatile("s_nop 1" : "+v"(lij), "+v"(nlij));        // VALU write -> DPP read of the same VGPR
 #pragma unroll
         for (int c = j + 1; c < 16; c++) fmac_row_bcast(x[c], lij, nlij, c);   // rows i < c: entries nobody reads
-        x[j] = (i == j) ? piv : (i > j ? lij : 0.0);
-        if (lane == j) rd[j] = rinv;                            // reciprocal pivots for the solves
+        x[j] = i > j ? lij : 0.0;                               // the diagonal entry follows below
     }
+    // L[i][i] = sqrt(d_i) = d_i / sqrt(d_i) refined by one Newton step (to the last bit), all sixteen at
+    // once, one per lane, instead of four FP64 instructions in every column step
+    double piv = my_d * my_r;
+    piv = fma(fma(-piv, piv, my_d), 0.5 * my_r, piv);
     if (lane < 16) {
 #pragma unroll
         for (int c = 0; c < 16; c++) S[i * PLD + c] = x[c];
+        S[i * PLD + i] = piv;
+        rd[i] = my_r;                                           // reciprocal pivots for the solves
     }
     return bad;
 }
