@@ -5,9 +5,10 @@
 //                       recomputes it: 64x64, cheaper than a second launch + dependency)
 //     X   <- B * Lkk^-T                                                     (dtrsm R,L,T,N)
 // Inside the workgroup everything is blocked by 16: the 16x16 diagonal factors run in a
-// single wave (shuffles), the 16-wide triangular solves are lane-per-row substitutions
-// (same operation order as LAPACK dpotf2/dtrsm: scale by the reciprocal pivot), and all
-// rank-16 updates are v_mfma_f64_16x16x4_f64.  LDS images use a row stride of 66 doubles:
+// single wave and the 16-wide triangular solves are lane-per-row substitutions, both with DPP
+// row broadcasts as multiply-add operands (same operation order as LAPACK dpotf2/dtrsm: scale
+// by the reciprocal pivot); all rank-16 updates are v_mfma_f64_16x16x4_f64; the four waves run
+// the 64x64 factor as a dataflow on LDS flags.  LDS images use a row stride of 66 doubles:
 // MFMA fragment reads (16 rows x {k, k+1}) then hit 32 distinct bank pairs.
 #include "common.h"
 
