@@ -228,8 +228,12 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np) {
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(V, 0, sizeof(double) * Np * Np, st));
-    hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)(Np / 64)), dim3(64), 0, st, L, V, Np, ctx->dinfo);
-    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->opt_trtri_diag_v1) {
+        hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)(Np / 64)), dim3(64), 0, st, L, V, Np, ctx->dinfo);
+        HIP_TRY(ctx, hipGetLastError());
+    } else {
+        GPRY_TRY(launch_trtri_diag(ctx, L, V, Np, st));
+    }
     TrtriPlan* pl = nullptr;
     GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
     for (size_t lev = 0; lev < pl->count.size(); lev++) {

@@ -200,6 +200,78 @@ __device__ __forceinline__ void store_block(double* __restrict__ G, int64_t ld, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// V_bb = L_bb^-1 for every 64x64 diagonal block of L (first stage of V = L^-1): one workgroup of four
+// waves per block.  Wave w inverts the 16x16 diagonal block w by a forward substitution on the identity
+// (trsm16_rows: DPP broadcasts, one reciprocal per pivot), then two doubling levels (16 -> 32 -> 64)
+// of V21 = -V22 (L21 V11) as 16x16 MFMA tiles in LDS; V is kept together with its transpose because
+// the tile product takes both operands row-wise.  (The single-wave version -- lane c solving L x = e_c
+// with 2016 multiply-adds and 64 divisions from broadcast LDS reads -- took 39 us, a quarter of the
+// factorisation latency at N <= 128.)
+__device__ __forceinline__ void tile_store_t(double* T, v4d v, int lane) {       // T[col][row] = v
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; q++) T[r * PLD + g + 4 * q] = v[q];
+}
+__global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restrict__ L, double* __restrict__ V,
+                                                           int64_t ld, const int* info) {
+    __shared__ __attribute__((aligned(16))) double sL[64 * PLD];
+    __shared__ __attribute__((aligned(16))) double sV[64 * PLD];
+    __shared__ __attribute__((aligned(16))) double sVt[64 * PLD];
+    __shared__ __attribute__((aligned(16))) double sTt[64 * PLD];
+    __shared__ double sRd[64];
+    if (*info != 0) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    for (int e = t; e < 64 * 64; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        sL[i * PLD + j] = (j <= i) ? L[(b0 + i) * ld + b0 + j] : 0.0;
+        sV[i * PLD + j] = 0.0;
+        sVt[i * PLD + j] = (i == j) ? 1.0 : 0.0;     // the identity the substitutions start from
+    }
+    if (t < 64) sRd[t] = 1.0 / L[(b0 + t) * ld + b0 + t];
+    __syncthreads();
+    {   // wave w: X = I L_ww^-T = (L_ww^-1)^T in place in sVt, then its transpose into sV
+        double* Xt = sVt + (w * 16) * PLD + w * 16;
+        trsm16_rows(Xt, sL + (w * 16) * PLD + w * 16, sRd + w * 16, lane);
+        wave_fence();
+        for (int e = lane; e < 256; e += 64) {
+            const int i = e >> 4, j = e & 15;
+            sV[(w * 16 + i) * PLD + w * 16 + j] = Xt[j * PLD + i];
+        }
+    }
+    __syncthreads();
+    for (int h = 16; h <= 32; h *= 2) {
+        const int hb = h / 16, ntile = (64 / (2 * h)) * hb * hb;
+        for (int id = w; id < ntile; id += 4) {        // T = L21 V11, stored transposed
+            const int p = id / (hb * hb), m = (id % (hb * hb)) / hb, n = id % hb;
+            const int lo = p * 2 * h, mid = lo + h;
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            acc = mfma_nt16<false>(acc, sL + (mid + 16 * m) * PLD + lo, sVt + (lo + 16 * n) * PLD + lo, h, lane);
+            tile_store_t(sTt + (lo + 16 * n) * PLD + 16 * m, acc, lane);
+        }
+        __syncthreads();
+        for (int id = w; id < ntile; id += 4) {        // V21 = -V22 T (and its transpose)
+            const int p = id / (hb * hb), m = (id % (hb * hb)) / hb, n = id % hb;
+            const int lo = p * 2 * h, mid = lo + h;
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            acc = mfma_nt16<true>(acc, sV + (mid + 16 * m) * PLD + mid, sTt + (lo + 16 * n) * PLD, h, lane);
+            tile_store(sV + (mid + 16 * m) * PLD + lo + 16 * n, acc, lane);
+            tile_store_t(sVt + (lo + 16 * n) * PLD + mid + 16 * m, acc, lane);
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < 64 * 64; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        V[(b0 + i) * ld + b0 + j] = sV[i * PLD + j];
+    }
+}
+int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st) {
+    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)(Np / 64)), dim3(256), 0, st, L, V, Np, ctx->dinfo);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 // `arrive` / `target`: the diagonal workgroup overwrites D with its factor in place, while every
 // other workgroup of the launch reads D.  Workgroups count in on `arrive` once their loads have
 // landed, and the diagonal workgroup stores only when all of them have (target = arrivals

@@ -104,6 +104,7 @@ struct gpry_ctx {
     int opt_split_k = 1;       // split-K for launches with fewer tiles than slots (trtri top levels, lauum)
     int opt_syrk_lds = 0;         // extra dynamic LDS of the trailing update (32768: one workgroup per CU)
     int opt_lauum_lds = 0;        // extra dynamic LDS of K^-1 = V^T V (32768: one workgroup per CU)
+    int opt_trtri_diag_v1 = 0;    // 1: single-wave inverse of the 64x64 diagonal blocks (comparator)
     int opt_trtri_split_cap = 0;  // > 0: upper limit of the split-K factor of the V = L^-1 levels (A/B)
     int opt_lauum_split = 0;      // > 0: force the split-K factor of K^-1 = V^T V (A/B)
     int opt_gemm_dma = 1;         // 128-aligned factor-chain products through gemm_dma_kernel
@@ -202,6 +203,7 @@ struct GemmArgs {
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
 int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
 // gemm_dma.hip: LDS-DMA staged, software-pipelined variant for 128-aligned products (NN, NT, TN)
+int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st);   // chol_panel.hip
 bool gemm_dma_usable(const GemmArgs& g, int M, int N, int K);
 int gemm_dma_launch_product(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi, dim3 grid);
 int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g);   // sweep_gemm.hip (LDS-DMA staging)

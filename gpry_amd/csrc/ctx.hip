@@ -210,6 +210,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "sweep_colouter")) { ctx->opt_sweep_colouter = (int)value; return 0; }
     if (!strcmp(key, "lauum_split")) { ctx->opt_lauum_split = (int)value; return 0; }
     if (!strcmp(key, "trtri_split_cap")) { ctx->opt_trtri_split_cap = (int)value; return 0; }
+    if (!strcmp(key, "trtri_diag_v1")) { ctx->opt_trtri_diag_v1 = (int)value; return 0; }
     if (!strcmp(key, "lauum_lds")) { ctx->opt_lauum_lds = (int)value; return 0; }
     if (!strcmp(key, "syrk_lds")) { ctx->opt_syrk_lds = (int)value; return 0; }
     if (!strcmp(key, "predict_small")) { ctx->opt_predict_small = (int64_t)value; return 0; }
