@@ -47,6 +47,7 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
             GPRY_TRY(trtri_lower(ctx, A, V, T, ctx->Np));
         }
     }
+    if (!info_host) return 0;      // the caller fetches dinfo itself, together with its results
     int info[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(info, ctx->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -166,12 +167,14 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     memcpy(saved, ctx->theta, sizeof(saved));
     for (int k = 0; k <= ctx->d; k++) ctx->theta[k] = theta[k];
     ctx->have_theta = true;
-    int inf = 0;
-    int rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, &inf);
+    // One stream synchronisation per evaluation: the factorisation status is not waited for in the
+    // middle (every kernel behind a failed factorisation either exits on *dinfo != 0 or works on
+    // values nobody reads); status and results come back together at the end.
+    int rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, nullptr);
     double* dz = ctx->dvec;                 // z = V y
     double* da = ctx->dvec + ctx->Np;       // alpha
     double* dout = ctx->dvec + 2 * ctx->Np; // [logdet/2, quad, grad...]
-    if (rc == 0 && inf == 0) {
+    if (rc == 0) {
         rc = solve_alpha(ctx, ctx->dW2, ctx->dy, dz, da, ctx->Np);
         if (rc == 0) rc = logdet_and_quad(ctx, ctx->dW, dz, ctx->Np, dout);
         if (rc == 0 && want_grad) {
@@ -185,20 +188,28 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
             }
         }
     }
+    memcpy(ctx->theta, saved, sizeof(saved));
+    ctx->have_theta = had;
+    // the scaled training coordinates belong to the prediction factor: restore them (same stream, behind
+    // the traces kernel that reads the ones of this evaluation)
+    if (rc == 0 && had && ctx->factor_valid) rc = launch_scale_train(ctx);
     double host[2 + 1 + GPRY_MAX_DIM];
-    if (rc == 0 && inf == 0) {
+    int hinfo[2] = {0, 0};
+    if (rc == 0) {
         hipError_t e = hipMemcpyAsync(host, dout, sizeof(double) * (2 + (want_grad ? ctx->d + 1 : 0)),
                                       hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hinfo, ctx->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = gpry_fail(ctx, -2, "lml copy-out: %s", hipGetErrorString(e));
     }
+    const int inf = hinfo[0] != 0 ? hinfo[0] : hinfo[1];
     ctx->lml_cache = (rc == 0 && inf == 0);
-    if (ctx->lml_cache) { memcpy(ctx->lml_theta, ctx->theta, sizeof(saved)); ctx->lml_kernel_id = ctx->kernel_id; }
-    memcpy(ctx->theta, saved, sizeof(saved));
-    ctx->have_theta = had;
+    if (ctx->lml_cache) {
+        memset(ctx->lml_theta, 0, sizeof(ctx->lml_theta));
+        for (int k = 0; k <= ctx->d; k++) ctx->lml_theta[k] = theta[k];
+        ctx->lml_kernel_id = ctx->kernel_id;
+    }
     if (rc) return rc;
-    // the scaled training coordinates belong to the prediction factor: restore them
-    if (had && ctx->factor_valid) { GPRY_TRY(launch_scale_train(ctx)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
     if (info) *info = inf;
     if (inf != 0) {   // sklearn:_gpr.py:586-589
         *lml = -INFINITY;

@@ -228,7 +228,12 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np) {
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(V, 0, sizeof(double) * Np * Np, st));
-    if (ctx->opt_trtri_diag_v1) {
+    // 0 = auto: the four-wave kernel from Np = 256 on.  Up to Np = 128 the whole inverse IS this stage, and
+    // the column-by-column substitution of the single-wave kernel is the operation order of the
+    // reference's dtrsm: on the cond(K) = 5e15 matrix of BASELINE config 1 (N = 64) any other order moves
+    // the posterior mean by 2..4e-5 of its range, beyond the one-ulp noise floor the golden test allows.
+    const bool single_wave = ctx->opt_trtri_diag_v1 == 1 || (ctx->opt_trtri_diag_v1 == 0 && Np <= 128);
+    if (single_wave) {
         hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)(Np / 64)), dim3(64), 0, st, L, V, Np, ctx->dinfo);
         HIP_TRY(ctx, hipGetLastError());
     } else {

@@ -202,8 +202,8 @@ __device__ __forceinline__ void store_block(double* __restrict__ G, int64_t ld, 
 
 // ---------------------------------------------------------------------------------------------
 // V_bb = L_bb^-1 for every 64x64 diagonal block of L (first stage of V = L^-1): one workgroup of four
-// waves per block.  Wave w inverts the 16x16 diagonal block w by a forward substitution on the identity
-// (trsm16_rows: DPP broadcasts, one reciprocal per pivot), then two doubling levels (16 -> 32 -> 64)
+// waves per block.  Wave w inverts the 16x16 diagonal block w (lane c: forward substitution for column c,
+// true divisions), then two doubling levels (16 -> 32 -> 64)
 // of V21 = -V22 (L21 V11) as 16x16 MFMA tiles in LDS; V is kept together with its transpose because
 // the tile product takes both operands row-wise.  (The single-wave version -- lane c solving L x = e_c
 // with 2016 multiply-adds and 64 divisions from broadcast LDS reads -- took 39 us, a quarter of the
@@ -219,7 +219,6 @@ __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restr
     __shared__ __attribute__((aligned(16))) double sV[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sVt[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sTt[64 * PLD];
-    __shared__ double sRd[64];
     if (*info != 0) return;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
@@ -227,17 +226,27 @@ __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restr
         const int i = e >> 6, j = e & 63;
         sL[i * PLD + j] = (j <= i) ? L[(b0 + i) * ld + b0 + j] : 0.0;
         sV[i * PLD + j] = 0.0;
-        sVt[i * PLD + j] = (i == j) ? 1.0 : 0.0;     // the identity the substitutions start from
+        sVt[i * PLD + j] = 0.0;
     }
-    if (t < 64) sRd[t] = 1.0 / L[(b0 + t) * ld + b0 + t];
     __syncthreads();
-    {   // wave w: X = I L_ww^-T = (L_ww^-1)^T in place in sVt, then its transpose into sV
-        double* Xt = sVt + (w * 16) * PLD + w * 16;
-        trsm16_rows(Xt, sL + (w * 16) * PLD + w * 16, sRd + w * 16, lane);
-        wave_fence();
-        for (int e = lane; e < 256; e += 64) {
-            const int i = e >> 4, j = e & 15;
-            sV[(w * 16 + i) * PLD + w * 16 + j] = Xt[j * PLD + i];
+    {   // wave w, lane c < 16: column c of L_ww^-1 by forward substitution with true divisions (the
+        // reciprocal-multiply form is one rounding per entry further from the reference's dtrsm: on the
+        // cond(K) = 5e15 matrix of config 1 that alone moved the posterior mean by 3e-5 of its range)
+        const double* Lw = sL + (w * 16) * PLD + w * 16;
+        if (lane < 16) {
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) sacc = fma(-Lw[i * PLD + k], x[k], sacc);
+                x[i] = (i >= lane) ? sacc / Lw[i * PLD + i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                sV[(w * 16 + i) * PLD + w * 16 + lane] = x[i];
+                sVt[(w * 16 + lane) * PLD + w * 16 + i] = x[i];
+            }
         }
     }
     __syncthreads();

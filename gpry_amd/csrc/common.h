@@ -104,7 +104,7 @@ struct gpry_ctx {
     int opt_split_k = 1;       // split-K for launches with fewer tiles than slots (trtri top levels, lauum)
     int opt_syrk_lds = 0;         // extra dynamic LDS of the trailing update (32768: one workgroup per CU)
     int opt_lauum_lds = 0;        // extra dynamic LDS of K^-1 = V^T V (32768: one workgroup per CU)
-    int opt_trtri_diag_v1 = 0;    // 1: single-wave inverse of the 64x64 diagonal blocks (comparator)
+    int opt_trtri_diag_v1 = 0;    // 0 auto, 1: single-wave inverse of the 64x64 diagonal blocks, 2: four-wave kernel
     int opt_trtri_split_cap = 0;  // > 0: upper limit of the split-K factor of the V = L^-1 levels (A/B)
     int opt_lauum_split = 0;      // > 0: force the split-K factor of K^-1 = V^T V (A/B)
     int opt_gemm_dma = 1;         // 128-aligned factor-chain products through gemm_dma_kernel
