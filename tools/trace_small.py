@@ -1,5 +1,6 @@
+import os
 import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpry_amd import _lib
 dev = _lib.Device(0)
 dev.set_option("timing", 0)
