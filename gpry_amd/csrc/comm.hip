@@ -10,6 +10,9 @@ struct gpry_comm {
     int world = 1, rank = 0;
     void *dsend = nullptr, *drecv = nullptr;
     int64_t cap_send = 0, cap_recv = 0;
+    // The exchanges move host buffers only, so they run on a stream of their own: nothing on the
+    // compute stream ever queues behind a collective (a peer that never shows up must not wedge it).
+    hipStream_t stream = nullptr;
 };
 
 #define NCCL_TRY(ctx, expr)                                                              \
@@ -55,8 +58,16 @@ int gpry_comm_init(gpry_ctx* ctx, int world, int rank, const uint8_t id[128], gp
     c->ctx = ctx; c->world = world; c->rank = rank;
     ncclUniqueId uid;
     memcpy(&uid, id, 128);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return gpry_fail(ctx, -2, "comm_init: hipStreamCreate failed");
+    }
     ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);
-    if (r != ncclSuccess) { delete c; return gpry_fail(ctx, -5, "ncclCommInitRank: %s", ncclGetErrorString(r)); }
+    if (r != ncclSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return gpry_fail(ctx, -5, "ncclCommInitRank: %s", ncclGetErrorString(r));
+    }
     *out = c;
     return 0;
 }
@@ -66,6 +77,7 @@ int gpry_comm_destroy(gpry_comm* c) {
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->dsend) (void)hipFree(c->dsend);
     if (c->drecv) (void)hipFree(c->drecv);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }
@@ -75,7 +87,7 @@ int gpry_comm_allgather(gpry_comm* c, const void* send, int64_t bytes, void* rec
     gpry_ctx* ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(comm_buffers(c, bytes, bytes * c->world));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = c->stream;
     HIP_TRY(ctx, hipMemcpyAsync(c->dsend, send, (size_t)bytes, hipMemcpyHostToDevice, st));
     NCCL_TRY(ctx, ncclAllGather(c->dsend, c->drecv, (size_t)bytes, ncclChar, c->comm, st));
     HIP_TRY(ctx, hipMemcpyAsync(recv, c->drecv, (size_t)(bytes * c->world), hipMemcpyDeviceToHost, st));
@@ -88,7 +100,7 @@ int gpry_comm_allreduce_max(gpry_comm* c, double* inout, int64_t n) {
     gpry_ctx* ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(comm_buffers(c, n * 8, n * 8));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = c->stream;
     HIP_TRY(ctx, hipMemcpyAsync(c->dsend, inout, (size_t)n * 8, hipMemcpyHostToDevice, st));
     NCCL_TRY(ctx, ncclAllReduce(c->dsend, c->drecv, (size_t)n, ncclDouble, ncclMax, c->comm, st));
     HIP_TRY(ctx, hipMemcpyAsync(inout, c->drecv, (size_t)n * 8, hipMemcpyDeviceToHost, st));
