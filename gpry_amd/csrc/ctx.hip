@@ -387,10 +387,20 @@ __global__ __launch_bounds__(256) void stream_fill_kernel(double2* __restrict__ 
     for (; i < n; i += stride) dst[i] = make_double2(v, v + 1.0);
 }
 
+namespace {
+struct EventPair {      // destroyed on every return path of the micro-benchmarks
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+}  // namespace
+
 extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* value) {
-    hipEvent_t e0, e1;
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
+    if (!ctx || !value) return gpry_fail(ctx, -1, "gpry_microbench: ctx and value must not be NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    EventPair ev;
+    HIP_TRY(ctx, hipEventCreate(&ev.a));
+    HIP_TRY(ctx, hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     float ms = 0.f;
     if (kind == 0) {
         double* out = nullptr;
@@ -514,6 +524,5 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
     } else {
         return gpry_fail(ctx, -1, "microbench: unknown kind %d", kind);
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;
 }
