@@ -43,7 +43,9 @@ StageScope::StageScope(gpry_ctx* c, const char* n, hipStream_t stream) : ctx(c),
 StageScope::~StageScope() {
     if (!e0) return;
     (void)hipEventRecord(e1, st);
-    ctx->timers[name].pending.push_back({e0, e1});
+    auto& tm = ctx->timers[name];
+    tm.pending.push_back({e0, e1});
+    if (tm.pending.size() >= 1024) timers_collect(ctx);   // bounded even if nobody ever reads the timers
 }
 void timers_collect(gpry_ctx* ctx) {
     for (auto& kv : ctx->timers) {
@@ -276,6 +278,7 @@ int gpry_timing_reset(gpry_ctx* ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     timers_collect(ctx);
     for (auto& kv : ctx->timers) { kv.second.total_ms = 0.0; kv.second.count = 0; }
+    ctx->opt_timing = 1;      // whoever resets the timers wants them; a production loop never pays for events
     return 0;
 }
 

@@ -71,7 +71,8 @@ const char* gpry_last_error(gpry_ctx* ctx); /* ctx may be NULL: last global erro
 int gpry_ctx_sync(gpry_ctx* ctx);
 /* option keys: "chol" = 0 hand-written MFMA Cholesky (default), 1 rocSOLVER dpotrf/dtrtri
  *              "sweep_chunk" = candidates per sweep chunk (default 32768)
- *              "timing" = 0/1 per-stage HIP-event timers (gpry_timing_get)
+ *              "timing" = 0/1 per-stage HIP-event timers (gpry_timing_get); off by default, switched on by
+ *                         gpry_timing_reset
  * Everything else is an A/B switch of the measurements quoted in DESIGN.md (defaults are the
  * measured best): "sweep_dma" 0..3, "sweep_persist", "sweep_overlap", "sweep_tilemap", "sweep_colouter", "chol_outer",
  * "chol_lookahead", "split_k", "gemm_dma", "syrk_lds", "lauum_lds", "lauum_split",
