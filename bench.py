@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the GP refit + NORA acquisition cycle (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload cycle|farm]
 
-One *step* is one active-learning cycle of GPry's hot path at configs[2] of
-BASELINE.json (16-d synthetic posterior, N_train -> 4096, Matern-5/2, LogExp NORA sweep
-over M = 1e6 candidates):
+``--workload cycle`` (default; BASELINE configs[2] at N=1, configs[3] at N>1).  One *step* is one
+active-learning cycle of GPry's hot path at EXACTLY N_train = 4096 (16-d synthetic posterior,
+Matern-5/2, LogExp NORA sweep over M = 1e6 candidates):
 
     gpr.append_to_data(X_new, y_new, fit_gpr="simple")   # L-BFGS-B refit, LML+grad on the GPU
     X_new, y_lie, acq = nora.multi_add(gpr, n_points=d)  # fused sweep + top-k + KB ranking
 
-The training set grows by d points per step and reaches exactly N in the last timed
-step (all steps share the padded size).  The candidate pool is resident in HBM before the
-timed region.  With N > 1 GPUs (one process per GPU, launched by torch.distributed.run)
-the refit is replicated and every rank sweeps its own M candidates of a pool of N*M
-("weak"); ``--scaling strong`` shards a fixed pool of M instead.  Rank 0 prints ONE JSON
-line; ``value`` = candidates swept by all ranks per second of whole cycle.
+Every step appends the d points proposed by the previous step to the SAME base of N - d training
+rows (the base is restored by truncating the host arrays, microseconds, inside the timed region), so
+every refit, factorisation and sweep of every timed step runs at N_train = N; ``config.
+N_train_per_step`` lists what each step saw and the run aborts if one differs.  The candidate pool
+is resident in HBM before the timed region.  With N > 1 GPUs (one process per GPU, launched by
+torch.distributed.run) the refit is replicated and the SAME pool of M candidates is sharded N-way
+(``--scaling strong``, the default: configs[3]); ``--scaling weak`` gives every rank M candidates.
+The shortlists are exchanged over RCCL; if the RCCL communicator cannot be built the run exits
+non-zero (``--allow-gloo`` permits the gloo stand-in and says so in ``config.comm``).
+
+``--workload farm`` (BASELINE configs[4]): N_train = 8192, d = 20; one step = one multi-restart
+hyper-parameter fit, 32 L-BFGS-B restarts split over the ranks (gpry/run.py:1238-1293).
+
+Rank 0 prints ONE JSON line; ``value`` = candidates swept by all ranks per second of whole cycle
+(farm: restarts per second).
 """
 import argparse
 import json
@@ -36,6 +45,7 @@ sys.path.insert(0, ROOT)
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X public spec (FP64 matrix == FP64 vector); the guide's
 #                               matrix-core table has no f64 row, see DESIGN.md
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+CPU_CHUNK = 32768             # the CPU sweep is chunked at 32 768 candidates
 
 
 def synthetic(N, d, M, seed_train=0, seed_cand=1):
@@ -59,21 +69,21 @@ def synthetic(N, d, M, seed_train=0, seed_cand=1):
     return bounds, X, truth(X), Xc, truth
 
 
-def cpu_baseline(N, d, M, n_points, lml_evals, cache_models, budget_s=40.0):
-    """Time the CPU oracle (numpy/scipy port of the reference path, same BLAS/LAPACK calls)
-    on a bounded sample of the same workload and extrapolate one cycle."""
-    from oracle import gpry_oracle as orc
+def _cpu_model():
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    try:
-        import psutil
-        avail_gb = psutil.virtual_memory().available / 2 ** 30
-    except Exception:
-        avail_gb = 16.0
-    bounds, X, y, Xc, _ = synthetic(N, d, 4096)
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def _cpu_leg(orc, N, d, n_sweep, lml_N, label):
+    """One pass of the CPU port over a bounded sample: factor update, predict+std on ``n_sweep``
+    candidates (one chunk of <= 32 768 rows), one LML+gradient at ``lml_N`` rows."""
+    bounds, X, y, Xc, _ = synthetic(N, d, n_sweep)
     m = orc.OracleGPR(bounds, kernel_id=orc.MATERN52)
     m.theta = np.log(np.array([4.0] + [0.3] * d))
     m.fitted = True
@@ -83,30 +93,77 @@ def cpu_baseline(N, d, M, n_points, lml_evals, cache_models, budget_s=40.0):
     t0 = time.time()
     m.predict(Xc, return_std=True)
     t_sweep = (time.time() - t0) / len(Xc)
-    # LML+grad materialises (N, N, d+1) float64 tensors several times (~10 GB at N=4096)
-    n_l = N if avail_gb > 24 else N // 2
     t0 = time.time()
-    orc.log_marginal_likelihood(m.X_train_[:n_l], m.y_train_[:n_l], m.alpha[:n_l], m.theta,
+    orc.log_marginal_likelihood(m.X_train_[:lml_N], m.y_train_[:lml_N], m.alpha[:lml_N], m.theta,
                                 orc.MATERN52, eval_gradient=True)
-    t_lml = (time.time() - t0) * (N / n_l) ** 2    # O(N^2 d) tensors dominate: quadratic scaling
-    cycle = lml_evals * t_lml + M * t_sweep + cache_models * t_update
+    t_lml_raw = time.time() - t0
+    t_lml = t_lml_raw * (N / lml_N) ** 2    # O(N^2 d) tensors dominate: quadratic scaling
+    return {"label": label, "update_model_s": t_update, "sweep_us_per_candidate": t_sweep * 1e6,
+            "sweep_sample": n_sweep, "lml_grad_s": t_lml, "lml_grad_measured_at_N": lml_N,
+            "lml_grad_measured_s": t_lml_raw}
+
+
+def cpu_baseline(N, d, M, lml_evals, cache_models):
+    """Time the CPU oracle (numpy/scipy port of the reference path, same BLAS/LAPACK calls in the
+    same order) on the box's host cores, on a bounded sample of the same workload, with all cores
+    and with one thread, and extrapolate one cycle from each."""
+    from oracle import gpry_oracle as orc
+    from threadpoolctl import threadpool_info, threadpool_limits
+    pools = threadpool_info()
+    threads = max([p.get("num_threads", 1) for p in pools] or [1])
+    blas = sorted({f"{p.get('internal_api')}-{p.get('version')}" for p in pools})
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    try:
+        import psutil
+        avail_gb = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        avail_gb = 16.0
+    # LML+grad materialises (N, N, d+1) float64 tensors several times (~10 GB at N=4096)
+    lml_N = N if avail_gb > 24 else N // 2
+    legs = {}
+    _cpu_leg(orc, 256, d, 256, 256, "warm-up (imports, thread pools)")
+    legs["all_cores"] = _cpu_leg(orc, N, d, min(CPU_CHUNK, M), lml_N, f"{threads} BLAS threads")
+    # one thread: same routines; the sample shrinks so that the leg stays within ~15 s
+    lml_1 = lml_N if legs["all_cores"]["lml_grad_measured_s"] < 10.0 else lml_N // 2
+    with threadpool_limits(limits=1):
+        legs["single_thread"] = _cpu_leg(orc, N, d, min(2048, M), lml_1, "threadpool_limits(1) "
+                                         "(= OMP_NUM_THREADS=1 for BLAS/LAPACK; numpy elementwise "
+                                         "code is single-threaded in both legs)")
+    out = {}
+    for name, g in legs.items():
+        cycle = lml_evals * g["lml_grad_s"] + M * g["sweep_us_per_candidate"] * 1e-6 + \
+            cache_models * g["update_model_s"]
+        g["cycle_s"] = cycle
+        g["candidates_per_s"] = M / cycle
+        out[name] = g
+    a = out["all_cores"]
     return {
-        "value": M / cycle, "unit": "candidates/s", "cores": threads, "kind": "port",
-        "sample": (f"oracle/gpry_oracle.py on host: 1 LML+grad at N={n_l} ({t_lml:.2f} s scaled to N={N}), "
-                   f"predict+std on 4096 candidates ({t_sweep * 1e6:.1f} us each), 1 factor update "
-                   f"({t_update:.2f} s); cycle = {lml_evals} LML evals + {M} candidates + {cache_models} "
-                   f"conditioned-model refits = {cycle:.1f} s"),
-        "cycle_s": cycle, "lml_grad_s": t_lml, "sweep_us_per_candidate": t_sweep * 1e6,
-        "update_model_s": t_update,
+        "value": a["candidates_per_s"], "unit": "candidates/s", "cores": min(threads, affinity),
+        "kind": "port",
+        "sample": (f"oracle/gpry_oracle.py on host, {threads} BLAS threads: 1 LML+grad at N="
+                   f"{a['lml_grad_measured_at_N']} ({a['lml_grad_measured_s']:.2f} s"
+                   + ("" if a["lml_grad_measured_at_N"] == N else f", scaled x{(N / a['lml_grad_measured_at_N']) ** 2:.0f} to N={N}")
+                   + f"), predict+std on one chunk of {a['sweep_sample']} candidates "
+                   f"({a['sweep_us_per_candidate']:.1f} us each), 1 factor update ({a['update_model_s']:.2f} s); "
+                   f"cycle = {lml_evals:g} LML evals + {M} candidates + {cache_models:g} conditioned-model "
+                   f"refits = {a['cycle_s']:.1f} s"),
+        "cpu_model": _cpu_model(), "nproc": os.cpu_count(), "affinity": affinity,
+        "blas_threads": threads, "blas": blas, "chunk_rows": CPU_CHUNK,
+        "cycle_s": a["cycle_s"], "lml_grad_s": a["lml_grad_s"],
+        "sweep_us_per_candidate": a["sweep_us_per_candidate"], "update_model_s": a["update_model_s"],
+        "single_thread": out["single_thread"],
     }
 
 
 class _GlooComm:
     """Same interface as gpry_amd._lib.RcclComm over torch.distributed/gloo: used by the bench only
-    if the RCCL communicator cannot be created (the exchanged shortlists are a few KB)."""
+    with ``--allow-gloo`` when the RCCL communicator cannot be created."""
 
-    def __init__(self, dist, dev):
-        self._dist, self._dev = dist, dev
+    def __init__(self, dist):
+        self._dist = dist
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
 
     def allgather(self, arr):
@@ -127,17 +184,197 @@ class _GlooComm:
         self._dist.barrier()
 
 
+def connect(args, rank, world, dev):
+    """Rendezvous over gloo (CPU), data-path communicator over RCCL.  Returns (comm, dist, kind,
+    rccl_ranks).  A failed or hanging RCCL bootstrap ends the run with a non-zero exit code unless
+    ``--allow-gloo`` was given; the process never continues with a thread stuck inside RCCL."""
+    from gpry_amd import _lib
+    import torch
+    import torch.distributed as dist   # rendezvous only; the exchanged shortlists travel over RCCL
+    dist.init_process_group("gloo")
+    box = [None]
+    err = None
+    try:
+        box = [_lib.RcclComm.unique_id() if rank == 0 else None]
+    except Exception as e:
+        err = repr(e)
+    dist.broadcast_object_list(box, src=0)
+    made = {}
+
+    def _connect():
+        try:
+            c = _lib.RcclComm(dev, world, rank, box[0])
+            got = c.allgather(np.array([rank], dtype=np.int64))
+            if list(got.ravel()) != list(range(world)):
+                raise RuntimeError(f"allgather self-test returned {got.ravel()}")
+            made["comm"] = c
+        except Exception as e:
+            made["error"] = repr(e)
+
+    if box[0] is not None:
+        import threading
+        th = threading.Thread(target=_connect, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("GPRY_BENCH_RCCL_TIMEOUT", "180")))
+        if th.is_alive():
+            print(f"bench.py[{rank}]: RCCL bootstrap still hanging after the time limit; giving up",
+                  file=sys.stderr, flush=True)
+            os._exit(4)      # a thread is stuck inside ncclCommInitRank: nothing sane can follow
+        err = made.get("error")
+    ok = torch.tensor([1.0 if "comm" in made else 0.0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks must agree on the transport
+    if float(ok[0]) >= 1.0:
+        n_rccl = made["comm"].info()[0]
+        return made["comm"], dist, "rccl", n_rccl
+    if "comm" in made:
+        made["comm"].close()
+    msg = f"bench.py[{rank}]: no RCCL communicator over {world} ranks ({err or 'a peer failed'})"
+    if world > 1 and not args.allow_gloo:
+        print(msg + "; exiting (pass --allow-gloo to exchange the shortlists over gloo instead)",
+              file=sys.stderr, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(3)
+    print(msg + "; using gloo (--allow-gloo)", file=sys.stderr, flush=True)
+    return _GlooComm(dist), dist, "gloo-fallback", 0
+
+
+def rewind(gpr, n_base):
+    """Bench-only: drop the rows appended by the previous step so that the next ``append_to_data``
+    arrives at exactly N again.  ``X_train_all`` / ``y_train_all`` are public attributes
+    (gpry/gpr.py:283); everything else is recomputed from them by ``append_to_data``."""
+    gpr.X_train_all = gpr.X_train_all[:n_base]
+    gpr.y_train_all = gpr.y_train_all[:n_base]
+
+
+def make_gpr(bounds, **kw):
+    from gpry_amd.gpr import GaussianProcessRegressor
+    from gpry_amd.preprocessing import Normalize_bounds, Normalize_y
+    kw.setdefault("random_state", 3)
+    return GaussianProcessRegressor(kernel={"Matern": {"nu": 2.5}}, bounds=bounds, noise_level=1e-2,
+                                    preprocessing_X=Normalize_bounds(bounds), preprocessing_y=Normalize_y(),
+                                    account_for_inf=None, verbose=1, **kw)
+
+
+def refit_extras(bounds, X, y):
+    """Not the headline: the hyper-parameter fit away from a converged theta, at the same N.
+    (a) ``fit_gpr='simple'`` from the default init C=10, l=0.1 (gpry/gpr.py:351-352) -- the ~60
+    evaluation case BASELINE.md section 2 prices at 32 min on the CPU; (b) a 4-restart full fit."""
+    from gpry_amd.kernels import clone
+    out = {}
+    for name, fit in (("cold_simple_from_default_init", "simple"),
+                      ("full_fit_4_restarts", {"n_restarts": 4, "start_from_current": True})):
+        g = make_gpr(bounds)
+        g.kernel_ = clone(g.kernel)
+        g._fitted = True                      # 'simple' then starts at kernel_.theta = the default init
+        g.device.set_train(np.zeros((len(X), X.shape[1])), np.zeros(len(X)), 1e-4)   # allocation: untimed
+        e0 = g.n_eval_loglike
+        t0 = time.perf_counter()
+        g.append_to_data(X, y, fit_gpr=fit)
+        g.device.sync()
+        dt = time.perf_counter() - t0
+        ev = g.n_eval_loglike - e0
+        out[name] = {"ms": dt * 1e3, "lml_grad_evals": ev, "ms_per_eval": dt * 1e3 / max(ev, 1),
+                     "lml": float(g.log_marginal_likelihood_value_), "N_train": g.n}
+        del g
+    return out
+
+
+def run_farm(args, rank, world, local_rank):
+    """BASELINE configs[4]: N=8192, d=20, 32 L-BFGS-B restarts of the LML farmed over the GPUs."""
+    from gpry_amd.parallel import fit_gpr_parallel, split_number_for_parallel_processes
+    N, d, K, W = args.N or 8192, args.d or 20, args.steps, args.warmup
+    n_restarts = args.restarts
+    bounds, X, y, _, truth = synthetic(N, d, 16)
+    n_base = N - d
+    gpr = make_gpr(bounds, n_restarts_optimizer=n_restarts)
+    dev = gpr.device
+    comm, dist, comm_kind, n_rccl = None, None, "none", 0
+    if world > 1 or "RANK" in os.environ:
+        comm, dist, comm_kind, n_rccl = connect(args, rank, world, dev)
+    # setup (untimed): first fit on the base set
+    gpr.append_to_data(X[:n_base], y[:n_base], fit_gpr="simple")
+    X_new, y_new = X[n_base:], y[n_base:]
+
+    def step():
+        rewind(gpr, n_base)
+        fit_gpr_parallel(gpr, X_new, y_new, comm=comm, fit="full", n_restarts=n_restarts)
+        assert gpr.n == N, (gpr.n, N)
+
+    def fence():
+        dev.sync()
+        if comm is not None:
+            comm.barrier()
+        dev.sync()
+
+    for _ in range(W):
+        step()
+    fence()
+    dev.timing_reset()
+    e0 = gpr.n_eval_loglike
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    evals_rank = (gpr.n_eval_loglike - e0) / K
+    if comm is not None:
+        elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
+        evals_all = comm.allgather(np.array([evals_rank]))[:, 0]
+    else:
+        evals_all = np.array([evals_rank])
+    names = ("kernel_build", "potrf", "trtri", "lauum", "lml_traces")
+    T = {k: dev.timing(k) for k in names}
+    Np = (N + 127) // 128 * 128
+    one_eval_ms = sum(T[k][0] / max(T[k][1], 1) for k in names)
+    po_ms, po_n = T["potrf"]
+    chain_ms = sum(T[k][0] / max(T[k][1], 1) for k in ("potrf", "trtri", "lauum"))
+    result = {
+        "metric": "gp_hyperparameter_restart_farm_throughput",
+        "value": n_restarts / (elapsed / K), "unit": "restarts/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: 20-d synthetic posterior, N_train=8192, Matern-5/2, "
+                               f"{n_restarts} L-BFGS-B restarts of the log-marginal-likelihood split over the GPUs",
+                   "N_train": N, "d": d, "n_restarts": n_restarts,
+                   "restarts_per_rank": [int(v) for v in split_number_for_parallel_processes(n_restarts, world)],
+                   "comm": comm_kind, "rccl_ranks": n_rccl},
+        "farm": {"lml_grad_evals_per_step_per_rank": [float(v) for v in evals_all],
+                 "one_lml_grad_call_ms_device": one_eval_ms,
+                 "stage_ms_per_eval": {k: T[k][0] / max(T[k][1], 1) for k in names}},
+        "roofline": {"kernel": "factor chain of one LML+gradient evaluation (potrf + V = L^-1 + K^-1 = V^T V)",
+                     "bound": "mfma", "achieved": float(Np) ** 3 / (chain_ms * 1e-3) / 1e12 if chain_ms else 0.0,
+                     "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (float(Np) ** 3 / (chain_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS) if chain_ms else 0.0,
+                     "traffic": None, "flops_per_call": float(Np) ** 3, "avg_ms": chain_ms,
+                     "potrf_ms": po_ms / max(po_n, 1),
+                     "potrf_tflops": (float(Np) ** 3 / 3.0) / (po_ms / max(po_n, 1) * 1e-3) / 1e12 if po_n else 0.0},
+    }
+    if comm is not None:
+        comm.barrier()
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--N", type=int, default=4096)
-    ap.add_argument("--d", type=int, default=16)
+    ap.add_argument("--workload", choices=["cycle", "farm"], default="cycle")
+    ap.add_argument("--N", type=int, default=None)
+    ap.add_argument("--d", type=int, default=None)
     ap.add_argument("--M", type=int, default=1_000_000)
     ap.add_argument("--n-points", type=int, default=None)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--restarts", type=int, default=32)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
+    ap.add_argument("--allow-gloo", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
+    ap.add_argument("--extras", choices=["auto", "off"], default="auto")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -149,87 +386,55 @@ def main():
                   f"{args.gpus} bench.py ...`; running 1 GPU", file=sys.stderr)
         args.gpus = world
     os.environ["GPRY_HIP_DEVICE"] = str(local_rank)
+    if args.workload == "farm":
+        return run_farm(args, rank, world, local_rank)
 
-    from gpry_amd import _lib
-    from gpry_amd.gpr import GaussianProcessRegressor
     from gpry_amd.gp_acquisition import NORA
-    from gpry_amd.preprocessing import Normalize_bounds, Normalize_y
 
-    N, d, K, W = args.N, args.d, args.steps, args.warmup
+    N, d, K, W = args.N or 4096, args.d or 16, args.steps, args.warmup
     npts = args.n_points or d
     M_total = args.M * world if args.scaling == "weak" else args.M
-    N0 = N - npts * (W + K)
-    if N0 < 2 * d:
-        raise SystemExit("N too small for the requested number of steps")
-    bounds, X, y, Xc, truth = synthetic(N0, d, M_total)
+    n_base = N - npts
+    if n_base < 2 * d:
+        raise SystemExit("N too small")
+    bounds, X, y, Xc, truth = synthetic(n_base, d, M_total)
 
-    gpr = GaussianProcessRegressor(kernel={"Matern": {"nu": 2.5}}, bounds=bounds, noise_level=1e-2,
-                                   preprocessing_X=Normalize_bounds(bounds), preprocessing_y=Normalize_y(),
-                                   account_for_inf=None, random_state=3, verbose=1)
+    gpr = make_gpr(bounds)
     dev = gpr.device
-    comm = None
-    dist = None
-    comm_kind = "none"
+    comm, dist, comm_kind, n_rccl = None, None, "none", 0
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
-        import torch.distributed as dist   # rendezvous only (CPU/gloo); the data path is RCCL
-        dist.init_process_group("gloo")
-        comm_kind = "rccl"
-        box = [None]
-        try:
-            box = [_lib.RcclComm.unique_id() if rank == 0 else None]
-        except Exception as e:
-            print(f"bench.py[{rank}]: {e!r}", file=sys.stderr)
-        dist.broadcast_object_list(box, src=0)
-        # communicator + one verified exchange under a watchdog: a bootstrap that fails or hangs on
-        # this node must not take the run down (the exchange is a few KB per cycle)
-        made = {}
-
-        def _connect():
-            try:
-                c = _lib.RcclComm(dev, world, rank, box[0])
-                got = c.allgather(np.array([rank], dtype=np.int64))
-                if list(got.ravel()) != list(range(world)):
-                    raise RuntimeError(f"allgather self-test returned {got.ravel()}")
-                made["comm"] = c
-            except Exception as e:
-                made["error"] = e
-
-        ok = 0.0
-        if box[0] is not None:
-            import threading
-            th = threading.Thread(target=_connect, daemon=True)
-            th.start()
-            th.join(timeout=float(os.environ.get("GPRY_BENCH_RCCL_TIMEOUT", "120")))
-            if "comm" in made:
-                comm, ok = made["comm"], 1.0
-            else:
-                why = repr(made.get("error", "timed out"))
-                print(f"bench.py[{rank}]: RCCL communicator failed ({why}); using gloo for the "
-                      f"shortlist exchange", file=sys.stderr)
-        import torch
-        flag = torch.tensor([ok])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks must agree on the transport
-        if float(flag[0]) < 1.0:
-            comm, comm_kind = _GlooComm(dist, dev), "gloo-fallback"
+        comm, dist, comm_kind, n_rccl = connect(args, rank, world, dev)
 
     acq = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=comm)
     acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
     rng = np.random.default_rng(2)
 
-    # ---- setup (untimed): first fit from the default init, first proposals, pool upload
+    # ---- setup (untimed): first fit of the base set, first proposals, pool upload
+    t0 = time.perf_counter()
+    e0 = gpr.n_eval_loglike
     gpr.append_to_data(X, y, fit_gpr="simple")
+    first_fit = {"ms": (time.perf_counter() - t0) * 1e3, "lml_grad_evals": gpr.n_eval_loglike - e0,
+                 "N_train": gpr.n, "note": "unfitted model: one run from a random start (gpry/gpr.py:917-918), "
+                                           "includes context creation and allocation"}
     X_new, _, _ = acq.multi_add(gpr, n_points=npts, rng=rng)
 
     host_t = {"refit": 0.0, "acq": 0.0}
+    n_seen = []
+    work = {"sweep_flops": 0.0, "kb_bytes": 0.0, "potrf_flops_each": []}
 
-    def step():
+    def step(acq=acq):
         nonlocal X_new
         t_a = time.perf_counter()
+        rewind(gpr, n_base)
         gpr.append_to_data(X_new, truth(X_new), fit_gpr="simple")
         t_b = time.perf_counter()
         X_new, _, _ = acq.multi_add(gpr, n_points=npts, rng=rng)
         host_t["refit"] += t_b - t_a
         host_t["acq"] += time.perf_counter() - t_b
+        n = gpr.n
+        n_seen.append(n)
+        # algorithmic work of THIS step at the size it actually ran at
+        work["sweep_flops"] += (acq._sweep_hi - acq._sweep_lo) * (float(n) ** 2 + 2.0 * n)
 
     def fence():
         dev.sync()
@@ -242,6 +447,8 @@ def main():
     fence()
     dev.timing_reset()
     host_t["refit"] = host_t["acq"] = 0.0
+    n_seen.clear()
+    work["sweep_flops"] = 0.0
     lml0 = gpr.n_eval_loglike
     cache_models = 0
     t0 = time.perf_counter()
@@ -253,7 +460,8 @@ def main():
     if comm is not None:
         elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
     lml_evals = (gpr.n_eval_loglike - lml0) / K
-    assert gpr.n == N, (gpr.n, N)
+    if any(n != N for n in n_seen):
+        raise SystemExit(f"bench.py: a timed step did not run at N_train={N}: {n_seen}")
 
     names = ("kernel_build", "potrf", "trtri", "lauum", "lml_traces", "cross_build", "sweep_gemm",
              "sweep_finish", "topk")
@@ -261,18 +469,19 @@ def main():
     per_step_ms = {k: T[k][0] / K for k in names}
     Np = (N + 127) // 128 * 128
     M_rank = acq._sweep_hi - acq._sweep_lo
-    # dominant kernel: the FP64-MFMA triangular GEMM of the sweep.  Algorithmic flops per
-    # candidate = N^2 (mul+add over the N^2/2 non-zeros of V) + 2N (mean), SURVEY.md 8(d)
+    # dominant kernel: the FP64-MFMA triangular GEMM of the sweep.  Algorithmic flops per candidate =
+    # N^2 (mul+add over the N^2/2 non-zeros of V) + 2N (mean), SURVEY.md 8(d), summed over the steps at
+    # the N each one ran at, over the HIP-event time of exactly those launches
     gemm_ms, gemm_n = T["sweep_gemm"]
-    cand_per_launch = M_rank * K / max(gemm_n, 1)
-    flops_launch = cand_per_launch * (float(N) ** 2 + 2.0 * N)
-    achieved = flops_launch / (gemm_ms / max(gemm_n, 1) * 1e-3) / 1e12 if gemm_ms else 0.0
+    flops_launch = work["sweep_flops"] / max(gemm_n, 1)
+    achieved = work["sweep_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         traffic = json.load(open(tfile)).get("sweep_gemm_hbm_bytes_per_launch")
     kb_ms, kb_n = T["kernel_build"]
-    kb_gbps = (8.0 * N * N + 8.0 * N * d) / (kb_ms / max(kb_n, 1) * 1e-3) / 1e9 if kb_ms else 0.0
+    kb_bytes = 8.0 * N * N + 8.0 * N * d          # every launch ran at N (checked above)
+    kb_gbps = kb_bytes / (kb_ms / max(kb_n, 1) * 1e-3) / 1e9 if kb_ms else 0.0
     sweep_ms = per_step_ms["cross_build"] + per_step_ms["sweep_gemm"] + per_step_ms["sweep_finish"]
 
     ms_per_step = elapsed / K * 1e3
@@ -287,11 +496,14 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: 16-d correlated-Gaussian posterior, N_train=4096, "
-                               "Matern-5/2, LogExp NORA sweep M=1e6, n_points=16, fit_gpr='simple'",
-                   "N_train": N, "d": d, "M_total": M_total, "M_per_gpu": M_rank, "n_points": npts,
+        "config": {"workload": ("BASELINE configs[2]" if world == 1 else "BASELINE configs[3]") +
+                               ": 16-d correlated-Gaussian posterior, N_train=4096 in every step, "
+                               "Matern-5/2, LogExp NORA sweep M=1e6, n_points=16, fit_gpr='simple'" +
+                               ("" if world == 1 else f", candidate pool sharded {world}-way, RCCL shortlist all-gather"),
+                   "N_train": N, "N_train_per_step": n_seen, "Np": Np, "d": d, "M_total": M_total,
+                   "M_per_gpu": M_rank, "n_points": npts,
                    "kernel": "ConstantKernel*Matern(nu=2.5)", "sharding": f"candidates x{world}",
-                   "comm": comm_kind},
+                   "comm": comm_kind, "rccl_ranks": n_rccl},
         "cycle": {"refit_plus_acq_ms": ms_per_step, "refit_ms": host_t["refit"] / K * 1e3,
                   "acquisition_ms": host_t["acq"] / K * 1e3,
                   "one_lml_grad_call_ms": (per_step_ms["kernel_build"] + per_step_ms["potrf"] + per_step_ms["trtri"] +
@@ -300,7 +512,8 @@ def main():
                   "stage_ms_per_step": per_step_ms, "device_sweep_ms_per_step": sweep_ms,
                   "sweep_candidates_per_s_per_gpu": M_rank / (sweep_ms * 1e-3) if sweep_ms else None,
                   "shortlist": acq.stats.get("shortlist"), "cache_models_per_step": cache_models / K,
-                  "rank_host_ms": acq.stats.get("rank_s", 0) * 1e3},
+                  "rank_host_ms": acq.stats.get("rank_s", 0) * 1e3,
+                  "first_fit_untimed": first_fit},
         "roofline": {"kernel": "sweep_gemm_dma_sp_kernel (V lower-triangular x K*^T panel, sum-of-squares epilogue)",
                      "bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -308,11 +521,11 @@ def main():
                      "flops_per_launch": flops_launch},
         "kernel_build": {"bound": "hbm", "achieved": kb_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": kb_gbps / HBM_PEAK_GBPS, "avg_launch_ms": kb_ms / max(kb_n, 1),
-                         "bytes_per_launch": 8.0 * N * N + 8.0 * N * d},
+                         "launches": kb_n, "bytes_per_launch": kb_bytes},
     }
-    # MFMA utilisation of the Cholesky (north_star): N^3/3 flop per factorisation over the average
-    # duration of the `potrf` stage (64 fused panel steps + 15 MFMA trailing updates at N=4096), and of
-    # the whole factor chain of one LML+gradient call (potrf + V = L^-1 + K^-1 = V^T V: N^3 flop)
+    # MFMA utilisation of the Cholesky (north_star): Np^3/3 flop per factorisation over the average
+    # duration of the `potrf` stage, and of the whole factor chain of one LML+gradient call
+    # (potrf + V = L^-1 + K^-1 = V^T V: Np^3 flop); every call ran at N (checked above)
     po_ms, po_n = T["potrf"]
     if po_n:
         tf = (float(Np) ** 3 / 3.0) / (po_ms / po_n * 1e-3) / 1e12
@@ -328,26 +541,59 @@ def main():
             us = dev.microbench(6, 50)
             result["kernel_build"].update({
                 "avg_launch_ms_back_to_back": us * 1e-3,
-                "achieved_back_to_back": (8.0 * N * N + 8.0 * N * d) / (us * 1e-6) / 1e9,
-                "frac_back_to_back": (8.0 * N * N + 8.0 * N * d) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS})
+                "achieved_back_to_back": kb_bytes / (us * 1e-6) / 1e9,
+                "frac_back_to_back": kb_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS})
         except Exception as e:
             result["kernel_build"]["back_to_back_error"] = repr(e)
         # measured ceilings of this very GPU, quoted beside the spec peaks used for `frac`
         try:
-            result["measured_peaks"] = {
-                "mfma_f64_vgpr_acc_TFLOPs": dev.microbench(2, 1),
-                "hbm_copy_GBps": dev.microbench(1, 1 << 30),
-                "hbm_fill_GBps": dev.microbench(3, 1 << 30)}
+            mp = {"mfma_f64_vgpr_acc_TFLOPs": dev.microbench(2, 1),
+                  "hbm_copy_GBps": dev.microbench(1, 1 << 30),
+                  "hbm_fill_GBps": dev.microbench(3, 1 << 30)}
+            result["measured_peaks"] = mp
+            result["roofline"]["frac_of_measured_peak"] = achieved / mp["mfma_f64_vgpr_acc_TFLOPs"]
+            if achieved > 1.03 * mp["mfma_f64_vgpr_acc_TFLOPs"]:
+                result["roofline"]["warning"] = ("achieved exceeds the MFMA rate measured on this GPU by "
+                                                 "more than 3 %: check the flop accounting")
         except Exception as e:
             result["measured_peaks"] = {"error": repr(e)}
+
+    # ---- strong scaling: the same cycle on ONE GPU of this node, measured in this very run, so
+    # that the line carries its own speed-up (whole cycle and device sweep)
+    if world > 1 and args.scaling == "strong" and args.extras == "auto":
+        ref = None
+        if rank == 0:
+            acq1 = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=None)
+            acq1.do_MC_sample = acq.do_MC_sample
+            X_new, _, _ = acq1.multi_add(gpr, n_points=npts, rng=rng)    # uploads the whole pool
+            step(acq1)
+            dev.sync()
+            dev.timing_reset()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                step(acq1)
+            dev.sync()
+            one_ms = (time.perf_counter() - t1) / 2 * 1e3
+            one_sweep = sum(dev.timing(k)[0] for k in ("cross_build", "sweep_gemm", "sweep_finish")) / 2
+            ref = {"one_gpu_ms_per_step": one_ms, "one_gpu_device_sweep_ms": one_sweep,
+                   "cycle_speedup": one_ms / ms_per_step,
+                   "device_sweep_speedup": one_sweep / sweep_ms if sweep_ms else None,
+                   "note": "1-GPU figures: rank 0 alone, whole pool, 2 steps after the timed region"}
+        if rank == 0:
+            result["scaling_check"] = ref
+    if rank == 0 and world == 1 and args.extras == "auto":
+        try:
+            result["refit_extras"] = refit_extras(bounds, gpr.X_train_all.copy(), gpr.y_train_all.copy())
+        except Exception as e:
+            result["refit_extras"] = {"error": repr(e)}
     if rank == 0 and world == 1 and args.cpu_baseline == "auto":
         try:
-            result["cpu_baseline"] = cpu_baseline(N, d, args.M, npts, lml_evals, cache_models / K)
+            result["cpu_baseline"] = cpu_baseline(N, d, args.M, lml_evals, cache_models / K)
         except Exception as e:   # the baseline must never take the GPU number down with it
             result["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": None,
                                       "kind": "port", "sample": f"failed: {e!r}"}
-    if comm is not None:
-        comm.barrier()
+    if dist is not None:
+        dist.barrier()      # gloo: the other ranks wait here while rank 0 measures its extras
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -70,6 +70,7 @@ SIGNATURES = {
     "gpry_comm_unique_id": (C.c_int, [_vp]),
     "gpry_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _P(_vp)]),
     "gpry_comm_destroy": (C.c_int, [_vp]),
+    "gpry_comm_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "gpry_comm_allgather": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "gpry_comm_allreduce_max": (C.c_int, [_vp, _vp, C.c_int64]),
     "gpry_comm_barrier": (C.c_int, [_vp]),
@@ -392,6 +393,13 @@ class RcclComm:
             raise GpryHipError("gpry_comm_unique_id failed: " +
                                lib.gpry_last_error(None).decode(errors="replace"))
         return buf.tobytes()
+
+    def info(self):
+        """(ranks, rank, device) as RCCL reports them for this communicator."""
+        n, r, dv = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._dev._check(self._lib.gpry_comm_info(self._h, C.byref(n), C.byref(r), C.byref(dv)),
+                         "gpry_comm_info")
+        return n.value, r.value, dv.value
 
     def allgather(self, arr):
         arr = np.ascontiguousarray(arr)

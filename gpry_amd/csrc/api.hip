@@ -669,6 +669,9 @@ static double key_to_acq(unsigned long long k) {
 
 extern "C" int gpry_sweep_topk(gpry_ctx* ctx, int64_t Kp, const int64_t* exclude, int64_t n_exclude,
                                gpry_cand* top, int64_t* n_out, double* bound) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_sweep_topk: ctx is NULL");
+    if (!top || !n_out || !bound) return gpry_fail(ctx, -1, "topk: top, n_out and bound must not be NULL");
+    if (n_exclude > 0 && !exclude) return gpry_fail(ctx, -1, "topk: n_exclude > 0 but exclude is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t M = ctx->sw_M;
     if (M <= 0 || !ctx->dacq_all) return gpry_fail(ctx, -1, "topk: no sweep results resident");
@@ -896,6 +899,8 @@ int gpry_kb_gram(gpry_ctx* ctx, int64_t p, double* G, double* kvec, int64_t* n) 
 extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, double* C, int M, int N,
                                int K, int a_trans, int b_trans, int epi, int kmode, int lower_only,
                                int tile_map) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_debug_gemm: ctx is NULL");
+    if (!A || !B || !C) return gpry_fail(ctx, -1, "debug_gemm: A, B and C must not be NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M % 64 || N % 64 || K % 64) return gpry_fail(ctx, -1, "debug_gemm: dims must be multiples of 64");
     int64_t crow = (epi == EPI_SUMSQ) ? (M + 127) / 128 : M;
@@ -928,6 +933,8 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
 }
 
 extern "C" int gpry_debug_read_diag(gpry_ctx* ctx, uint64_t out[6], int reset) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_debug_read_diag: ctx is NULL");
+    if (!out) return gpry_fail(ctx, -1, "debug_read_diag: out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

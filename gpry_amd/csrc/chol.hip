@@ -186,8 +186,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
     if (pl.Np == Np) { *out = &pl; return 0; }
     for (auto p : pl.d_t) if (p) (void)hipFree(p);
     for (auto p : pl.d_v) if (p) (void)hipFree(p);
-    pl = TrtriPlan();
-    pl.Np = Np;
+    pl = TrtriPlan();       // Np = 0: an incomplete plan is never taken for a finished one
     std::vector<TriNode> nodes;
     int nlev = build_tree(0, (int)(Np / 64), nodes);
     for (int lev = 1; lev <= nlev; lev++) {
@@ -211,14 +210,23 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
         }
         GemmBatchItem *dt = nullptr, *dv = nullptr;
         size_t bytes = bt.size() * sizeof(GemmBatchItem);
-        HIP_TRY(ctx, hipMalloc(&dt, bytes));
-        HIP_TRY(ctx, hipMalloc(&dv, bytes));
-        HIP_TRY(ctx, hipMemcpy(dt, bt.data(), bytes, hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(dv, bv.data(), bytes, hipMemcpyHostToDevice));
+        hipError_t e = hipMalloc(&dt, bytes);
+        if (e == hipSuccess) e = hipMalloc(&dv, bytes);
+        if (e == hipSuccess) e = hipMemcpy(dt, bt.data(), bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dv, bv.data(), bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {      // drop the partial plan: the next call starts over
+            if (dt) (void)hipFree(dt);
+            if (dv) (void)hipFree(dv);
+            for (auto p : pl.d_t) if (p) (void)hipFree(p);
+            for (auto p : pl.d_v) if (p) (void)hipFree(p);
+            pl = TrtriPlan();
+            return gpry_fail(ctx, -2, "trtri plan (Np = %lld): %s", (long long)Np, hipGetErrorString(e));
+        }
         pl.d_t.push_back(dt); pl.d_v.push_back(dv);
         pl.count.push_back((int)bt.size()); pl.maxM.push_back(mM); pl.maxN.push_back(mN);
         pl.aligned.push_back(al);
     }
+    pl.Np = Np;             // committed only once every level is on the device
     *out = &pl;
     return 0;
 }

@@ -72,6 +72,18 @@ int gpry_comm_init(gpry_ctx* ctx, int world, int rank, const uint8_t id[128], gp
     return 0;
 }
 
+int gpry_comm_info(gpry_comm* c, int* world, int* rank, int* device) {
+    if (!c) return gpry_fail(nullptr, -1, "gpry_comm_info: communicator is NULL");
+    int n = 0, r = 0, dv = 0;
+    NCCL_TRY(c->ctx, ncclCommCount(c->comm, &n));
+    NCCL_TRY(c->ctx, ncclCommUserRank(c->comm, &r));
+    NCCL_TRY(c->ctx, ncclCommCuDevice(c->comm, &dv));
+    if (world) *world = n;
+    if (rank) *rank = r;
+    if (device) *device = dv;
+    return 0;
+}
+
 int gpry_comm_destroy(gpry_comm* c) {
     if (!c) return 0;
     if (c->comm) (void)ncclCommDestroy(c->comm);

@@ -130,7 +130,7 @@ struct gpry_ctx {
     std::map<std::string, StageTimer> timers;
 };
 
-extern char g_last_error[1024];
+extern thread_local char g_last_error[1024];
 
 int gpry_fail(gpry_ctx* ctx, int code, const char* fmt, ...);
 

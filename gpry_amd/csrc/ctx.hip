@@ -2,7 +2,8 @@
 #include "common.h"
 #include <stdarg.h>
 
-char g_last_error[1024] = {0};
+// per thread: concurrent optimiser restarts drive distinct contexts from distinct host threads
+thread_local char g_last_error[1024] = {0};
 void trtri_plan_free(gpry_ctx* ctx);
 
 int gpry_fail(gpry_ctx* ctx, int code, const char* fmt, ...) {
@@ -88,18 +89,21 @@ int ensure_capacity(gpry_ctx* ctx, int64_t N, int d) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         double** bufs[] = {&ctx->dX, &ctx->dXs, &ctx->dy, &ctx->dnoise, &ctx->dA, &ctx->dV, &ctx->dW,
                            &ctx->dW2, &ctx->dW3, &ctx->dalpha_, &ctx->dvec};
-        for (auto b : bufs) { if (*b) { GPRY_TRY(dev_free(ctx, *b)); *b = nullptr; } }
-        GPRY_TRY(dev_alloc(ctx, &ctx->dX, cap * dp));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dXs, cap * dp));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dy, cap));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dnoise, cap));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dA, cap * cap));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dV, cap * cap));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dW, cap * cap));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dW2, cap * cap));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dW3, cap * cap));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dalpha_, cap));
-        GPRY_TRY(dev_alloc(ctx, &ctx->dvec, 8 * cap + 4096));
+        const int64_t counts[] = {cap * dp, cap * dp, cap, cap, cap * cap, cap * cap, cap * cap,
+                                  cap * cap, cap * cap, cap, 8 * cap + 4096};
+        // nothing is valid while the buffers are being replaced: a failed allocation leaves an empty
+        // context (cap = 0) that the next set_train allocates afresh, never stale or NULL pointers
+        // behind the old capacity
+        ctx->cap = 0; ctx->dp_cap = 0; ctx->N = 0; ctx->Np = 0;
+        ctx->factor_valid = false; ctx->lml_cache = false;
+        for (auto b : bufs) { if (*b) { (void)hipFree(*b); *b = nullptr; } }
+        for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) {
+            int rc = dev_alloc(ctx, bufs[i], counts[i]);
+            if (rc) {
+                for (auto b : bufs) { if (*b) { (void)hipFree(*b); *b = nullptr; } }
+                return rc;
+            }
+        }
         ctx->cap = cap;
         ctx->dp_cap = dp;
         ctx->kst_cap = 0; if (ctx->dKst) { GPRY_TRY(dev_free(ctx, ctx->dKst)); ctx->dKst = nullptr; }

@@ -36,11 +36,22 @@ except Exception:  # pragma: no cover
 
 
 def default_device_index():
-    """GPU of this process: ``GPRY_HIP_DEVICE`` or ``LOCAL_RANK`` (one process per GPU), else 0."""
+    """GPU of this process: ``GPRY_HIP_DEVICE`` or ``LOCAL_RANK`` (one process per GPU), else 0.
+
+    An index beyond the visible devices raises: two ranks silently sharing a GPU is what made the
+    RCCL bootstrap fail with "invalid usage" (a communicator cannot hold one device twice).
+    ``GPRY_HIP_DEVICE_WRAP=1`` restores the wrap-around for development boxes with fewer GPUs
+    than ranks (no RCCL communicator can be built there)."""
     for var in ("GPRY_HIP_DEVICE", "LOCAL_RANK"):
         if os.environ.get(var, "") != "":
-            n = _lib.device_count()
-            return int(os.environ[var]) % max(n, 1)
+            n, idx = _lib.device_count(), int(os.environ[var])
+            if n > 0 and idx >= n:
+                if os.environ.get("GPRY_HIP_DEVICE_WRAP", "") == "1":
+                    return idx % n
+                raise _lib.GpryHipError(
+                    f"{var}={idx} but only {n} GPU(s) are visible: one process per GPU "
+                    "(set GPRY_HIP_DEVICE_WRAP=1 to share devices, without RCCL)")
+            return idx
     return 0
 
 

@@ -49,12 +49,17 @@ def fit_gpr_parallel(gpr, new_X, new_y, comm=None, fit="full", n_restarts=None,
     ranks; ``"simple"`` -- one run per rank; ``None``/``False`` -- theta kept.  As in the
     reference only rank 0 starts from the current theta (``start_from_current =
     mpi.is_main_process``, run.py:1251); the other ranks draw their starts from their own
-    ``gpr.random_state`` stream.  Ties are broken towards the lowest rank (``np.argmax``,
+    ``gpr.random_state`` stream (an int / None ``random_state`` is replaced by this rank's child of
+    ``SeedSequence(seed).spawn(world)`` first, so that the ranks do not optimise duplicates).  Ties are broken towards the lowest rank (``np.argmax``,
     run.py:1287).  Returns ``(best_lml, best_rank, lml_per_rank)``; afterwards every rank's
     ``gpr`` holds the winning theta and a factor for it.
     """
     world = 1 if comm is None else comm.world
     rank = 0 if comm is None else comm.rank
+    if world > 1 and (gpr.random_state is None or isinstance(gpr.random_state, (int, np.integer))):
+        # an int seed (or None) would give every rank the same start points: each rank gets its own
+        # child stream of the seed, as Runner does (gpry/run.py:321,756 -> mpi.get_random_generator)
+        gpr.set_random_state(get_random_generator(gpr.random_state, comm))
     if fit == "full":
         total = gpr.n_restarts_optimizer if n_restarts is None else n_restarts
         n_mine = int(split_number_for_parallel_processes(total, world)[rank])
@@ -73,8 +78,8 @@ def fit_gpr_parallel(gpr, new_X, new_y, comm=None, fit="full", n_restarts=None,
         # ranks without a run still need the new rows (the reference ships them the whole
         # pickled model afterwards); theta untouched
         gpr.append_to_data(new_X, new_y, fit_classifier=fit_classifier, fit_gpr=False)
-        lml = -np.inf if fit in ("full", "simple") else float(
-            getattr(gpr, "log_marginal_likelihood_value_", -np.inf))
+        held = getattr(gpr, "log_marginal_likelihood_value_", None)
+        lml = -np.inf if (fit in ("full", "simple") or held is None) else float(held)
     theta = np.asarray(gpr.kernel_.theta, dtype=float)
     if comm is None:
         return lml, 0, np.array([lml])

@@ -182,6 +182,9 @@ int gpry_comm_unique_id(uint8_t id[128]);
 int gpry_comm_init(gpry_ctx* ctx, int world, int rank, const uint8_t id[128],
                    gpry_comm** out);
 int gpry_comm_destroy(gpry_comm* comm);
+/* what RCCL itself reports for this communicator: ncclCommCount / ncclCommUserRank / ncclCommCuDevice
+ * (any pointer may be NULL).  bench.py prints the count as config.rccl_ranks. */
+int gpry_comm_info(gpry_comm* comm, int* world, int* rank, int* device);
 /* all-gather of `bytes` host bytes per rank (staged through device buffers, RCCL) */
 int gpry_comm_allgather(gpry_comm* comm, const void* send, int64_t bytes, void* recv);
 /* all-reduce(max) of n doubles */

@@ -185,6 +185,40 @@ def test_two_rank_restart_farm():
     np.testing.assert_allclose(lm, r0[3], rtol=1e-12)
 
 
+def test_int_seed_gives_each_rank_of_the_farm_its_own_start_points():
+    """An int ``random_state`` must not make the ranks optimise duplicates: the farm hands rank r child r
+    of ``SeedSequence(seed).spawn(world)`` (gpry/mpi.py:32-50, gpry/run.py:321,756)."""
+    from gpry_amd.parallel import fit_gpr_parallel
+
+    class FakeComm:
+        world = 2
+
+        def __init__(self, rank):
+            self.rank = rank
+
+        def allgather(self, a):
+            return np.stack([np.asarray(a)] * self.world)
+
+    g = load_golden("fit")
+    p = "f6_k3_"
+    X, y = g[p + "X"][:24], g[p + "y"][:24]
+    draws = []
+    for rank in range(2):
+        gpr = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=2, random_state=7)
+        gpr.kernel_ = gpr.kernel.clone_with_theta(gpr.kernel.theta)
+        fit_gpr_parallel(gpr, X, y, comm=FakeComm(rank), fit=None)
+        assert isinstance(gpr.random_state, np.random.Generator)
+        ref = np.random.default_rng(np.random.SeedSequence(7).spawn(2)[rank])
+        draws.append(gpr.random_state.uniform(size=3))
+        np.testing.assert_array_equal(draws[-1], ref.uniform(size=3))
+    assert not np.array_equal(draws[0], draws[1])
+    # a single process keeps the reference's single-rank behaviour (the seed is left alone)
+    gpr = make_gpr(g[p + "bounds"], 3, random_state=7)
+    gpr.kernel_ = gpr.kernel.clone_with_theta(gpr.kernel.theta)
+    fit_gpr_parallel(gpr, X, y, comm=None, fit=None)
+    assert gpr.random_state == 7
+
+
 # ---- x-gradients through the host mirror (oracle arithmetic underneath) -----------------------
 @pytest.mark.parametrize("kid", [0, 2, 3])
 def test_host_predict_gradients_and_logexp_gradient_vs_reference(kid):
