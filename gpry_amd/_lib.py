@@ -74,6 +74,20 @@ SIGNATURES = {
     "gpry_comm_allgather": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "gpry_comm_allreduce_max": (C.c_int, [_vp, _vp, C.c_int64]),
     "gpry_comm_barrier": (C.c_int, [_vp]),
+    "gpry_group_create": (C.c_int, [C.c_int, _P(C.c_int), _vp, _P(_vp)]),
+    "gpry_group_destroy": (C.c_int, [_vp]),
+    "gpry_group_size": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int)]),
+    "gpry_group_member": (_vp, [_vp, C.c_int]),
+    "gpry_group_last_error": (C.c_char_p, [_vp]),
+    "gpry_group_set_model": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp,
+                                       _P(GpryAffine), _P(C.c_int)]),
+    "gpry_group_set_gates": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_int, _vp]),
+    "gpry_group_sweep_logexp": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_double, C.c_double,
+                                          C.c_double, _vp, _vp, _vp, _P(C.c_int64)]),
+    "gpry_group_sweep_fetch": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    "gpry_group_sweep_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _P(C.c_int64),
+                                        _P(C.c_double), _P(C.c_int)]),
+    "gpry_group_lml_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "gpry_timing_reset": (C.c_int, [_vp]),
     "gpry_timing_get": (C.c_int, [_vp, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
     "gpry_microbench": (C.c_int, [_vp, C.c_int, C.c_int64, _P(C.c_double)]),
@@ -126,6 +140,18 @@ def device_count():
     return n.value
 
 
+def make_affine(x_lo=None, x_span=None, y_mean=0.0, y_std=1.0, clip_hi=np.inf):
+    tf = GpryAffine()
+    tf.has_x_affine = 0 if x_lo is None else 1
+    if x_lo is not None:
+        for k in range(len(x_lo)):
+            tf.x_lo[k] = float(x_lo[k])
+            tf.x_span[k] = float(x_span[k])
+    tf.y_mean, tf.y_std = float(y_mean), float(y_std)
+    tf.clip_hi = float(clip_hi)
+    return tf
+
+
 class Device:
     """One ``gpry_ctx``: the device-resident GP state of one GPU."""
 
@@ -142,6 +168,16 @@ class Device:
         self.N = 0
         self.d = 0
 
+    @classmethod
+    def _view(cls, handle, device):
+        """Non-owning wrapper of a context that belongs to a ``DeviceGroup``."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        self.device, self.N, self.d = int(device), 0, 0
+        return self
+
     # -- plumbing -------------------------------------------------------------------
     def _check(self, rc, what):
         if rc != 0:
@@ -149,6 +185,9 @@ class Device:
             raise GpryHipError(f"{what} failed ({rc}): {msg}")
 
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self._h = None
+            return
         if getattr(self, "_h", None):
             try:
                 self._lib.gpry_ctx_destroy(self._h)
@@ -191,14 +230,7 @@ class Device:
                     "gpry_set_theta")
 
     def set_affine(self, x_lo=None, x_span=None, y_mean=0.0, y_std=1.0, clip_hi=np.inf):
-        tf = GpryAffine()
-        tf.has_x_affine = 0 if x_lo is None else 1
-        if x_lo is not None:
-            for k in range(len(x_lo)):
-                tf.x_lo[k] = float(x_lo[k])
-                tf.x_span[k] = float(x_span[k])
-        tf.y_mean, tf.y_std = float(y_mean), float(y_std)
-        tf.clip_hi = float(clip_hi)
+        tf = make_affine(x_lo, x_span, y_mean, y_std, clip_hi)
         self._check(self._lib.gpry_set_affine(self._h, C.byref(tf)), "gpry_set_affine")
 
     # -- kernels --------------------------------------------------------------------
@@ -371,6 +403,139 @@ class Device:
         self._check(self._lib.gpry_microbench(self._h, int(kind), int(nbytes), C.byref(v)),
                     "gpry_microbench")
         return v.value
+
+
+class DeviceGroup:
+    """Several contexts behind one call (``gpry_group_*``): the sharded sweep of ONE process.
+
+    ``devices``: device indices, repeats allowed (several contexts on one GPU).  ``adopt``: a
+    ``Device`` on ``devices[0]`` that becomes member 0 and keeps belonging to its owner (the
+    regressor's own context: its factor is used as it is, the other members get the model through
+    ``set_model``).  The methods mirror ``Device``'s sweep calls on the whole pool."""
+
+    def __init__(self, devices, adopt=None):
+        self._lib = load_library()
+        devices = [int(v) for v in devices]
+        if not devices:
+            raise ValueError("DeviceGroup needs at least one device")
+        self.devices = devices
+        self._adopt = adopt             # keeps the adopted context alive as long as the group
+        arr = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        rc = self._lib.gpry_group_create(len(devices), arr, adopt._h if adopt is not None else None,
+                                         C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.gpry_group_last_error(None).decode(errors="replace")
+            self._h = None
+            raise GpryHipError(f"gpry_group_create({devices}) failed ({rc}): {msg}")
+        n, tr = C.c_int(0), C.c_int(0)
+        self._lib.gpry_group_size(self._h, C.byref(n), C.byref(tr))
+        self.size, self.transport = n.value, {0: "host", 1: "rccl"}[tr.value]
+        self.note = self._lib.gpry_group_last_error(self._h).decode(errors="replace")
+        self.sweep_epoch = 0
+        self._sweep_M = 0
+        self.d = 0
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.gpry_group_last_error(self._h).decode(errors="replace")
+            raise GpryHipError(f"{what} failed ({rc}): {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                self._lib.gpry_group_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def member(self, i):
+        """Member ``i`` as a (non-owning) ``Device`` -- options, timers."""
+        h = self._lib.gpry_group_member(self._h, int(i))
+        if not h:
+            raise IndexError(i)
+        v = Device._view(h, self.devices[i])
+        v._group = self                # the view must not outlive the group
+        return v
+
+    def set_model(self, X_, y_, alpha, kernel_id, theta, affine=None):
+        """Replicate (training set, theta, affine maps) on every owned member and factorise there."""
+        X_ = _f64(X_)
+        N, d = X_.shape
+        y_ = _f64(y_, (N,))
+        alpha = _f64(np.broadcast_to(alpha, (N,)))
+        theta = _f64(theta, (d + 1,))
+        tf = make_affine(*affine) if affine is not None else None
+        info = C.c_int(0)
+        self._check(self._lib.gpry_group_set_model(self._h, _ptr(X_), _ptr(y_), _ptr(alpha), N, d, int(kernel_id),
+                                                   _ptr(theta), C.byref(tf) if tf is not None else None,
+                                                   C.byref(info)), "gpry_group_set_model")
+        self.d = d
+        return info.value
+
+    def set_gates(self, sv=None, coef=None, gamma=0.0, intercept=0.0, positive_is_finite=True,
+                  trust_bounds=None):
+        n_sv = 0
+        if sv is not None and len(sv):
+            sv = _f64(sv)
+            n_sv = sv.shape[0]
+            coef = _f64(coef, (n_sv,))
+        else:
+            sv = coef = None
+        tb = None if trust_bounds is None else _f64(trust_bounds)
+        self._check(self._lib.gpry_group_set_gates(self._h, _ptr(sv), _ptr(coef), n_sv, float(gamma),
+                                                   float(intercept), int(bool(positive_is_finite)), _ptr(tb)),
+                    "gpry_group_set_gates")
+
+    def sweep_logexp(self, X, zeta, baseline, sigma_n, mask=None, M=None, want=("y", "sigma", "acq")):
+        if X is not None:
+            X = _f64(X)
+            M = X.shape[0]
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        out = {k: (np.empty(M) if k in want else None) for k in ("y", "sigma", "acq")}
+        n_nan = C.c_int64(0)
+        self._check(self._lib.gpry_group_sweep_logexp(
+            self._h, _ptr(X), M, _ptr(mask), float(zeta), float(baseline), float(sigma_n),
+            _ptr(out["y"]), _ptr(out["sigma"]), _ptr(out["acq"]), C.byref(n_nan)), "gpry_group_sweep_logexp")
+        out["n_nan"] = n_nan.value
+        self.sweep_epoch += 1
+        self._sweep_M = M
+        return out
+
+    def sweep_fetch(self, want=("y", "sigma")):
+        M = self._sweep_M
+        out = {k: (np.empty(M) if k in want else None) for k in ("y", "sigma", "acq")}
+        self._check(self._lib.gpry_group_sweep_fetch(self._h, M, _ptr(out["y"]), _ptr(out["sigma"]),
+                                                     _ptr(out["acq"])), "gpry_group_sweep_fetch")
+        return out
+
+    def sweep_topk(self, Kp, exclude=None):
+        """(records sorted by (acq desc, global idx desc), bound, exhausted)."""
+        Kp = int(Kp)
+        top = np.zeros(max(Kp, 1) * self.size, dtype=CAND_DTYPE)
+        n_out, bound, exh = C.c_int64(0), C.c_double(0.0), C.c_int(0)
+        if exclude is not None and len(exclude):
+            exclude = np.ascontiguousarray(np.sort(np.asarray(exclude, dtype=np.int64)))
+            nex = len(exclude)
+        else:
+            exclude, nex = None, 0
+        self._check(self._lib.gpry_group_sweep_topk(self._h, Kp, _ptr(exclude), nex, _ptr(top), C.byref(n_out),
+                                                    C.byref(bound), C.byref(exh)), "gpry_group_sweep_topk")
+        return top[:n_out.value], bound.value, bool(exh.value)
+
+    def lml_batch(self, thetas, eval_gradient=True):
+        thetas = _f64(np.atleast_2d(thetas))
+        n, w = thetas.shape
+        lml = np.empty(n)
+        grad = np.zeros((n, w)) if eval_gradient else None
+        info = np.zeros(n, dtype=np.int32)
+        self._check(self._lib.gpry_group_lml_batch(self._h, _ptr(thetas), n, int(bool(eval_gradient)), _ptr(lml),
+                                                   _ptr(grad), _ptr(info)), "gpry_group_lml_batch")
+        return (lml, grad, info) if eval_gradient else (lml, info)
 
 
 class RcclComm:

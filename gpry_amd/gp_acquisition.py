@@ -16,8 +16,11 @@ the work happens:
   ``deepcopy`` + refit;
 * with several ranks (one process per GPU) each rank sweeps a contiguous shard and the
   per-rank shortlists are merged after one all-gather (RCCL), replacing the gathers of
-  per-rank pools (:1148-1191).
+  per-rank pools (:1148-1191);
+* in ONE process (what ``gpry.Runner`` is without mpi4py, gpry/mpi.py:18-28) the same sharding
+  runs over a device group (``devices=``, ``gpry_group_*``): every visible GPU by default.
 """
+import os
 import inspect
 import sys
 import warnings
@@ -88,14 +91,19 @@ class NORA(GenericGPAcquisition):
     them on rank 0, gpry/mpi.py:118-131) -- ``True``, ``False`` (they stay ``None``, which the
     reference's interface allows: "may be None if not computed while sampling"), or ``"auto"``
     = only when a later reweighting will need them (``mc_every > 1``).  The ranking itself never
-    needs them: it works on the devices' shortlists.
+    needs them: it works on the devices' shortlists.  ``devices``: the GPUs that share the sweep
+    inside THIS process -- ``None`` (default: ``GPRY_HIP_DEVICES`` if set, else every visible GPU when
+    the process is not one rank of a multi-process launch), ``"all"``, an int ``k`` (the first ``k``
+    GPUs), a list of device indices (repeats = several contexts on one GPU) or a ready group object
+    with the ``gpry_amd._lib.DeviceGroup`` interface.  Candidate shards, model replication and the
+    shortlist merge are those of the multi-rank path; results are identical to one context's.
     """
 
     def __init__(self, bounds, preprocessing_X=None, verbose=1, acq_func="LogExp", sampler=None,
                  mc_every="1d", nlive_per_training=3, nlive_max="25d", nlive_per_dim_max=None,
                  num_repeats="5d", num_repeats_per_dim=None, precision_criterion_target=0.01,
                  nprior_per_nlive=10, max_ncalls=None, tmpdir=None, comm=None,
-                 shortlist_size=None, gather_y="auto"):
+                 shortlist_size=None, gather_y="auto", devices=None):
         super().__init__(bounds=np.asarray(bounds), preprocessing_X=preprocessing_X,
                          verbose=verbose, acq_func=acq_func)
         self.log_header = f"[ACQUISITION : {self.__class__.__name__}] "
@@ -120,6 +128,11 @@ class NORA(GenericGPAcquisition):
         self.is_last_MC_reweighted = None
         self.pool = None
         self.comm = comm
+        if devices is not None and comm is not None and getattr(comm, "world", 1) > 1:
+            raise ValueError("pass either comm= (one process per GPU) or devices= (one process, several "
+                             "GPUs), not both")
+        self.devices = devices
+        self._group = self._group_key = self._group_model = None
         self.shortlist_size = shortlist_size
         self.gather_y = gather_y
         self._X_already_proposed = np.empty((0, self.n_d))
@@ -175,36 +188,91 @@ class NORA(GenericGPAcquisition):
         per = -(-M // w)
         return min(r * per, M), min((r + 1) * per, M)
 
+    def _resolve_devices(self):
+        """Device indices of the in-process group, or None for the plain one-context sweep."""
+        from gpry_amd import _lib
+        spec = self.devices
+        if spec is None:
+            spec = os.environ.get("GPRY_HIP_DEVICES", "")
+            if spec == "":
+                if self.comm is not None or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+                    return None                     # one process per GPU: this process has its own
+                spec = "all"
+        if isinstance(spec, str):
+            spec = spec.strip().lower()
+            if spec in ("", "none", "1"):
+                return None
+            spec = "all" if spec == "all" else [int(v) for v in spec.split(",")]
+        if isinstance(spec, str):                   # "all"
+            n = _lib.device_count()
+            return list(range(n)) if n > 1 else None
+        if isinstance(spec, (int, np.integer)):
+            return list(range(int(spec))) if spec > 1 else None
+        spec = [int(v) for v in spec]
+        return spec if len(spec) > 1 else None
+
+    def _sweeper(self, gpr):
+        """What runs the sweep: the model's own context, or the device group that shards it inside
+        this process (built on first use around the model's context as member 0)."""
+        if hasattr(self.devices, "sweep_topk"):         # a ready group (tests inject a double)
+            return self.devices, True
+        if not hasattr(gpr.device, "_h"):               # not a libgpry_hip context
+            return gpr.device, False
+        if self._group is not None and self._group_key is gpr.device:
+            return self._group, True
+        devs = self._resolve_devices()
+        if devs is None:
+            return gpr.device, False
+        from gpry_amd import _lib
+        if devs[0] != gpr.device.device:                # member 0 is the model's own context
+            devs = [gpr.device.device] + [v for v in devs if v != gpr.device.device]
+        self._group = _lib.DeviceGroup(devs, adopt=gpr.device)
+        self._group_key, self._group_model = gpr.device, None
+        return self._group, True
+
     def _device_sweep(self, gpr, X, need_arrays=False):
         """Mean, std and LogExp acquisition of every row of X (this rank's shard on the
         device; y and sigma all-gathered so that every rank holds the full arrays)."""
         t0 = time()
         X = np.ascontiguousarray(X, dtype=float)
         M = len(X)
-        lo, hi = self._shard(M)
         gpr._ensure_factor()
         gpr._push_affine()
+        dev, grouped = self._sweeper(gpr)
+        lo, hi = (0, M) if grouped else self._shard(M)
+        if grouped:
+            # replicate the model on the other members when it has changed since the last sweep
+            key = (gpr.device, getattr(gpr, "_factor_epoch", None))
+            if key[1] is None or key != self._group_model:
+                kid, theta = gpr._device_theta()
+                info = dev.set_model(gpr.X_train_, gpr.y_train_, gpr.alpha, kid, theta, gpr._affine_args())
+                if info:
+                    raise np.linalg.LinAlgError(f"a group member could not factorise the model (info={info})")
+                self._group_model = key
         # classifier / trust-region verdicts: on the device if they have a device form
         mask = None
-        if hi > lo and not (hasattr(gpr, "_push_gates") and gpr._push_gates()):
-            mask = gpr._masks(X[lo:hi], False, False)
+        if hi > lo:
+            on_device = hasattr(gpr, "_push_gates") and (gpr._push_gates(sinks=[gpr.device, dev]) if grouped
+                                                         else gpr._push_gates())
+            if not on_device:
+                mask = gpr._masks(X[lo:hi], False, False)
         noise = gpr.noise_level
         if np.iterable(noise):
             raise ValueError("NORA needs a scalar noise_level (the reference passes it raw to "
                              "LogExp.f, gp_acquisition.py:1049-1051)")
         # the very same array object as last time is still resident in HBM: skip the upload
-        resident = (X is getattr(self, "_sweep_X", None) and getattr(self, "_sweep_dev", None) is gpr.device
+        resident = (X is getattr(self, "_sweep_X", None) and getattr(self, "_sweep_dev", None) is dev
                     and (lo, hi) == (self._sweep_lo, self._sweep_hi))
         sharded = self.comm is not None and self.comm.world > 1
         gather = (self.mc_every > 1) if self.gather_y == "auto" else bool(self.gather_y)
         # one rank: y / sigma stay on the device and are fetched when somebody asks for them
         # (last_MC_sample, a later reweighting) -- 16 MB of copies per 1e6 candidates otherwise
         lazy = (not sharded and not need_arrays and self.gather_y == "auto"
-                and hasattr(gpr.device, "sweep_fetch"))
+                and hasattr(dev, "sweep_fetch"))
         want = ("y", "sigma") if ((gather and sharded) or (not sharded and not lazy)) else ()
-        out = gpr.device.sweep_logexp(None if resident else X[lo:hi], self.acq_func.zeta, gpr.y_max,
-                                      noise, mask=mask, M=hi - lo, want=want)
-        self._sweep_dev = gpr.device
+        out = dev.sweep_logexp(None if resident else X[lo:hi], self.acq_func.zeta, gpr.y_max,
+                               noise, mask=mask, M=hi - lo, want=want)
+        self._sweep_dev = dev
         gpr.n_eval += M
         if out["n_nan"]:
             raise ValueError("Acquisition function value not a number: nan")
@@ -219,10 +287,12 @@ class NORA(GenericGPAcquisition):
             else:
                 y = np.concatenate([allb[r, 0, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
                 s = np.concatenate([allb[r, 1, :max(0, min(per, M - r * per))] for r in range(self.comm.world)])
-        self._lazy = (gpr.device, gpr.device.sweep_epoch) if lazy else None
+        self._lazy = (dev, dev.sweep_epoch) if lazy else None
         self._sweep_X, self._sweep_lo, self._sweep_hi = X, lo, hi
+        self._sweep_grouped = grouped
         self.stats["sweep_s"] = time() - t0
         self.stats["sweep_M"] = M
+        self.stats["sweep_contexts"] = getattr(dev, "size", 1) if grouped else 1
         return y, s
 
     def _shortlist(self, gpr, K, exclude_global):
@@ -233,6 +303,9 @@ class NORA(GenericGPAcquisition):
         if exclude_global is not None and len(exclude_global):
             e = np.asarray(exclude_global, dtype=np.int64)
             excl = e[(e >= lo) & (e < hi)] - lo
+        if getattr(self, "_sweep_grouped", False):
+            # the group merges its members' shortlists itself (same rule as below, in the library)
+            return self._sweep_dev.sweep_topk(K, exclude=excl)
         top, bound = gpr.device.sweep_topk(K, exclude=excl)
         top = top.copy()
         top["idx"] += lo

@@ -219,10 +219,14 @@ class GaussianProcessRegressor(_RM, _BE):
             return np.inf
         return self.clip_factor * max(self.y_train) - (self.clip_factor - 1) * min(self.y_train)
 
-    def _push_affine(self):
+    def _affine_args(self):
+        """(x_lo, x_span, y_mean, y_std, clip_hi) of the fused pre-/post-processing."""
         lo, span = self._x_affine()
         mean_y, std_y = self._y_affine()
-        self.device.set_affine(lo, span, mean_y, std_y, self._clip_hi())
+        return lo, span, mean_y, std_y, self._clip_hi()
+
+    def _push_affine(self):
+        self.device.set_affine(*self._affine_args())
 
     def _device_theta(self, kernel=None):
         return (kernel or self.kernel_).device_spec(self.d)
@@ -242,6 +246,7 @@ class GaussianProcessRegressor(_RM, _BE):
                 "estimator." % self.kernel_,
                 f"{info}-th leading minor of the array is not positive definite")
         self._dev_factor_ok = True
+        self._factor_epoch = getattr(self, "_factor_epoch", 0) + 1   # replicas elsewhere are stale now
         self._host_factor = {}
         self._kb = None
 
@@ -688,26 +693,30 @@ class GaussianProcessRegressor(_RM, _BE):
             mask = bits if mask is None else (mask | bits)
         return mask
 
-    def _push_gates(self, ignore_trust_region=False):
+    def _push_gates(self, ignore_trust_region=False, sinks=None):
         """Hand the classifier's decision function and the trust box to the device so that the
         sweep computes the per-candidate mask itself.  Returns True
         if the device now covers every gate ``_masks`` would apply, False if the caller must
         keep using ``_masks`` (classifier without a device form); the device gates are switched
-        off in that case."""
+        off in that case.  ``sinks``: what receives the gates (default: this model's context; a
+        sharded sweep passes its device group)."""
         clf = self.infinities_classifier
+        sinks = [self.device] if sinks is None else list(sinks)
         trust = None if (self.trust_bounds is None or ignore_trust_region) else self.trust_bounds
         params = None
         if clf is not None:
             always_finite = getattr(clf, "all_finite", False) and getattr(clf, "y_train", None) is not None
             params = clf.device_params() if hasattr(clf, "device_params") else None
             if params is None and not always_finite:
-                self.device.set_gates()
+                for snk in sinks:
+                    snk.set_gates()
                 return False
-        if params is None:
-            self.device.set_gates(trust_bounds=trust)
-        else:
-            sv, coef, gamma, intercept, pos = params
-            self.device.set_gates(sv, coef, gamma, intercept, pos, trust_bounds=trust)
+        for snk in sinks:
+            if params is None:
+                snk.set_gates(trust_bounds=trust)
+            else:
+                sv, coef, gamma, intercept, pos = params
+                snk.set_gates(sv, coef, gamma, intercept, pos, trust_bounds=trust)
         return True
 
     def _validate_X(self, X, validate):

@@ -26,6 +26,7 @@ extern "C" {
 
 typedef struct gpry_ctx gpry_ctx;
 typedef struct gpry_comm gpry_comm;
+typedef struct gpry_group gpry_group;
 
 /* kernel ids: Product(ConstantKernel, RBF | Matern(nu)) -- gpry/kernels.py:213,281,601,681 */
 enum { GPRY_RBF = 0, GPRY_MATERN12 = 1, GPRY_MATERN32 = 2, GPRY_MATERN52 = 3 };
@@ -190,6 +191,53 @@ int gpry_comm_allgather(gpry_comm* comm, const void* send, int64_t bytes, void* 
 /* all-reduce(max) of n doubles */
 int gpry_comm_allreduce_max(gpry_comm* comm, double* inout, int64_t n);
 int gpry_comm_barrier(gpry_comm* comm);
+
+/* ---- a16: single-process device group (k contexts behind one call) ------------------ */
+/* What an unmodified gpry.Runner needs to use several GPUs: it is ONE Python process (mpi4py absent
+ * => 1-rank dummy, gpry/mpi.py:18-28) that calls multi_add once per iteration (gpry/run.py:838-844).
+ * A group holds n contexts on devices[0..n) (entries may repeat: several contexts on one GPU) and
+ * drives them from n host threads inside each call.  Partitioning and merge are those of the
+ * one-process-per-GPU path: contiguous candidate shards [i*ceil(M/n), ...), model replicated and
+ * factorised on every member (gpry/mpi.py:105-131,182-218 shard X[rank::SIZE] and gather instead),
+ * shortlists merged with the hold-back rule that keeps the descending stream exact
+ * (gpry/gp_acquisition.py:1148-1191 merges per-rank pools).  adopt0 (nullable): an existing context
+ * on devices[0] becomes member 0 and stays owned by the caller (it must hold the factorised model;
+ * gpry_group_set_model leaves it alone).  If all devices are distinct the shortlist records travel
+ * by an in-process RCCL all-gather (ncclCommInitAll; transport 1), otherwise -- or with
+ * GPRY_GROUP_TRANSPORT=host, or if RCCL fails to initialise -- through the host (transport 0). */
+int gpry_group_create(int n, const int* devices, gpry_ctx* adopt0, gpry_group** out);
+int gpry_group_destroy(gpry_group* group);
+int gpry_group_size(gpry_group* group, int* n, int* transport);
+gpry_ctx* gpry_group_member(gpry_group* group, int i);     /* for per-member options / timers */
+const char* gpry_group_last_error(gpry_group* group);
+/* gpry_set_train + gpry_set_theta + gpry_set_affine + gpry_factorize on every owned member,
+ * concurrently; *info = first non-zero factorisation status. */
+int gpry_group_set_model(gpry_group* group, const double* X_, const double* y_, const double* alpha,
+                         int64_t N, int d, int kernel_id, const double* theta, const gpry_affine* tf,
+                         int* info);
+/* gpry_set_gates on every member (adopted one included) */
+int gpry_group_set_gates(gpry_group* group, const double* sv, const double* coef, int64_t n_sv,
+                         double gamma, double intercept, int positive_is_finite,
+                         const double* trust_bounds);
+/* gpry_sweep_logexp over the whole pool, member i on rows [lo_i, hi_i); arguments as there (host
+ * arrays of M rows; X == NULL re-uses the resident shards).  gpry_group_sweep_fetch likewise. */
+int gpry_group_sweep_logexp(gpry_group* group, const double* X, int64_t M, const uint8_t* mask,
+                            double zeta, double baseline, double sigma_n, double* y_all,
+                            double* sigma_all, double* acq_all, int64_t* n_nan);
+int gpry_group_sweep_fetch(gpry_group* group, int64_t M, double* y_all, double* sigma_all,
+                           double* acq_all);
+/* Global shortlist: every member selects its Kp best (gpry_sweep_topk, exclusions = sorted GLOBAL
+ * rows), the records are merged in the total order (acq desc, idx desc, idx global) and entries
+ * with acq <= max_i bound_i are held back unless every member was exhausted.  top must hold
+ * n * Kp records; *bound = largest acq that may be missing from the returned prefix (-inf if the
+ * pool is exhausted), *exhausted (nullable) = 1 if every member returned fewer than Kp. */
+int gpry_group_sweep_topk(gpry_group* group, int64_t Kp, const int64_t* exclude, int64_t n_exclude,
+                          gpry_cand* top, int64_t* n_out, double* bound, int* exhausted);
+/* n_theta independent LML (+gradient) evaluations, theta t on member t mod n, members concurrently
+ * (restart farm, gpry/run.py:1252-1293: independent start points).  thetas: n_theta x (1+d);
+ * grad: n_theta x (1+d); info: n_theta (nullable).  Every member must hold the training set. */
+int gpry_group_lml_batch(gpry_group* group, const double* thetas, int n_theta, int want_grad,
+                         double* lml, double* grad, int* info);
 
 /* ---- measurement ------------------------------------------------------------------ */
 /* Device-side timing of the last call's stages in milliseconds (HIP events on the

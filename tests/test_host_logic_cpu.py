@@ -148,6 +148,56 @@ class FakeDevice:
         return top, bound
 
 
+class FakeGroup:
+    """Test double of gpry_amd._lib.DeviceGroup: k FakeDevices on contiguous shards, shortlists merged
+    with the hold-back rule (a Python restatement of gpry_group_sweep_topk)."""
+
+    def __init__(self, model, k):
+        self.members = [FakeDevice(model) for _ in range(k)]
+        self.size, self.sweep_epoch, self.n_set_model = k, 0, 0
+
+    def set_model(self, *a):
+        self.n_set_model += 1
+        return 0
+
+    def set_gates(self, *a, **kw):
+        pass
+
+    def sweep_logexp(self, X, zeta, baseline, sigma_n, mask=None, M=None, want=()):
+        if X is not None:
+            M = len(X)
+            per = -(-M // self.size)
+            self.cuts = [(min(i * per, M), min((i + 1) * per, M)) for i in range(self.size)]
+        outs = [m.sweep_logexp(None if X is None else X[lo:hi], zeta, baseline, sigma_n)
+                for m, (lo, hi) in zip(self.members, self.cuts)]
+        self.sweep_epoch += 1
+        out = {k: np.concatenate([o[k] for o in outs]) for k in ("y", "sigma", "acq")}
+        out["n_nan"] = sum(o["n_nan"] for o in outs)
+        self._last = out
+        return out
+
+    def sweep_fetch(self, want=("y", "sigma")):
+        return self._last
+
+    def sweep_topk(self, K, exclude=None):
+        parts, gbound, exhausted = [], -np.inf, True
+        for m, (lo, hi) in zip(self.members, self.cuts):
+            if hi <= lo:
+                continue
+            ex = None if exclude is None else np.asarray([e - lo for e in exclude if lo <= e < hi], dtype=int)
+            top, bound = m.sweep_topk(K, exclude=ex)
+            top = top.copy()
+            top["idx"] += lo
+            parts.append(top)
+            gbound = max(gbound, bound)
+            exhausted = exhausted and len(top) < K
+        merged = np.concatenate(parts)
+        merged = merged[np.lexsort((-merged["idx"], -merged["acq"]))]
+        if not exhausted:
+            merged = merged[merged["acq"] > gbound]
+        return merged, (-np.inf if exhausted else gbound), exhausted
+
+
 class FakeGPR:
     """Quacks like gpry_amd.gpr.GaussianProcessRegressor where NORA / RankedPool touch it."""
 
@@ -156,6 +206,14 @@ class FakeGPR:
         self.device = FakeDevice(model)
         self.d, self.n_eval, self.noise_level = model.d, 0, model.noise_level
         self.infinities_classifier = None
+        self._factor_epoch = 1
+        self.X_train_ = self.y_train_ = self.alpha = None      # what a device group would replicate
+
+    def _device_theta(self):
+        return 0, None
+
+    def _affine_args(self):
+        return None
 
     y_max = property(lambda self: self.m.y_max)
     n = property(lambda self: self.m.n)
@@ -180,6 +238,7 @@ class FakeGPR:
 
     def append_to_data(self, X, y, **kw):
         self.m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+        self._factor_epoch += 1
 
 
 def _golden_model(tag):
@@ -216,6 +275,57 @@ def test_nora_shortlist_stream_reproduces_reference_pool(tag, shortlist):
     np.testing.assert_array_equal(Xp2, g[p + "X_pool2"])
     np.testing.assert_allclose(ap2, g[p + "acq_pool2"], rtol=1e-7)
     assert len(acq.last_MC_sample(warn_reweight=False)[1]) == int(g[p + "n_rw"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("k,shortlist", [(2, 4), (3, 64), (8, 4)])
+def test_nora_over_a_device_group_reproduces_reference_pool(tag, k, shortlist):
+    """``NORA(devices=<group>)``: the protocol between multi_add and a device group (global exclusion
+    rows, shortlist extension with held-back entries, resident pool, reweighted second call)."""
+    from gpry_amd.gp_acquisition import NORA
+    g, p, bounds, Xc, m = _golden_model(tag)
+    gpr = FakeGPR(m)
+    grp = FakeGroup(m, k)
+    npts = len(g[p + "acq_cond"]) - 1
+    acq = NORA(bounds, sampler="uniform", mc_every=2, verbose=0, shortlist_size=shortlist, devices=grp)
+    acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+    Xp, yp, ap = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
+    np.testing.assert_array_equal(Xp, g[p + "X_pool"])
+    np.testing.assert_allclose(ap, g[p + "acq_pool"], rtol=1e-8)
+    np.testing.assert_allclose(acq.pool.acq_cond, g[p + "acq_cond"], rtol=1e-6)
+    assert acq.stats["sweep_contexts"] == k and grp.n_set_model == 1
+    gpr.append_to_data(Xp, g[p + "y_new"])
+    Xp2, yp2, ap2 = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
+    np.testing.assert_array_equal(Xp2, g[p + "X_pool2"])
+    np.testing.assert_allclose(ap2, g[p + "acq_pool2"], rtol=1e-7)
+    assert len(acq.last_MC_sample(warn_reweight=False)[1]) == int(g[p + "n_rw"])
+    assert grp.n_set_model == 2                      # the model changed once between the calls
+    with pytest.raises(ValueError):
+        class C:
+            world, rank = 2, 0
+        NORA(bounds, sampler="uniform", comm=C(), devices=[0, 1])
+
+
+def test_nora_device_spec_resolution(monkeypatch):
+    from gpry_amd import _lib
+    from gpry_amd.gp_acquisition import NORA
+    b = np.array([[0.0, 1.0]] * 2)
+    monkeypatch.setattr(_lib, "device_count", lambda: 4)
+    monkeypatch.delenv("GPRY_HIP_DEVICES", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert NORA(b, verbose=0)._resolve_devices() == [0, 1, 2, 3]          # one process: every GPU
+    assert NORA(b, verbose=0, devices=2)._resolve_devices() == [0, 1]
+    assert NORA(b, verbose=0, devices=[0, 0, 0])._resolve_devices() == [0, 0, 0]
+    assert NORA(b, verbose=0, devices=[2])._resolve_devices() is None
+    monkeypatch.setenv("WORLD_SIZE", "8")                                   # one process per GPU
+    assert NORA(b, verbose=0)._resolve_devices() is None
+    monkeypatch.setenv("GPRY_HIP_DEVICES", "1,3")
+    assert NORA(b, verbose=0)._resolve_devices() == [1, 3]
+    monkeypatch.setenv("GPRY_HIP_DEVICES", "none")
+    assert NORA(b, verbose=0)._resolve_devices() is None
+    monkeypatch.setattr(_lib, "device_count", lambda: 1)
+    monkeypatch.setenv("GPRY_HIP_DEVICES", "all")
+    assert NORA(b, verbose=0)._resolve_devices() is None
 
 
 def test_ranked_pool_mirror_equals_oracle_restatement():
