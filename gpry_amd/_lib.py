@@ -92,6 +92,7 @@ SIGNATURES = {
     "gpry_timing_get": (C.c_int, [_vp, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
     "gpry_microbench": (C.c_int, [_vp, C.c_int, C.c_int64, _P(C.c_double)]),
     "gpry_debug_gemm": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 9),
+    "gpry_debug_logexp": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_double, _vp]),
     "gpry_debug_read_diag": (C.c_int, [_vp, _vp, C.c_int]),
 }
 
@@ -392,6 +393,14 @@ class Device:
                                               int(a_trans), int(b_trans), int(epi), int(kmode),
                                               int(lower_only), int(tile_map)), "gpry_debug_gemm")
         return Cout
+
+    def debug_logexp(self, mu, sigma, zeta, baseline, sigma_n):
+        """The sweep's acquisition epilogue on given (mean, std) pairs (test hook)."""
+        mu, sigma = _f64(mu), _f64(sigma)
+        acq = np.empty(len(mu))
+        self._check(self._lib.gpry_debug_logexp(self._h, _ptr(mu), _ptr(sigma), len(mu), float(zeta),
+                                                float(baseline), float(sigma_n), _ptr(acq)), "gpry_debug_logexp")
+        return acq
 
     def read_diag(self, reset=True):
         out = np.zeros(6, dtype=np.uint64)

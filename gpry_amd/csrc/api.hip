@@ -230,6 +230,28 @@ struct FinishParams {
     int want_std, want_acq;
 };
 
+// LogExp.f on one (mean, std) pair (gpry/acquisition_functions.py:1068-1074): log sqrt(0) = -inf and a
+// mean of -inf give -inf, as numpy does under the errstate the reference sets (gp_acquisition.py:1099)
+__device__ __forceinline__ double logexp_value(double y, double sd, double zeta, double baseline, double sigma_n) {
+    // std**2 - noise**2 as numpy evaluates it: both squares rounded, then the difference.  Contracted
+    // into one FMA the cancellation just above sigma_n moved the result by 1e-9 relative (found by the
+    // reference's own F5 edge vectors).  -ffp-contract=fast fuses in the backend whatever the source
+    // pragmas say, so the products are pinned behind empty asm statements.
+    double s2 = sd * sd, n2 = sigma_n * sigma_n;
+    asm volatile("" : "+v"(s2));
+    asm volatile("" : "+v"(n2));
+    double v = s2 - n2;
+    if (v < 0.0) v = 0.0;
+    double lin = (2.0 * zeta) * (y - baseline);
+    asm volatile("" : "+v"(lin));
+    return lin + log(sqrt(v));
+}
+__global__ void logexp_kernel(const double* __restrict__ mu, const double* __restrict__ sd, int64_t n, double zeta,
+                              double baseline, double sigma_n, double* __restrict__ acq) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acq[i] = logexp_value(mu[i], sd[i], zeta, baseline, sigma_n);
+}
+
 // per candidate: reduce the partials, apply the reference's post-processing chain
 // (gpry/gpr.py:1180-1231) and LogExp.f (gpry/acquisition_functions.py:1068-1074)
 __global__ void sweep_finish_kernel(const double* __restrict__ mean_part, const double* __restrict__ ss_part,
@@ -255,9 +277,7 @@ __global__ void sweep_finish_kernel(const double* __restrict__ mean_part, const 
     if (mk & GPRY_MASK_CLASSIFIED_INF) sd = 0.0;
     sig_all[m] = sd;
     if (!fp.want_acq) return;
-    double v = sd * sd - fp.sigma_n * fp.sigma_n;
-    if (v < 0.0) v = 0.0;
-    acq_all[m] = 2.0 * fp.zeta * (y - fp.baseline) + log(sqrt(v));
+    acq_all[m] = logexp_value(y, sd, fp.zeta, fp.baseline, fp.sigma_n);
 }
 
 static int ensure_sweep_buffers(gpry_ctx* ctx, int64_t M) {
@@ -929,6 +949,27 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
     HIP_TRY(ctx, hipMemcpyAsync(C, dC, sizeof(double) * crow * N, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     GPRY_TRY(dev_free(ctx, dA)); GPRY_TRY(dev_free(ctx, dB)); GPRY_TRY(dev_free(ctx, dC));
+    return 0;
+}
+
+// model-free entry to the acquisition epilogue of the sweep (the F5 edge vectors go through it)
+extern "C" int gpry_debug_logexp(gpry_ctx* ctx, const double* mu, const double* sigma, int64_t n, double zeta,
+                                 double baseline, double sigma_n, double* acq) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_debug_logexp: ctx is NULL");
+    if (n <= 0) return 0;
+    if (!mu || !sigma || !acq) return gpry_fail(ctx, -1, "debug_logexp: mu, sigma and acq must not be NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double* d = nullptr;
+    GPRY_TRY(dev_alloc(ctx, &d, 3 * n));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(d, mu, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d + n, sigma, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(logexp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, d + n, n, zeta, baseline,
+                       sigma_n, d + 2 * n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(acq, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    GPRY_TRY(dev_free(ctx, d));
     return 0;
 }
 

@@ -303,9 +303,14 @@ class NORA(GenericGPAcquisition):
         if exclude_global is not None and len(exclude_global):
             e = np.asarray(exclude_global, dtype=np.int64)
             excl = e[(e >= lo) & (e < hi)] - lo
+        # K is the length wanted for the MERGED list: shards of one pool are statistically alike, so
+        # nearly every record of every member survives the hold-back rule and 2K / members each is
+        # plenty (the caller extends the list if it was not: exactness never depends on this choice)
         if getattr(self, "_sweep_grouped", False):
             # the group merges its members' shortlists itself (same rule as below, in the library)
-            return self._sweep_dev.sweep_topk(K, exclude=excl)
+            return self._sweep_dev.sweep_topk(-(-2 * K // self._sweep_dev.size), exclude=excl)
+        if self.comm is not None and self.comm.world > 1:
+            K = -(-2 * K // self.comm.world)
         top, bound = gpr.device.sweep_topk(K, exclude=excl)
         top = top.copy()
         top["idx"] += lo

@@ -265,6 +265,12 @@ int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, double* C, 
                     int K, int a_trans, int b_trans, int epi, int kmode, int lower_only,
                     int tile_map);
 
+/* The acquisition epilogue of the sweep on caller-given (mean, std) pairs, no model involved:
+ * acq[i] = LogExp.f(mu[i], sigma[i], baseline, sigma_n, zeta) (gpry/acquisition_functions.py:1068-1074),
+ * incl. the edge cases sigma <= sigma_n and mu = -inf (-> -inf). */
+int gpry_debug_logexp(gpry_ctx* ctx, const double* mu, const double* sigma, int64_t n, double zeta,
+                      double baseline, double sigma_n, double* acq);
+
 /* Diagnostic build of the sweep GEMM (option "sweep_diag"=1): per-phase s_memtime sums
  * [issue loads, mfma block, vmcnt wait, lds store, barrier, slab count]; reset != 0 zeroes them. */
 int gpry_debug_read_diag(gpry_ctx* ctx, uint64_t out[6], int reset);

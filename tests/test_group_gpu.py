@@ -79,8 +79,8 @@ def test_group_shortlist_is_the_prefix_of_the_global_descending_stream(k):
     assert grp.size == k and grp.transport == "host"        # one device: no RCCL between the members
     kid, theta = gpr._device_theta()
     assert grp.set_model(gpr.X_train_, gpr.y_train_, gpr.alpha, kid, theta, gpr._affine_args()) == 0
-    out = grp.sweep_logexp(Xc, 0.4, gpr.y_max, gpr.noise_level)
-    ref = gpr.device.sweep_logexp(Xc, 0.4, gpr.y_max, gpr.noise_level)
+    ref = gpr.device.sweep_logexp(Xc, 0.4, gpr.y_max, gpr.noise_level)    # one context, whole pool
+    out = grp.sweep_logexp(Xc, 0.4, gpr.y_max, gpr.noise_level)           # (member 0 IS that context)
     for key in ("y", "sigma", "acq"):
         np.testing.assert_array_equal(out[key], ref[key])
     acq = out["acq"]

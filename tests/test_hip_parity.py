@@ -548,3 +548,75 @@ def test_capacity_does_not_grow_when_only_the_dimension_changes(dev):
     assert dev.factorize() == 0
     m = dev.predict(rng.uniform(0, 1, (5, 3)))
     assert np.all(np.isfinite(m))
+
+
+def test_f5_logexp_edge_vectors_through_the_device_epilogue(dev):
+    """The reference's own F5 vectors (incl. sigma <= sigma_n and mu = -inf rows) fed straight to the
+    acquisition epilogue of the sweep (gpry/acquisition_functions.py:1068-1074)."""
+    g = load_golden("predict")
+    zeta, base, noise = float(g["f5_zeta"]), float(g["f5_baseline"]), float(g["f5_noise"])
+    acq = dev.debug_logexp(g["f5_mu"], g["f5_std"], zeta, base, noise)
+    ref = g["f5_acq"]
+    assert np.isneginf(ref).sum() >= 2                       # the fixture does hold edge rows
+    assert np.array_equal(np.isneginf(acq), np.isneginf(ref)) and not np.isnan(acq).any()
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(acq[fin], ref[fin], rtol=1e-14, atol=1e-14)
+    # a few more edges: sigma exactly sigma_n, sigma = 0, mu = -inf with a large sigma, +inf baseline gap
+    mu = np.array([1.0, 2.0, -np.inf, 0.5])
+    sd = np.array([noise, 0.0, 3.0, 1e-300])
+    got = dev.debug_logexp(mu, sd, zeta, base, noise)
+    assert np.all(np.isneginf(got))
+
+
+@pytest.mark.timeout(600)
+def test_full_size_config2_sweep_topk_and_multi_add_vs_oracle():
+    """BASELINE configs[2] at full size: N=4096, d=16, Matern-5/2, M=1e6 resident pool, default chunking
+    (31 chunks).  (a) the device shortlist is the head of np.lexsort on the fetched acquisition and
+    `bound` is the first value outside it; (b) mean / std / acquisition of a random 2048-row subset
+    against the oracle; (c) NORA.multi_add(n_points=16) equals the oracle's restatement of the
+    reference (gpry/gp_acquisition.py:971-1108) run on the device shortlist united with 50 000 random
+    rows of the pool -- every candidate that can enter the ranked pool is in that union."""
+    from gpry_amd.gp_acquisition import NORA
+    from test_host_mirror_gpu import make_gpr
+    N, d, M, npts = 4096, 16, 1_000_000, 16
+    bounds, X, y, Xc = orc.synthetic_problem(N, d, M)
+    theta = np.log(np.array([4.0] + [0.3] * d))
+    gpr = make_gpr(bounds, 3, theta=theta)
+    gpr.append_to_data(X, y, fit_gpr=False)
+    acq = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, devices=[0])
+    acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+    Xp, yp, ap = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
+    dev = gpr.device
+    out = dev.sweep_fetch(("y", "sigma", "acq"))
+    # (a) exact selection over 1e6 candidates
+    a = out["acq"]
+    assert len(a) == M and not np.isnan(a).any()
+    order = np.lexsort((-np.arange(M), -a))
+    top, bound = dev.sweep_topk(256)
+    np.testing.assert_array_equal(top["idx"], order[:256])
+    np.testing.assert_array_equal(top["acq"], a[order[:256]])
+    np.testing.assert_array_equal(top["y"], out["y"][order[:256]])
+    np.testing.assert_array_equal(top["sigma"], out["sigma"][order[:256]])
+    assert bound == a[order[256]]
+    # (b) a random subset against the oracle (same tolerances as the small-size tests, DESIGN.md section 2)
+    ref = orc.OracleGPR(bounds, kernel_id=orc.MATERN52)
+    ref.theta = theta
+    ref.fitted = True
+    ref.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    rng = np.random.default_rng(5)
+    sub = np.sort(rng.choice(M, 2048, replace=False))
+    rm, rs = ref.predict(Xc[sub], return_std=True)
+    C = np.exp(theta[0]) * ref.pre_y.std_ ** 2
+    assert np.max(np.abs(out["y"][sub] - rm)) <= 1e-8 * np.max(np.abs(rm))
+    assert np.max(np.abs(out["sigma"][sub] ** 2 - rs ** 2)) <= 1e-9 * C
+    zeta = orc.auto_zeta(d)
+    racq = orc.logexp_f(rm, rs, ref.y_max, ref.noise_level, zeta)
+    assert np.array_equal(np.isneginf(a[sub]), np.isneginf(racq))
+    fin = np.isfinite(racq)
+    np.testing.assert_allclose(a[sub][fin], racq[fin], rtol=1e-6, atol=1e-6)
+    # (c) the proposals
+    union = np.union1d(order[:max(256, acq.stats["shortlist"])], rng.choice(M, 50_000, replace=False))
+    Xr, yr, ar = orc.nora_multi_add(ref, Xc[union], npts)
+    np.testing.assert_array_equal(Xp, Xr)
+    np.testing.assert_allclose(yp, yr, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(ap, ar, rtol=1e-5, atol=1e-6)
