@@ -262,6 +262,7 @@ __global__ void sweep_finish_kernel(const double* __restrict__ mean_part, const 
     if (ml >= mc) return;
     int64_t m = m0 + ml;
     double mu_ = 0.0;
+#pragma unroll 8
     for (int t = 0; t < nt; t++) mu_ += mean_part[(int64_t)t * ldp + ml];
     double y = mu_ * fp.y_std + fp.y_mean;
     y = fmin(y, fp.clip_hi);
@@ -270,6 +271,7 @@ __global__ void sweep_finish_kernel(const double* __restrict__ mean_part, const 
     y_all[m] = y;
     if (!fp.want_std) return;
     double ss = 0.0;
+#pragma unroll 8
     for (int t = 0; t < nt; t++) ss += ss_part[(int64_t)t * ldp + ml];
     double var = fp.C - ss;
     if (var < 0.0) var = 0.0;
@@ -278,6 +280,43 @@ __global__ void sweep_finish_kernel(const double* __restrict__ mean_part, const 
     sig_all[m] = sd;
     if (!fp.want_acq) return;
     acq_all[m] = logexp_value(y, sd, fp.zeta, fp.baseline, fp.sigma_n);
+}
+
+// Split-K contraction of a small batch: the slices P[y] (Np x ldp each, `stride` doubles apart) hold
+// partial products of u = V k*; per 128-row tile ti and candidate m
+//     ss_part[ti][m] = sum_{i in tile} ( sum_y P[y][i][m] )^2
+// -- the same per-tile partials the SUMSQ epilogue of the one-pass contraction leaves, slices added
+// in a fixed order (deterministic).  Block = one row tile x 64 candidates, 4 waves x 32 rows.
+template <int NS>
+__global__ __launch_bounds__(1024) void splitk_sumsq_kernel(const double* __restrict__ P, int64_t stride,
+                                                            int64_t ldp, double* __restrict__ ss_part) {
+    // 1024 threads = 64 candidates x 16 row groups of 8 rows: every thread has its NS x 2 loads of two
+    // rows in flight at once (a 256-thread version that walked 32 rows x NS slices per thread was a
+    // chain of dependent memory round trips: 100+ us for a 20-us amount of data)
+    __shared__ double red[16][64];
+    const int ti = blockIdx.x, col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.y * 64 + col;
+    double acc = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 8; rr += 2) {
+        const int64_t off = ((int64_t)ti * 128 + rg * 8 + rr) * ldp + c;
+        double v0[NS], v1[NS];
+#pragma unroll
+        for (int y = 0; y < NS; y++) { v0[y] = P[(int64_t)y * stride + off]; v1[y] = P[(int64_t)y * stride + off + ldp]; }
+        double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+        for (int y = 0; y < NS; y++) { u0 += v0[y]; u1 += v1[y]; }      // slices in a fixed order
+        acc = fma(u0, u0, acc);
+        acc = fma(u1, u1, acc);
+    }
+    red[rg][col] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s += red[k][col];
+        ss_part[(int64_t)ti * ldp + c] = s;
+    }
 }
 
 static int ensure_sweep_buffers(gpry_ctx* ctx, int64_t M) {
@@ -349,7 +388,34 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
             StageScope s(ctx, "cross_build");
             GPRY_TRY(launch_cross_build(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
         }
-        if (want_std) {
+        // A batch of a few hundred to a few thousand points has fewer tiles than the GPU has workgroup
+        // slots, and its longest tile walks all Np/16 slabs alone (1 ms at Np = 4096): split every
+        // tile's k-range over grid.y so that ~512 workgroups share the contraction, keep the partial
+        // products u_y in scratch and square their sum in a second, small kernel.
+        int nsplit = 1;
+        if (want_std && ctx->opt_predict_split && M <= chunk) {
+            const int64_t tiles = (int64_t)nt * (mcp / 128);
+            while (nsplit < 16 && tiles * nsplit * 2 <= 1024 && Np / (nsplit * 2) >= 64) nsplit *= 2;
+        }
+        if (want_std && nsplit > 1) {
+            StageScope s(ctx, "sweep_gemm_splitk");
+            double* sbuf = nullptr;
+            GPRY_TRY(gemm_split_scratch(ctx, nsplit, Np * mcp, &sbuf));
+            GemmArgs g = {};
+            g.A = ctx->dV; g.lda = Np; g.B = Kst; g.ldb = mcp; g.C = sbuf; g.ldc = mcp;
+            g.M = (int)Np; g.N = (int)mcp; g.K = (int)Np;
+            g.kmode = KM_A_LOWER; g.tile_map = TM_ROWMAJOR;
+            g.nsplit = nsplit; g.split_buf = sbuf; g.split_stride = Np * mcp; g.skip_reduce = 1;
+            GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_STORE));
+            const dim3 rg((unsigned)nt, (unsigned)(mcp / 64));
+            switch (nsplit) {
+                case 2: hipLaunchKernelGGL(splitk_sumsq_kernel<2>, rg, dim3(1024), 0, ctx->stream, sbuf, Np * mcp, mcp, ss_part); break;
+                case 4: hipLaunchKernelGGL(splitk_sumsq_kernel<4>, rg, dim3(1024), 0, ctx->stream, sbuf, Np * mcp, mcp, ss_part); break;
+                case 8: hipLaunchKernelGGL(splitk_sumsq_kernel<8>, rg, dim3(1024), 0, ctx->stream, sbuf, Np * mcp, mcp, ss_part); break;
+                default: hipLaunchKernelGGL(splitk_sumsq_kernel<16>, rg, dim3(1024), 0, ctx->stream, sbuf, Np * mcp, mcp, ss_part); break;
+            }
+            HIP_TRY(ctx, hipGetLastError());
+        } else if (want_std) {
             StageScope s(ctx, "sweep_gemm");
             GemmArgs g = {};
             g.A = ctx->dV; g.lda = Np; g.B = Kst; g.ldb = mcp; g.C = ss_part; g.ldc = mcp;
@@ -475,6 +541,31 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         return 0;
     }
     PredictSetGuard guard(ctx);
+    if (M <= 4096) {
+        // A few thousand points: candidates, mask and results live in the pinned, device-mapped staging
+        // buffer that the kernels read and write directly.  Four pageable hipMemcpyAsync calls cost more
+        // (~100 us together) than the whole contraction of such a batch.
+        const int64_t xb = round_up(sizeof(double) * M * ctx->d, 256), mb = round_up(M, 256), ob = round_up(sizeof(double) * M, 256);
+        GPRY_TRY(ensure_pinned(ctx, xb + mb + 3 * ob));
+        char* h = (char*)ctx->hpin;
+        char* hd = (char*)ctx->hpin_dev;
+        memcpy(h, X, sizeof(double) * M * ctx->d);
+        if (mask) memcpy(h + xb, mask, (size_t)M);
+        struct Saved { double* X; uint8_t* m; double *y, *s, *a; int64_t cap; } sv =
+            {ctx->dXc, ctx->dmask, ctx->dy_all, ctx->dsig_all, ctx->dacq_all, ctx->sw_cap};
+        ctx->dXc = (double*)hd; ctx->dmask = (uint8_t*)(hd + xb);
+        ctx->dy_all = (double*)(hd + xb + mb); ctx->dsig_all = (double*)(hd + xb + mb + ob);
+        ctx->dacq_all = (double*)(hd + xb + mb + 2 * ob);
+        int rc = run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        ctx->dXc = sv.X; ctx->dmask = sv.m; ctx->dy_all = sv.y; ctx->dsig_all = sv.s; ctx->dacq_all = sv.a; ctx->sw_cap = sv.cap;
+        ctx->sw_M = 0;                       // the staging buffer is not a resident candidate set
+        if (rc) return rc;
+        if (e != hipSuccess) return gpry_fail(ctx, -2, "predict: %s", hipGetErrorString(e));
+        memcpy(mean, h + xb + mb, sizeof(double) * M);
+        if (std) memcpy(std, h + xb + mb + ob, sizeof(double) * M);
+        return 0;
+    }
     GPRY_TRY(upload_candidates(ctx, X, M, mask));
     GPRY_TRY(run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0));
     HIP_TRY(ctx, hipMemcpyAsync(mean, ctx->dy_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));

@@ -102,6 +102,7 @@ struct gpry_ctx {
     double* dsplit = nullptr;  // split-K partial products of the factor GEMMs
     int64_t split_cap = 0;
     int opt_split_k = 1;       // split-K for launches with fewer tiles than slots (trtri top levels, lauum)
+    int opt_predict_split = 1; // split-K contraction for predict / sweeps of a few thousand points (one chunk)
     int opt_syrk_lds = 0;         // extra dynamic LDS of the trailing update (32768: one workgroup per CU)
     int opt_lauum_lds = 0;        // extra dynamic LDS of K^-1 = V^T V (32768: one workgroup per CU)
     int opt_trtri_diag_v1 = 0;    // 0 auto, 1: single-wave inverse of the 64x64 diagonal blocks, 2: four-wave kernel
@@ -198,6 +199,7 @@ struct GemmArgs {
     int nsplit;            // > 1: split-K over grid.y into split_buf (store epilogues only), then reduced
     double* split_buf; int64_t split_stride;
     int dma_ok;            // batched launches: 1 = every item meets gemm_dma_usable (checked by the caller)
+    int skip_reduce;       // split-K: leave the slices in split_buf (the caller reduces them itself)
 };
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);

@@ -345,7 +345,7 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
     else if (!a_trans && b_trans) rc = launch_epi<false, true>(ctx, g, epi, grid);
     else if (a_trans && !b_trans) rc = launch_epi<true, false>(ctx, g, epi, grid);
     else rc = launch_epi<true, true>(ctx, g, epi, grid);
-    if (rc != 0 || g.nsplit <= 1) return rc;
+    if (rc != 0 || g.nsplit <= 1 || g.skip_reduce) return rc;
     dim3 rgrid((unsigned)nblk, 8, g.batch ? (unsigned)g.n_batch : 1u);
     hipLaunchKernelGGL(gemm_split_reduce_kernel, rgrid, dim3(256), 0, g.stream ? g.stream : ctx->stream, g,
                        epi == EPI_STORE_NEG ? -1.0 : 1.0);

@@ -620,3 +620,36 @@ def test_full_size_config2_sweep_topk_and_multi_add_vs_oracle():
     np.testing.assert_array_equal(Xp, Xr)
     np.testing.assert_allclose(yp, yr, rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(ap, ar, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,d,M", [(1000, 7, 17), (1000, 7, 130), (4096, 16, 64), (4096, 16, 1000), (2500, 5, 3000)])
+def test_split_k_contraction_of_small_batches_equals_the_one_pass_contraction(dev, N, d, M):
+    """predict(return_std=True) for 17 ... a few thousand points splits every tile's k-range over
+    several workgroups (partial products in scratch, squared after a fixed-order sum): same
+    variances as the one-pass contraction (SUMSQ epilogue) to rounding, and as the oracle."""
+    from gpry_amd import _lib
+    bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M, seed=29)
+    m = orc.OracleGPR(bounds, kernel_id=3)
+    m.theta = np.log(np.array([4.0] + [0.3] * d))
+    m.fitted = True
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    mask = np.zeros(M, dtype=np.uint8)
+    mask[1], mask[2] = _lib.MASK_CLASSIFIED_INF, _lib.MASK_OUTSIDE_TRUST
+    try:
+        dev.set_option("predict_split", 0)
+        mean_1, std_1 = dev.predict(Xc, return_std=True, mask=mask)
+        dev.timing_reset()
+        dev.set_option("predict_split", 1)
+        mean_s, std_s = dev.predict(Xc, return_std=True, mask=mask)
+        assert dev.timing("sweep_gemm_splitk")[1] == 1 and dev.timing("sweep_gemm")[1] == 0   # the path ran
+    finally:
+        dev.set_option("predict_split", 1)
+        dev.set_option("timing", 0)
+    np.testing.assert_array_equal(mean_s, mean_1)
+    C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
+    assert np.max(np.abs(std_s ** 2 - std_1 ** 2)) <= 1e-12 * C
+    assert std_s[1] == 0.0 and std_s[2] > 0.0 and np.isneginf(mean_s[1]) and np.isneginf(mean_s[2])
+    rm, rs = m.predict(Xc, return_std=True)
+    keep = mask != _lib.MASK_CLASSIFIED_INF
+    assert np.max(np.abs(std_s[keep] ** 2 - rs[keep] ** 2)) <= 1e-9 * C

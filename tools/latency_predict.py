@@ -16,7 +16,7 @@ for N, d in ((1024, 8), (4096, 16)):
     assert dev.factorize() == 0
     if len(sys.argv) > 1:
         dev.set_option("timing", int(sys.argv[1]))
-    for M in (1, 16, 17, 400):
+    for M in (1, 16, 17, 64, 400, 2000):
         Xc = rng.uniform(0, 1, (M, d))
         for std in (False, True):
             for _ in range(5):
@@ -26,7 +26,17 @@ for N, d in ((1024, 8), (4096, 16)):
             for _ in range(reps):
                 dev.predict(Xc, return_std=std)
             us = (time.perf_counter() - t0) / reps * 1e6
-            print(f"N={N} d={d} M={M:5d} std={int(std)}: {us:8.1f} us per call, {us / M:8.2f} us per point")
+            line = f"N={N} d={d} M={M:5d} std={int(std)}: {us:8.1f} us per call, {us / M:8.2f} us per point"
+            if std and M > 16:      # the same call through the one-pass contraction (round 1's path)
+                dev.set_option("predict_split", 0)
+                for _ in range(3):
+                    dev.predict(Xc, return_std=True)
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    dev.predict(Xc, return_std=True)
+                line += f"   (one-pass contraction: {(time.perf_counter() - t0) / 20 * 1e6:8.1f} us)"
+                dev.set_option("predict_split", 1)
+            print(line)
     dev.close()
 
 # one point with x-gradients (what a gradient-based acquisition optimiser calls per step)
