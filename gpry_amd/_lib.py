@@ -55,6 +55,7 @@ SIGNATURES = {
     "gpry_kernel_cross": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "gpry_factorize": (C.c_int, [_vp, _P(C.c_int)]),
     "gpry_get_factor": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gpry_append_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _P(C.c_int)]),
     "gpry_lml": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_double), _vp, _P(C.c_int)]),
     "gpry_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "gpry_predict_grad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
@@ -254,6 +255,21 @@ class Device:
     def factorize(self):
         info = C.c_int(0)
         self._check(self._lib.gpry_factorize(self._h, C.byref(info)), "gpry_factorize")
+        return info.value
+
+    def append_rows(self, Xnew_, ynew_, alphanew):
+        """Extend the factor by the rows ``Xnew_`` (bordered update, fixed theta).  Returns ``info``."""
+        Xnew_ = _f64(np.atleast_2d(Xnew_))
+        k = Xnew_.shape[0]
+        if Xnew_.shape[1] != self.d:
+            raise ValueError(f"expected {self.d} columns, got {Xnew_.shape[1]}")
+        ynew_ = _f64(ynew_, (k,))
+        alphanew = _f64(np.broadcast_to(alphanew, (k,)))
+        info = C.c_int(0)
+        self._check(self._lib.gpry_append_rows(self._h, _ptr(Xnew_), _ptr(ynew_), _ptr(alphanew), k,
+                                               C.byref(info)), "gpry_append_rows")
+        if info.value == 0:
+            self.N += k
         return info.value
 
     def get_factor(self, want_L=True, want_V=True, want_alpha=True):

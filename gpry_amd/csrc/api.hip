@@ -337,7 +337,7 @@ static int ensure_sweep_buffers(gpry_ctx* ctx, int64_t M) {
 
 // runs the chunked sweep over candidates resident in ctx->dXc
 static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bool want_acq,
-                     double zeta, double baseline, double sigma_n) {
+                     double zeta, double baseline, double sigma_n, bool allow_split = false) {
     const int64_t Np = ctx->Np;
     const int nt = (int)(Np / 128);
     int64_t chunk = ctx->opt_sweep_chunk;
@@ -392,8 +392,11 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
         // slots, and its longest tile walks all Np/16 slabs alone (1 ms at Np = 4096): split every
         // tile's k-range over grid.y so that ~512 workgroups share the contraction, keep the partial
         // products u_y in scratch and square their sum in a second, small kernel.
+        // Only for gpry_predict: the NORA sweep keeps the one-pass contraction, whose result for a candidate
+        // does not depend on which other candidates share its launch -- a pool sharded over several
+        // contexts / GPUs then gives bit for bit what one context gives (tests/test_group_gpu.py).
         int nsplit = 1;
-        if (want_std && ctx->opt_predict_split && M <= chunk) {
+        if (allow_split && want_std && ctx->opt_predict_split && M <= chunk) {
             const int64_t tiles = (int64_t)nt * (mcp / 128);
             while (nsplit < 16 && tiles * nsplit * 2 <= 1024 && Np / (nsplit * 2) >= 64) nsplit *= 2;
         }
@@ -556,7 +559,7 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         ctx->dXc = (double*)hd; ctx->dmask = (uint8_t*)(hd + xb);
         ctx->dy_all = (double*)(hd + xb + mb); ctx->dsig_all = (double*)(hd + xb + mb + ob);
         ctx->dacq_all = (double*)(hd + xb + mb + 2 * ob);
-        int rc = run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0);
+        int rc = run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0, true);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         ctx->dXc = sv.X; ctx->dmask = sv.m; ctx->dy_all = sv.y; ctx->dsig_all = sv.s; ctx->dacq_all = sv.a; ctx->sw_cap = sv.cap;
         ctx->sw_M = 0;                       // the staging buffer is not a resident candidate set
@@ -567,7 +570,7 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         return 0;
     }
     GPRY_TRY(upload_candidates(ctx, X, M, mask));
-    GPRY_TRY(run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0));
+    GPRY_TRY(run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0, true));
     HIP_TRY(ctx, hipMemcpyAsync(mean, ctx->dy_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
     if (std) HIP_TRY(ctx, hipMemcpyAsync(std, ctx->dsig_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

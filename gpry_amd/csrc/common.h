@@ -123,6 +123,10 @@ struct gpry_ctx {
     double* dXkb = nullptr;    // kb_cap x dpad scaled candidate rows
     double* dkbout = nullptr;  // 2 * kb_cap
 
+    double* dbord = nullptr;   // border workspace of gpry_append_rows: B, U (Np x 128), T (128 x Np), S / L22 / W22
+    int64_t bord_cap = 0;
+    int64_t n_border = 0;      // rows appended by border updates since the last full factorisation (diagnostic)
+
     void* trtri_plan = nullptr;   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
 
     // host pinned staging
@@ -216,6 +220,7 @@ int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g);  // variant 1 + 
 int upload_params(gpry_ctx* ctx, const double* theta);
 int launch_scale_train(gpry_ctx* ctx);                         // dXs from dX and theta
 int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise); // full symmetric K
+int launch_kernel_rows(gpry_ctx* ctx, int64_t row0, int k, int64_t ldk, double* Bk, double* Cb);   // border rows of K
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
                        int64_t ldk, double* Kst, double* mean_part, int raw_affine,
                        hipStream_t st = nullptr);

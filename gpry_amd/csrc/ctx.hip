@@ -174,7 +174,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
                     ctx->dsig_all, ctx->dacq_all, ctx->dKst, ctx->dpart, ctx->dkeys, ctx->dhist,
                     ctx->dcand, ctx->dsel, ctx->dU, ctx->dXkb, ctx->dkbout, ctx->pr.dXc, ctx->pr.dmask,
                     ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq, ctx->dsched, ctx->dG,
-                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit};
+                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit, ctx->dbord};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     (void)hipStreamDestroy(ctx->stream);

@@ -263,6 +263,44 @@ int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
 }
 
 // ------------------------------------------------------------------------------------
+// Rows [row0, row0 + k) of the training covariance matrix K + diag(noise) of the CURRENT training set
+// (kp.N rows, scaled coordinates Xs), with the arithmetic of kernel_train_kernel (same corr_r2, diagonal
+// forced to C + noise): the border of a factor that grows by k points (gpry_append_rows).
+//   Bk[j * ldk + a] = K[row0 + a][j]   for j < row0 (0 for j >= row0 and a >= k):  the k-major image the
+//                                       product U = V B wants, like the cross-kernel panel
+//   Cb[a * 64 + b]  = K[row0 + a][row0 + b]                                        (k <= 64)
+template <int KID>
+__global__ __launch_bounds__(256) void kernel_rows_kernel(const double* __restrict__ Xs, const double* __restrict__ noise,
+                                                          int64_t row0, int k, int64_t Np, int64_t ldk,
+                                                          double* __restrict__ Bk, double* __restrict__ Cb, KernParams kp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (j, a): a fastest
+    if (idx >= Np * ldk) return;
+    const int64_t j = idx / ldk;
+    const int a = (int)(idx - j * ldk);
+    double v = 0.0;
+    if (a < k && j < row0 + k) {
+        const double* xa = Xs + (row0 + a) * kp.dpad;
+        const double* xj = Xs + j * kp.dpad;
+        double r2 = 0.0;
+        for (int c = 0; c < kp.dpad; c++) { const double df = xa[c] - xj[c]; r2 = fma(df, df, r2); }
+        v = kp.C * corr_r2<KID>(r2);
+        if (j == row0 + a) v = kp.C + noise[j];
+        if (j >= row0) { Cb[a * 64 + (int)(j - row0)] = v; v = 0.0; }
+    }
+    Bk[idx] = v;
+}
+int launch_kernel_rows(gpry_ctx* ctx, int64_t row0, int k, int64_t ldk, double* Bk, double* Cb) {
+    KernParams kp = make_kp(ctx);
+    const int64_t n = ctx->Np * ldk;
+#define KR(KID) hipLaunchKernelGGL((kernel_rows_kernel<KID>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, \
+                                   ctx->dXs, ctx->dnoise, row0, k, ctx->Np, ldk, Bk, Cb, kp)
+    DISPATCH_KID(ctx->kernel_id, KR)
+#undef KR
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // Cross-kernel panel.  Thread <-> candidate (coalesced stores along m); a workgroup
 // covers 256 candidates x 128 training rows; scaled candidate coordinates stay in
 // registers, the training chunk sits in LDS and is read wave-uniformly (broadcast).

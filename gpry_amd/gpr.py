@@ -184,6 +184,8 @@ class GaussianProcessRegressor(_RM, _BE):
     def _invalidate(self, train=False):
         if train:
             self._dev_train_ok = False
+            self._train_epoch = getattr(self, "_train_epoch", 0) + 1     # pre-processors may have been refit
+            self._affine_cache = None
         self._dev_factor_ok = False
         self._host_factor = {}
         self._kb = None
@@ -217,16 +219,28 @@ class GaussianProcessRegressor(_RM, _BE):
     def _clip_hi(self):
         if self.clip_factor is None:
             return np.inf
-        return self.clip_factor * max(self.y_train) - (self.clip_factor - 1) * min(self.y_train)
+        # np.max / np.min: the builtin max() the reference uses walks the array in Python (50 us at
+        # N = 1000 -- twice the whole device call of a one-point predict); same element either way
+        return self.clip_factor * np.max(self.y_train) - (self.clip_factor - 1) * np.min(self.y_train)
 
     def _affine_args(self):
-        """(x_lo, x_span, y_mean, y_std, clip_hi) of the fused pre-/post-processing."""
-        lo, span = self._x_affine()
-        mean_y, std_y = self._y_affine()
-        return lo, span, mean_y, std_y, self._clip_hi()
+        """(x_lo, x_span, y_mean, y_std, clip_hi) of the fused pre-/post-processing; computed once per
+        training set (the samplers call predict point by point)."""
+        key = (self.clip_factor, id(self.preprocessing_X), id(self.preprocessing_y), len(self.y_train),
+               getattr(self, "_train_epoch", 0))
+        cached = getattr(self, "_affine_cache", None)
+        if cached is None or cached[0] != key:
+            lo, span = self._x_affine()
+            mean_y, std_y = self._y_affine()
+            cached = (key, (lo, span, mean_y, std_y, self._clip_hi()))
+            self._affine_cache = cached
+        return cached[1]
 
     def _push_affine(self):
-        self.device.set_affine(*self._affine_args())
+        args = self._affine_args()
+        if getattr(self, "_dev_affine", None) is not args or getattr(self, "_dev_affine_on", None) is not self.device:
+            self.device.set_affine(*args)
+            self._dev_affine, self._dev_affine_on = args, self.device
 
     def _device_theta(self, kernel=None):
         return (kernel or self.kernel_).device_spec(self.d)
@@ -438,6 +452,12 @@ class GaussianProcessRegressor(_RM, _BE):
         self.n_last_appended_finite = int(sum(last_finite))
         if not self.n_last_appended_finite and not force_fit:
             return self
+        # fixed theta, frozen pre-processors, a valid factor on the device: the factor can grow by border
+        # rows instead of being rebuilt (the "lies" of the acquisition step)
+        border = None
+        if (not do_fit and not fit_preprocessors and self._dev_factor_ok and self._dev_train_ok
+                and self.X_train_ is not None and self.kernel_ is not None and hasattr(self.device, "append_rows")):
+            border = (self.X_train_, self.y_train_, np.asarray(self.alpha))
         self.X_train, self.y_train = X_fin, y_fin
         self.X_train_ = np.ascontiguousarray(self.preprocessing_X.transform(self.X_train))
         self.y_train_ = np.ascontiguousarray(self.preprocessing_y.transform(self.y_train))
@@ -446,10 +466,27 @@ class GaussianProcessRegressor(_RM, _BE):
         self._invalidate(train=True)
         if do_fit:
             self.fit_gpr_hyperparameters(**fit_kwargs)
-        else:
+        elif border is None or not self._border_update(*border):
             self._update_model()
         self.update_trust_region()
         return self
+
+    def _border_update(self, X_old_, y_old_, alpha_old):
+        """Extend the device factor by the rows appended last (``gpry_append_rows``) if the old
+        training rows are an unchanged prefix of the new ones; False -> the caller refactorises."""
+        n_old = len(y_old_)
+        k = len(self.y_train_) - n_old
+        if k <= 0 or not (np.array_equal(self.X_train_[:n_old], X_old_) and np.array_equal(self.y_train_[:n_old], y_old_)
+                          and np.array_equal(self.alpha[:n_old], np.broadcast_to(alpha_old, (n_old,)))):
+            return False
+        info = self.device.append_rows(self.X_train_[n_old:], self.y_train_[n_old:], self.alpha[n_old:])
+        if info != 0:
+            return False        # the full path raises the reference's "not positive definite" error
+        self._dev_train_ok = self._dev_factor_ok = True
+        self._factor_epoch = getattr(self, "_factor_epoch", 0) + 1
+        self.n_border_updates = getattr(self, "n_border_updates", 0) + 1
+        self.newly_appended_for_inv = 0
+        return True
 
     def fit(self, X, y):
         """Thin alias (the reference never calls sklearn's ``fit``; SURVEY.md preamble)."""
@@ -841,7 +878,7 @@ class GaussianProcessRegressor(_RM, _BE):
 
     def __getstate__(self):
         state = dict(self.__dict__)
-        for k in ("_dev", "_kb", "_host_factor", "_fit_devs"):
+        for k in ("_dev", "_kb", "_host_factor", "_fit_devs", "_affine_cache", "_dev_affine", "_dev_affine_on"):
             state.pop(k, None)
         state["_dev_train_ok"] = False
         state["_dev_factor_ok"] = False

@@ -104,6 +104,19 @@ int gpry_factorize(gpry_ctx* ctx, int* info);
 /* copy-out for attribute parity (L_, V_, alpha_); any pointer may be NULL */
 int gpry_get_factor(gpry_ctx* ctx, double* L, double* V, double* alpha_);
 
+/* ---- a15: grow the factor at fixed theta (bordered update instead of refactorising) ------------- */
+/* append_to_data(X, y, fit_gpr=False, fit_classifier=False) (gpry/gpr.py:577-753): k more training
+ * points with the hyper-parameters AND the pre-processors frozen, so that the old rows of X_train_,
+ * y_train_ and alpha are unchanged.  The reference rebuilds K and refactorises (gpry/gpr.py:1015-1017,
+ * O(N^3)); this extends L, V = L^-1 and alpha_ by border rows, O(k N^2) (two N x N x k products).
+ * Xnew_: k x d, ynew_: k, alphanew: k (noise_^2), all in the TRANSFORMED space as in gpry_set_train.
+ * *info = 0 ok; > 0: the enlarged matrix is not positive definite at that (1-based) column -- the
+ * model is then left without a valid factor (re-send the training set and call gpry_factorize).
+ * Used by the "lies" of BatchOptimizer (gpry/gp_acquisition.py:488-491) and RankedPool.cache_model
+ * (:1550-1553). */
+int gpry_append_rows(gpry_ctx* ctx, const double* Xnew_, const double* ynew_, const double* alphanew,
+                     int64_t k, int* info);
+
 /* ---- a4/a5: log marginal likelihood (+ gradient) ---------------------------------- */
 /* sklearn:_gpr.py:574-652 via gpry/gpr.py:876-881.  Non-PD: returns 0 with
  * *lml = -inf, grad = 0, *info > 0 (sklearn:_gpr.py:586-589).  Does not disturb the

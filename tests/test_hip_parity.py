@@ -653,3 +653,92 @@ def test_split_k_contraction_of_small_batches_equals_the_one_pass_contraction(de
     rm, rs = m.predict(Xc, return_std=True)
     keep = mask != _lib.MASK_CLASSIFIED_INF
     assert np.max(np.abs(std_s[keep] ** 2 - rs[keep] ** 2)) <= 1e-9 * C
+
+
+def test_f8_bordered_append_vs_reference(dev):
+    """F8 through gpry_append_rows: the factor of the first 32 points is extended by border rows for the
+    three appended ones (fixed theta, frozen pre-processors) and must match what the reference gets by
+    rebuilding K and refactorising (gpry/gpr.py:1015-1017)."""
+    g = load_golden("predict")
+    m = _oracle_model(g, "f8_", 2)
+    X, y, Xc = g["f8_X"], g["f8_y"], g["f8_Xc"]
+    m.append_to_data(X[:32], y[:32], fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)                                     # 32-point model, factorised
+    m.append_to_data(X[32:], y[32:], fit_gpr=False, fit_preprocessors=False)
+    assert np.array_equal(m.X_train_[:32], dev_rows := m.X_train_[:32]) and len(m.y_train_) == 35
+    assert dev.append_rows(m.X_train_[32:], m.y_train_[32:], m.alpha[32:]) == 0
+    assert dev.N == 35
+    dev.set_affine(m.pre_X.lo, m.pre_X.hi - m.pre_X.lo, m.pre_y.mean_, m.pre_y.std_, m.clip_hi())
+    L, V, a = dev.get_factor()
+    np.testing.assert_allclose(L, g["f8_L"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(V, g["f8_V"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(a, g["f8_alpha_"], rtol=1e-8, atol=1e-9)
+    assert np.all(np.triu(L, 1) == 0.0) and np.all(np.triu(V, 1) == 0.0)
+    mean, std = dev.predict(Xc, return_std=True)
+    np.testing.assert_allclose(mean, g["f8_mean_after"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(std, g["f8_std_after"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("N,k,d,kid", [(100, 1, 3, 0), (120, 20, 4, 3), (128, 1, 2, 1), (250, 70, 5, 2),
+                                       (1000, 8, 8, 3), (4090, 16, 16, 3)])
+def test_bordered_append_equals_refactorisation(dev, N, k, d, kid):
+    """gpry_append_rows against gpry_factorize on the enlarged set: sizes that stay inside the padded
+    size, cross it (120 + 20, 128 + 1, 4090 + 16), need more than one 64-row chunk (70) or new buffers;
+    then an LML evaluation and a second append on top of the first."""
+    rng = np.random.default_rng(N + k)
+    X = rng.uniform(0, 1, (N + k + 2, d))
+    y = np.sin(3 * X).sum(1) + 0.05 * rng.standard_normal(len(X))
+    alpha = np.full(len(X), 1e-4)
+    theta = np.log(np.array([2.0] + [0.35] * d))
+    dev.set_affine()                                  # the shared context may carry another test's maps
+    dev.set_train(X[:N + k], y[:N + k], alpha[:N + k])
+    dev.set_theta(kid, theta)
+    assert dev.factorize() == 0
+    L1, V1, a1 = dev.get_factor()
+    lml1 = dev.lml(theta, True)
+    dev.set_train(X[:N], y[:N], alpha[:N])
+    dev.set_theta(kid, theta)
+    assert dev.factorize() == 0
+    assert dev.append_rows(X[N:N + k], y[N:N + k], alpha[N:N + k]) == 0
+    L2, V2, a2 = dev.get_factor()
+    assert L2.shape == (N + k, N + k)
+    scale = np.max(np.abs(L1))
+    assert np.max(np.abs(L2 - L1)) <= 1e-11 * scale
+    assert np.max(np.abs(V2 - V1)) <= 1e-9 * np.max(np.abs(V1))
+    assert np.max(np.abs(a2 - a1)) <= 1e-8 * np.max(np.abs(a1))
+    assert np.all(np.triu(L2, 1) == 0.0) and np.all(np.triu(V2, 1) == 0.0)
+    assert np.max(np.abs(V2 @ L2 - np.eye(N + k))) < 1e-8
+    Xc = rng.uniform(0, 1, (40, d))
+    m2, s2 = dev.predict(Xc, return_std=True)
+    lml2 = dev.lml(theta, True)                       # works on the enlarged training set
+    assert abs(lml2[0] - lml1[0]) <= 1e-10 * abs(lml1[0])
+    np.testing.assert_allclose(lml2[1], lml1[1], rtol=1e-7, atol=1e-7 * np.max(np.abs(lml1[1])))
+    # a second append on top of the bordered factor, against a fresh factorisation of everything
+    assert dev.append_rows(X[N + k:], y[N + k:], alpha[N + k:]) == 0
+    L3, V3, a3 = dev.get_factor()
+    m3, s3 = dev.predict(Xc, return_std=True)
+    dev.set_train(X, y, alpha)
+    dev.set_theta(kid, theta)
+    assert dev.factorize() == 0
+    L4, V4, a4 = dev.get_factor()
+    m4, s4 = dev.predict(Xc, return_std=True)
+    assert np.max(np.abs(L3 - L4)) <= 1e-11 * scale and np.max(np.abs(a3 - a4)) <= 1e-8 * np.max(np.abs(a4))
+    np.testing.assert_allclose(m3, m4, rtol=1e-9, atol=1e-9)
+    assert np.max(np.abs(s3 ** 2 - s4 ** 2)) <= 1e-10 * np.exp(theta[0])
+
+
+def test_bordered_append_reports_a_non_positive_definite_border(dev):
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 1, (50, 2))
+    y = rng.standard_normal(50)
+    dev.set_affine()
+    dev.set_train(X, y, np.full(50, 1e-10))
+    dev.set_theta(0, np.log(np.array([1.0, 5.0, 5.0])))
+    if dev.factorize() != 0:
+        pytest.skip("base matrix already singular")
+    # an exact duplicate of a training point whose diagonal entry is pushed down: the Schur complement
+    # C - u^T u of the border is negative
+    info = dev.append_rows(X[:1], y[:1], np.array([-0.5]))
+    assert info == 51                                  # 1-based column of the failing pivot
+    with pytest.raises(Exception):
+        dev.predict(X[:3], return_std=True)           # no valid factor any more: the caller must refactorise

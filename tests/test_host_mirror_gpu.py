@@ -358,3 +358,44 @@ def test_device_gates_match_host_masks_in_the_sweep():
         res.append(acq.multi_add(gpr, n_points=4, bounds=gpr.trust_bounds, rng=np.random.default_rng(0)))
     for a, b in zip(res[0], res[1]):
         np.testing.assert_array_equal(a, b)
+
+
+def test_fixed_theta_appends_grow_the_factor_by_border_rows():
+    """append_to_data(fit_gpr=False, fit_classifier=False) -- the lie-append of the acquisition step
+    (gpry/gp_acquisition.py:488-491) -- extends the device factor instead of refactorising; F8 vectors,
+    then a chain of single-point lies against a model that was built in one piece."""
+    g = load_golden("predict")
+    X, y, Xc = g["f8_X"], g["f8_y"], g["f8_Xc"]
+    gpr = make_gpr(g["f8_bounds"], 2, theta=g["f8_theta"])
+    gpr.append_to_data(X[:32], y[:32], fit_gpr=False)
+    np.testing.assert_allclose(gpr.predict_std(Xc), g["f8_std_before"], rtol=1e-6, atol=1e-9)
+    gpr.append_to_data(X[32:], y[32:], fit_gpr=False, fit_classifier=False)
+    assert gpr.n_border_updates == 1 and gpr.n == 35
+    np.testing.assert_allclose(gpr.L_, g["f8_L"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gpr.V_, g["f8_V"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(gpr.alpha_, g["f8_alpha_"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(gpr.X_train_, g["f8_X_train_"], rtol=1e-15)
+    m, s = gpr.predict(Xc, return_std=True)
+    np.testing.assert_allclose(m, g["f8_mean_after"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(s, g["f8_std_after"], rtol=1e-6, atol=1e-9)
+    # lies one at a time (what BatchOptimizer.multi_add does) == the oracle with all of them appended
+    bounds, Xa, ya, Xq = orc.synthetic_like_goldens(300, 5, 64, seed=77)
+    theta = np.log(np.array([4.0] + [0.3] * 5))
+    gpr = make_gpr(bounds, 3, theta=theta)
+    gpr.append_to_data(Xa[:290], ya[:290], fit_gpr=False)
+    ref = orc.OracleGPR(bounds, kernel_id=3)
+    ref.theta, ref.fitted = theta, True
+    ref.append_to_data(Xa[:290], ya[:290], fit_gpr=False, fit_preprocessors=True)
+    for i in range(290, 300):
+        lie = gpr.predict(Xa[i:i + 1])
+        gpr.append_to_data(Xa[i:i + 1], lie, fit_gpr=False, fit_classifier=False)
+        ref.append_to_data(Xa[i:i + 1], lie, fit_gpr=False, fit_preprocessors=False)
+    assert gpr.n_border_updates == 10 and gpr.n == 300
+    mq, sq = gpr.predict(Xq, return_std=True)
+    rq, rs = ref.predict(Xq, return_std=True)
+    np.testing.assert_allclose(mq, rq, rtol=1e-8, atol=1e-8)
+    C = np.exp(theta[0]) * ref.pre_y.std_ ** 2
+    assert np.max(np.abs(sq ** 2 - rs ** 2)) <= 1e-9 * C
+    # a refit afterwards takes the normal route
+    gpr.append_to_data(Xq[:2], np.array([0.0, 1.0]), fit_gpr=False)      # fit_classifier=True: pre-processors refit
+    assert gpr.n_border_updates == 10
