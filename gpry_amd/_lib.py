@@ -59,6 +59,7 @@ SIGNATURES = {
     "gpry_lml": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_double), _vp, _P(C.c_int)]),
     "gpry_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "gpry_predict_grad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "gpry_predict_grad_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
     "gpry_set_gates": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_int, _vp]),
     "gpry_sweep_logexp": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_double, C.c_double,
                                     C.c_double, _vp, _vp, _vp, _P(C.c_int64)]),
@@ -328,6 +329,18 @@ class Device:
         self._check(self._lib.gpry_predict_grad(self._h, _ptr(x), int(bool(want_kinv)), _ptr(G),
                                                 _ptr(mg), _ptr(kg)), "gpry_predict_grad")
         return (mg, kg, G) if want_kgrad else (mg, kg)
+
+    def predict_grad_batch(self, X, want_kinv=True):
+        """``(mean, std, G^T alpha_, G^T K^-1 k*)`` for every row of ``X`` in one call."""
+        X = _f64(np.atleast_2d(X))
+        m = X.shape[0]
+        mean, std = np.empty(m), np.empty(m)
+        mg = np.empty((m, self.d))
+        kg = np.zeros((m, self.d))
+        if m:
+            self._check(self._lib.gpry_predict_grad_batch(self._h, _ptr(X), m, int(bool(want_kinv)), _ptr(mean),
+                                                          _ptr(std), _ptr(mg), _ptr(kg)), "gpry_predict_grad_batch")
+        return mean, std, mg, kg
 
     def sweep_logexp(self, X, zeta, baseline, sigma_n, mask=None, M=None, want=("y", "sigma", "acq")):
         """Run the fused sweep.  ``X=None`` re-uses the candidate set resident on the device."""

@@ -40,7 +40,7 @@ class LogExp(AcquisitionFunction):
         self.zeta = zeta
         self.sigma_n = sigma_n
         self.fixed = fixed
-        self.hasgradient = False
+        self.hasgradient = True      # x-gradient branch of __call__ (gpry/acquisition_functions.py:993-1007)
 
     @staticmethod
     def auto_zeta(dimension, scaling=0.85):

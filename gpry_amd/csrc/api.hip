@@ -506,9 +506,10 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         }
         return 0;
     }
-    if (std && M <= 16 && ctx->opt_predict_small > 0) {
-        // a handful of points with std: k* rows + one multi-vector triangular product (the panel
-        // path has a ~1 ms floor at N = 4096); partial sums come back through pinned memory
+    if (std && M <= 4 && ctx->opt_predict_small > 0) {
+        // a handful of points with std: k* rows + one multi-vector triangular product; partial sums come
+        // back through pinned memory.  54 us for one point at N = 4096 and ~16 us per further point; from
+        // five points on the split-K contraction below (138 us for up to 128 points) is faster
         const int64_t Np = ctx->Np, nmb = (Np + 255) / 256, nsb = Np / 16;
         const int64_t xb = round_up(sizeof(double) * M * ctx->d, 256);
         GPRY_TRY(ensure_pinned(ctx, xb + sizeof(double) * M * (nmb + nsb)));
@@ -607,6 +608,99 @@ int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgr
     for (int k = 0; k < d; k++) {
         if (mean_grad) mean_grad[k] = h[k];
         if (kinvk_grad) kinvk_grad[k] = want_kinv ? h[dpad + k] : 0.0;
+    }
+    return 0;
+}
+
+// column sums of squares of U (Np x ld): ss[i] = |u_i|^2, one workgroup per column
+__global__ __launch_bounds__(256) void colsumsq_kernel(const double* __restrict__ U, int64_t ld, int64_t nrow,
+                                                       double* __restrict__ ss) {
+    __shared__ double red[256];
+    const int64_t i = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < nrow; j += 256) { const double u = U[j * ld + i]; acc = fma(u, u, acc); }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ss[i] = red[0];
+}
+
+int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_kinv, double* mean, double* std,
+                            double* mean_grad, double* kinvk_grad) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_predict_grad_batch: ctx is NULL");
+    GPRY_TRY(require_model(ctx, true));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (m <= 0) return 0;
+    if (!X || !mean_grad || (want_kinv && !kinvk_grad)) return gpry_fail(ctx, -1, "predict_grad_batch: X, mean_grad and (with want_kinv) kinvk_grad must not be NULL");
+    if (m > 4096) return gpry_fail(ctx, -1, "predict_grad_batch: at most 4096 points per call (got %lld)", (long long)m);
+    hipStream_t st = ctx->stream;
+    const int64_t Np = ctx->Np, mp = round_up(m, 128);
+    const int nt = (int)(Np / 128), d = ctx->d, dpad = ctx->dpad;
+    const bool need_u = want_kinv || std != nullptr;
+    // workspace: points | k* panel (Np x mp) | U | W | mean partials (nt x mp) | |u|^2 (mp) | gradients (m x 2 dpad)
+    const int64_t need = round_up(m * d, 2) + 3 * Np * mp + (int64_t)nt * mp + mp + m * 2 * dpad;
+    if (need > ctx->g_cap) {
+        if (ctx->dG) GPRY_TRY(dev_free(ctx, ctx->dG));
+        ctx->dG = nullptr; ctx->g_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dG, need));
+        ctx->g_cap = need;
+    }
+    double* dXb = ctx->dG;
+    double* Kst = dXb + round_up(m * d, 2);
+    double* Um = Kst + Np * mp;
+    double* Wm = Um + Np * mp;
+    double* mpart = Wm + Np * mp;
+    double* ss = mpart + (int64_t)nt * mp;
+    double* gout = ss + mp;
+    HIP_TRY(ctx, hipMemcpyAsync(dXb, X, sizeof(double) * m * d, hipMemcpyHostToDevice, st));
+    StageScope scope(ctx, "predict_grad_batch");
+    const int64_t saveM = ctx->sw_M; ctx->sw_M = m;
+    int rc = launch_cross_build(ctx, dXb, 0, mp, mp, Kst, mpart, 1);
+    ctx->sw_M = saveM;
+    if (rc) return rc;
+    auto splits = [&](int64_t tiles) { int n = 1; while (n < 16 && tiles * n * 2 <= 1024 && Np / (n * 2) >= 64) n *= 2; return n; };
+    if (need_u) {       // U = V K*^T
+        GemmArgs g = {};
+        g.A = ctx->dV; g.lda = Np; g.B = Kst; g.ldb = mp; g.C = Um; g.ldc = mp;
+        g.M = (int)Np; g.N = (int)mp; g.K = (int)Np; g.kmode = KM_A_LOWER; g.tile_map = TM_ROWMAJOR;
+        g.nsplit = splits((int64_t)nt * (mp / 128));
+        if (g.nsplit > 1) { GPRY_TRY(gemm_split_scratch(ctx, g.nsplit, Np * mp, &g.split_buf)); g.split_stride = Np * mp; }
+        GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_STORE));
+        hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)m), dim3(256), 0, st, Um, mp, Np, ss);
+    }
+    if (want_kinv) {    // W = V^T U = K^-1 K*^T
+        GemmArgs g = {};
+        g.A = ctx->dV; g.lda = Np; g.B = Um; g.ldb = mp; g.C = Wm; g.ldc = mp;
+        g.M = (int)Np; g.N = (int)mp; g.K = (int)Np; g.kmode = KM_AT_LOWER; g.tile_map = TM_ROWMAJOR;
+        g.nsplit = splits((int64_t)nt * (mp / 128));
+        if (g.nsplit > 1) { GPRY_TRY(gemm_split_scratch(ctx, g.nsplit, Np * mp, &g.split_buf)); g.split_stride = Np * mp; }
+        GPRY_TRY(gemm_f64_launch(ctx, g, true, false, EPI_STORE));
+    }
+    GPRY_TRY(launch_gradx_batch(ctx, dXb, m, 1, want_kinv ? Wm : nullptr, mp, gout));
+    std::vector<double> hm((size_t)nt * mp), hs((size_t)mp), hg((size_t)m * 2 * dpad);
+    HIP_TRY(ctx, hipMemcpyAsync(hm.data(), mpart, sizeof(double) * nt * mp, hipMemcpyDeviceToHost, st));
+    if (need_u) HIP_TRY(ctx, hipMemcpyAsync(hs.data(), ss, sizeof(double) * mp, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(hg.data(), gout, sizeof(double) * m * 2 * dpad, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const double C = exp(ctx->theta[0]);
+    for (int64_t i = 0; i < m; i++) {
+        if (mean) {
+            double mu_ = 0.0;
+            for (int t = 0; t < nt; t++) mu_ += hm[(size_t)t * mp + i];
+            mean[i] = fmin(mu_ * ctx->tf.y_std + ctx->tf.y_mean, ctx->tf.clip_hi);
+        }
+        if (std) {
+            double var = C - hs[i];
+            if (var < 0.0) var = 0.0;
+            std[i] = sqrt(var) * ctx->tf.y_std;
+        }
+        for (int k = 0; k < d; k++) {
+            mean_grad[i * d + k] = hg[(size_t)i * 2 * dpad + k];
+            if (kinvk_grad) kinvk_grad[i * d + k] = want_kinv ? hg[(size_t)i * 2 * dpad + dpad + k] : 0.0;
+        }
     }
     return 0;
 }

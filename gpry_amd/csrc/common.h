@@ -173,7 +173,8 @@ enum GemmKMode {
     KM_A_LOWER = 1,   // A lower triangular (rows i, cols k): k < (ti+1)*TILE
     KM_B_LOWER = 2,   // B lower triangular (rows k, cols j): k >= tj*TILE
     KM_AT_LOWER_B_LOWER = 3, // C = A^T B with A, B lower: k >= max(ti, tj)*TILE
-    KM_B_UPPER = 4    // B upper triangular (rows k, cols j): k < (tj+1)*TILE
+    KM_B_UPPER = 4,   // B upper triangular (rows k, cols j): k < (tj+1)*TILE
+    KM_AT_LOWER = 5   // C = A^T B with A lower triangular (stored rows k, cols i): k >= ti*TILE
 };
 enum GemmEpi { EPI_STORE = 0, EPI_STORE_NEG = 1, EPI_SUB = 2, EPI_SUMSQ = 3 };
 // TM_BALANCED (gemm_dma.hip): workgroups go to the XCDs round-robin by block index, so the enumeration
@@ -230,6 +231,8 @@ int launch_predict_small_std(gpry_ctx* ctx, const double* Xc, int M, double* kst
                              double* ss_part);
 int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, double* kstar, double* G,
                  double* u, double* w, double* part, double* out);
+int launch_gradx_batch(gpry_ctx* ctx, const double* Xb, int64_t m, int raw_affine, const double* Wm, int64_t ldw,
+                       double* out);
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
                       double* grad_out_dev);
 

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs g) {
     else if (g.kmode == KM_B_LOWER) kbeg = min(K, col0);
     else if (g.kmode == KM_AT_LOWER_B_LOWER) kbeg = min(K, max(row0, col0));
     else if (g.kmode == KM_B_UPPER) kend = min(K, col0 + BN);
+    else if (g.kmode == KM_AT_LOWER) kbeg = min(K, row0);
     if (g.nsplit > 1) {      // split-K over grid.y, in units of slab pairs
         const int all = (kend - kbeg) / (2 * BK);
         const int per = (all + g.nsplit - 1) / g.nsplit;

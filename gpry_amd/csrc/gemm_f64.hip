@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     else if (g.kmode == KM_B_LOWER) kbeg = min(K, col0);
     else if (g.kmode == KM_AT_LOWER_B_LOWER) kbeg = min(K, max(row0, col0));
     else if (g.kmode == KM_B_UPPER) kend = min(K, col0 + BN);
+    else if (g.kmode == KM_AT_LOWER) kbeg = min(K, row0);
     // split-K (grid.y = g.nsplit > 1): this workgroup takes a contiguous share of the tile's slabs and
     // stores its partial product (EPI_STORE) into slice blockIdx.y of g.split_buf; the reduce kernel
     // below adds the slices in a fixed order and applies the sign.  Shortens the critical path of

@@ -674,6 +674,84 @@ int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, 
 }
 
 // ------------------------------------------------------------------------------------
+// x-gradients for a BATCH of points (the restarts of an acquisition optimiser evaluated side by side,
+// gpry/gp_acquisition.py:270-389): workgroup <-> point i, threads over the training rows; G_i is never
+// stored.  With w_i = K^-1 k*_i as column i of Wm (Np x ldw, may be NULL):
+//     out[i][c]        = sum_j G_i[j][c] alpha_[j]          (-> mean gradient)
+//     out[i][dpad + c] = sum_j G_i[j][c] Wm[j][i]           (-> std gradient)
+// Same per-pair arithmetic as gradx_kernel (exact exp / sqrt), fixed-order tree reduction.
+template <int KID>
+__global__ __launch_bounds__(256) void gradx_batch_kernel(const double* __restrict__ Xb, const double* __restrict__ Xs,
+                                                          const double* __restrict__ alpha_, const double* __restrict__ Wm,
+                                                          int64_t ldw, double* __restrict__ out, KernParams kp, AffParams ap) {
+    __shared__ double red[256];
+    const int64_t i = blockIdx.x;
+    const int t = threadIdx.x;
+    double xs[32], sa[32], sw[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        sa[k] = 0.0; sw[k] = 0.0; xs[k] = 0.0;
+        if (k < kp.d) {
+            double v = Xb[i * kp.d + k];
+            if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
+            xs[k] = v / ap.ls[k];
+        }
+    }
+    for (int64_t j = t; j < kp.N; j += 256) {
+        double diff[32];
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            diff[k] = 0.0;
+            if (k < kp.d) { diff[k] = xs[k] - Xs[j * kp.dpad + k]; r2 = fma(diff[k], diff[k], r2); }
+        }
+        double coef;
+        if (KID == GPRY_RBF) coef = -exp(-0.5 * r2);
+        else if (KID == GPRY_MATERN12) { const double r = sqrt(r2); coef = r != 0.0 ? -exp(-r) / r : 0.0; }
+        else if (KID == GPRY_MATERN32) coef = -3.0 * exp(-sqrt(r2) * SQRT3);
+        else { const double tt = sqrt(r2) * SQRT5; coef = -(5.0 / 3.0) * (1.0 + tt) * exp(-tt); }
+        const double a = alpha_[j], w = Wm ? Wm[j * ldw + i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            if (k < kp.d) {
+                double g = kp.C * coef * diff[k] / ap.ls[k];
+                if (KID == GPRY_MATERN12 && r2 == 0.0) g = -kp.C / ap.ls[k];
+                sa[k] = fma(g, a, sa[k]);
+                sw[k] = fma(g, w, sw[k]);
+            }
+        }
+    }
+    // 2 d block reductions (d <= 32): cheap next to the pair loop
+    for (int k = 0; k < kp.d; k++) {
+        for (int which = 0; which < 2; which++) {
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 32; q++) if (q == k) v = which ? sw[q] : sa[q];
+            red[t] = v;
+            __syncthreads();
+            for (int s = 128; s >= 1; s >>= 1) {
+                if (t < s) red[t] += red[t + s];
+                __syncthreads();
+            }
+            if (t == 0) out[i * 2 * kp.dpad + which * kp.dpad + k] = red[0];
+            __syncthreads();
+        }
+    }
+}
+int launch_gradx_batch(gpry_ctx* ctx, const double* Xb, int64_t m, int raw_affine, const double* Wm, int64_t ldw,
+                       double* out) {
+    KernParams kp = make_kp(ctx);
+    kp.has_aff = raw_affine && ctx->tf.has_x_affine;
+    AffParams ap = make_ap(ctx, kp.has_aff);
+#define GXB(KID) hipLaunchKernelGGL((gradx_batch_kernel<KID>), dim3((unsigned)m), dim3(256), 0, ctx->stream, \
+                                    Xb, ctx->dXs, ctx->dalpha_, Wm, ldw, out, kp, ap)
+    DISPATCH_KID(ctx->kernel_id, GXB)
+#undef GXB
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // Low-latency posterior mean for small batches (the per-point
 // calls of nested samplers / MCMC, gpry/gp_acquisition.py:769-793, gpry/mc.py:387-391).
 // One workgroup per point: mean = y_std * sum_j alpha_j C k(x, X_j) + y_mean, clipped and

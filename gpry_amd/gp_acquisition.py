@@ -31,7 +31,10 @@ from time import time
 
 import numpy as np
 
+import scipy.optimize
+
 import gpry_amd.acquisition_functions as gpryacqfuncs
+from gpry_amd.proposal import CentroidsProposer, PartialProposer, Proposer
 from gpry_amd.tools import get_Xnumber, get_random_generator, is_in_bounds, remove_0_weight_samples
 
 
@@ -76,6 +79,131 @@ class GenericGPAcquisition:
 
     def __call__(self, X, gpr, eval_gradient=False):
         return self.acq_func(X, gpr, eval_gradient=eval_gradient)
+
+
+class BatchOptimizer(GenericGPAcquisition):
+    """Batch acquisition by optimising the acquisition function from several starting points and
+    appending "lies" (gpry/gp_acquisition.py:127-525): same control flow, random-number order and
+    optimiser (scipy ``fmin_l_bfgs_b`` with the analytic x-gradient) as the reference.  On the device:
+    every objective evaluation is one ``predict`` with x-gradients (``gpry_predict_grad``), and each lie
+    extends the factor by a border row (``gpry_append_rows``, O(N^2)) where the reference rebuilds and
+    refactorises the model (gpry/gp_acquisition.py:488-491 -> gpry/gpr.py:1015-1017, O(N^3))."""
+
+    def __init__(self, bounds, preprocessing_X=None, verbose=1, acq_func="LogExp", proposer=None,
+                 acq_optimizer="fmin_l_bfgs_b", n_restarts_optimizer="5d", n_repeats_propose=10):
+        super().__init__(bounds=bounds, preprocessing_X=preprocessing_X, verbose=verbose, acq_func=acq_func)
+        self.obj_func = None
+        if proposer is None:
+            proposer = PartialProposer(self.bounds_, CentroidsProposer(self.bounds_))
+        elif not isinstance(proposer, Proposer):
+            raise TypeError(f"'proposer' must be a Proposer instance. Got {proposer} of type {type(proposer)}.")
+        else:
+            proposer.update_bounds(self.bounds_)
+        self.proposer = proposer
+        if acq_optimizer == "auto":
+            acq_optimizer = "fmin_l_bfgs_b" if self.acq_func.hasgradient else "sampling"
+        if isinstance(acq_optimizer, str):
+            if acq_optimizer == "fmin_l_bfgs_b" and not self.acq_func.hasgradient:
+                raise ValueError("In order to use the 'fmin_l_bfgs_b' optimizer the acquisition function needs "
+                                 "to be able to return gradients. Got %s" % self.acq_func)
+            if acq_optimizer not in ("fmin_l_bfgs_b", "sampling"):
+                raise ValueError("Supported internal optimizers are 'auto', 'lbfgs' or 'sampling', "
+                                 "got {0}".format(acq_optimizer))
+        self.acq_optimizer = acq_optimizer
+        self.n_restarts_optimizer = get_Xnumber(n_restarts_optimizer, "d", self.n_d, int, "n_restarts_optimizer")
+        self.n_repeats_propose = n_repeats_propose
+        self.mean_ = None
+        self.cov = None
+
+    def _objective(self, gpr):
+        def obj_func(X, eval_gradient=False):
+            X = np.expand_dims(np.asarray(X), axis=0)
+            if X.ndim != 2:
+                raise ValueError("X is {}-dimensional, however, it must be 2-dimensional.".format(X.ndim))
+            if self.preprocessing_X is not None:
+                X = self.preprocessing_X.inverse_transform(X)
+            if eval_gradient:
+                acq, grad = self.acq_func(X, gpr, eval_gradient=True)
+                return -1 * acq, -1 * grad
+            return -1 * self.acq_func(X, gpr, eval_gradient=False)
+        return obj_func
+
+    def optimize_acquisition_function(self, gpr, i, bounds=None, rng=None):
+        """One optimisation run: ``i == 0`` from the last in-bounds training point, otherwise from
+        the best of ``n_repeats_propose + 1`` finite proposals (gpry/gp_acquisition.py:270-389)."""
+        self.proposer.update(gpr)
+        use_bounds = self.bounds_ if bounds is None else bounds
+        self.proposer.update_bounds(use_bounds)
+        if not self.obj_func:
+            if not hasattr(gpr, "X_train_"):
+                raise AttributeError("The model which is given has not been fed any points.")
+            self.obj_func = self._objective(gpr)
+        px = self.preprocessing_X
+        tbounds = px.transform_bounds(use_bounds) if px is not None else use_bounds
+
+        def start(x0):
+            return self._constrained_optimization(self.obj_func, px.transform(x0) if px is not None else x0, tbounds)
+
+        if i == 0:
+            return start(next(X for X in gpr.X_train[::-1] if np.all(is_in_bounds(X, bounds, check_shape=False))))
+        d = self.bounds_.shape[0]
+        x0s = np.empty((self.n_repeats_propose + 1, d))
+        values = np.empty(self.n_repeats_propose + 1)
+        ifull = 0
+        x0 = value = None
+        for _ in range(10 * d * self.n_restarts_optimizer):
+            x0 = self.proposer.get(rng=rng)
+            value = self.acq_func(x0, gpr)
+            if not np.isfinite(value):
+                continue
+            x0s[ifull], values[ifull] = x0, np.ravel(value)[0]
+            ifull += 1
+            if ifull > self.n_repeats_propose:
+                return start(x0s[np.argmax(values)])
+        if ifull > 0:
+            return start(x0s[np.argmax(values[:ifull])])
+        return (px.transform(x0) if px is not None else x0), -1 * value
+
+    def multi_add(self, gpr, n_points=1, bounds=None, rng=None, force_resample=False):
+        """``n_points`` proposals, each the best of ``n_restarts_optimizer`` optimiser runs on the model
+        augmented by the previous proposals at their predicted means (gpry/gp_acquisition.py:391-497)."""
+        if not (isinstance(n_points, int) and n_points > 0):
+            raise ValueError(f"n_points should be int > 0, got {n_points}")
+        rng = get_random_generator(rng)
+        use_bounds = self.bounds_ if bounds is None else bounds
+        X_opts, y_lies, acq_vals = np.empty((n_points, gpr.d)), np.empty(n_points), np.empty(n_points)
+        gpr_ = deepcopy(gpr)                    # the lies go into a copy
+        n_runs = self.n_restarts_optimizer
+        proposal_X, acq_X = np.empty((n_runs, gpr_.d)), np.empty((n_runs,))
+        for ipoint in range(n_points):
+            for i in range(n_runs):
+                proposal_X[i], acq_X[i] = self.optimize_acquisition_function(gpr_, i, bounds=use_bounds, rng=rng)
+            self.obj_func = None
+            best = np.argmin(acq_X) if np.any(np.isfinite(acq_X)) else len(acq_X) - 1
+            X_opt = proposal_X[best]
+            if self.preprocessing_X is not None:
+                X_opt = self.preprocessing_X.inverse_transform(X_opt)
+            X_opt = np.array([X_opt])
+            y_lie = gpr_.predict(X_opt)
+            if ipoint < n_points - 1:
+                lie_noise = np.array([np.mean(gpr_.noise_level)]) if np.iterable(gpr_.noise_level) else None
+                gpr_.append_to_data(X_opt, y_lie, noise_level=lie_noise, fit_gpr=False, fit_classifier=False)
+            X_opts[ipoint], y_lies[ipoint], acq_vals[ipoint] = X_opt[0], y_lie[0], -1 * acq_X[best]
+        gpr.n_eval = gpr_.n_eval
+        self.stats = {"border_updates": getattr(gpr_, "n_border_updates", 0)}
+        return X_opts, y_lies, acq_vals
+
+    def _constrained_optimization(self, obj_func, initial_X, bounds):
+        if self.acq_optimizer == "fmin_l_bfgs_b":
+            res = scipy.optimize.fmin_l_bfgs_b(obj_func, initial_X, args={"eval_gradient": True}, bounds=bounds,
+                                               approx_grad=False)
+            return res[0], res[1]
+        if self.acq_optimizer == "sampling":
+            res = scipy.optimize.minimize(obj_func, initial_X, args=(False), method="Powell", bounds=bounds)
+            return res.x, res.fun
+        if callable(self.acq_optimizer):
+            return self.acq_optimizer(obj_func, initial_X, bounds=bounds)
+        raise ValueError("Unknown optimizer %s." % self.acq_optimizer)
 
 
 class NORA(GenericGPAcquisition):

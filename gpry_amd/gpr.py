@@ -178,7 +178,8 @@ class GaussianProcessRegressor(_RM, _BE):
     @property
     def device(self):
         if self._dev is None:
-            self._dev = _lib.Device(default_device_index())
+            kind = getattr(self, "_device_kind", None) or _lib.Device
+            self._dev = kind(default_device_index())
         return self._dev
 
     def _invalidate(self, train=False):
@@ -822,6 +823,36 @@ class GaussianProcessRegressor(_RM, _BE):
             return y_mean, y_std, grad_mean, grad_std
         return (y_mean, y_std, grad_mean) if return_std else (y_mean, grad_mean)
 
+    def predict_with_gradients(self, X, validate=True, ignore_trust_region=False):
+        """``predict(x, return_std=True, return_mean_grad=True, return_std_grad=True)`` for every row of
+        ``X`` in ONE device call (``gpry_predict_grad_batch``): ``(mean (m,), std (m,), mean_grad (m, d),
+        std_grad (m, d))`` with the reference's single-point conventions row by row (gpry/gpr.py:1236-1266:
+        gradients in the transformed coordinates, scaled once / twice by std_y; classifier-rejected
+        points give -inf, 0, +inf, 0; a vanishing std gives a zero std gradient).  The reference
+        evaluates one point per call ("not implemented for n_samples > 1"); a batch of acquisition
+        optimiser restarts evaluated side by side reads V once instead of twice per point."""
+        X = self._validate_X(np.atleast_2d(X), validate)
+        m, n_dims = X.shape
+        self.n_eval += m
+        if self.X_train_ is None:
+            raise ValueError("predict_with_gradients needs a model with training data")
+        self._ensure_factor()
+        self._push_affine()
+        mask = self._masks(X, validate, ignore_trust_region)
+        mean, std, mg, kg = self.device.predict_grad_batch(X, want_kinv=True)
+        _, std_y = self._y_affine()
+        grad_mean = mg * std_y
+        with np.errstate(divide="ignore", invalid="ignore"):
+            grad_std = -kg / (std / std_y)[:, None] * std_y * std_y
+        grad_std[np.isclose(std, 0.0)] = 0.0            # gpry/gpr.py:1253-1254
+        if mask is not None:
+            mean[mask != 0] = self.minus_inf_value
+            rejected = (mask & _lib.MASK_CLASSIFIED_INF) != 0
+            std[rejected] = 0.0
+            grad_mean[rejected] = self.inf_value        # gpry/gpr.py:1157-1171
+            grad_std[rejected] = 0.0
+        return mean, std, grad_mean, grad_std
+
     def predict_std(self, X, validate=True):
         """gpry/gpr.py:1275-1352 (no trust-region gate, classifier-masked rows give 0)."""
         self.n_eval += len(X)
@@ -874,6 +905,8 @@ class GaussianProcessRegressor(_RM, _BE):
                      "trust_region_factor", "trust_region_nstd", "inf_value", "minus_inf_value"):
             if hasattr(self, name):
                 setattr(c, name, copy.deepcopy(getattr(self, name)))
+        if self._dev is not None:
+            c._device_kind = type(self._dev)       # a copy gets a context of the same kind (tests: a double)
         return c
 
     def __getstate__(self):

@@ -143,6 +143,14 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
 int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgrad,
                       double* mean_grad, double* kinvk_grad);
 
+/* The same for m points in one call (m <= 4096): V is read once for all of them (two triangular
+ * products on the MFMA engine) instead of twice per point.  What a batch of acquisition-optimiser
+ * restarts evaluated side by side needs (gpry/gp_acquisition.py:270-389 runs them one after another,
+ * each step = one predict with gradients).  mean / std (nullable, m each): as gpry_predict without a
+ * mask; mean_grad, kinvk_grad: m x d, transformed units as above. */
+int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_kinv, double* mean,
+                            double* std, double* mean_grad, double* kinvk_grad);
+
 /* ---- f4: gates of the sweep evaluated on the device --------------------------------- */
 /* Replaces the host-side verdicts that gpry/gpr.py:1107-1112 (trust region, raw coordinates,
  * closed box) and :1145-1150 -> gpry/svm.py:308-347 (sklearn SVC, RBF kernel, two classes:

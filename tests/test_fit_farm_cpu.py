@@ -348,3 +348,62 @@ def test_pool_arrays_are_fetched_from_the_device_only_on_demand():
     a2 = ref.multi_add(gpr3, n_points=2, rng=np.random.default_rng(0))
     np.testing.assert_array_equal(a1[0], Xp)
     np.testing.assert_array_equal(a2[0], acq2._X_already_proposed[-2:])
+
+
+# ---- BatchOptimizer mirror (oracle arithmetic underneath) against the reference's run -----------------
+def test_batch_optimizer_mirror_vs_reference_vectors():
+    """F10b: same control flow, random-number order and optimiser as gpry/gp_acquisition.py:127-525; the
+    L-BFGS-B runs see gradients that differ from the reference's in the last digits, so optima are
+    compared to 1e-5 of the box."""
+    from gpry_amd.gp_acquisition import BatchOptimizer
+    from gpry_amd.proposal import UniformProposer
+    from gpry_amd.kernels import clone
+    g = load_golden("gradients")
+    bounds = g["f10b_bounds"]
+
+    def model():
+        gpr = make_gpr(bounds, 3)
+        k = clone(gpr.kernel)
+        k.theta = g["f10b_theta"]
+        gpr.kernel_, gpr._fitted = k, True
+        gpr.append_to_data(g["f10b_X"], g["f10b_y"], fit_gpr=False)
+        return gpr
+
+    gpr = model()
+    acq = BatchOptimizer(bounds, proposer=UniformProposer(bounds), n_restarts_optimizer=2, n_repeats_propose=1, verbose=0)
+    rng = np.random.default_rng(9)
+    x0, f0 = acq.optimize_acquisition_function(gpr, 0, bounds=bounds, rng=rng)
+    x1, f1 = acq.optimize_acquisition_function(gpr, 1, bounds=bounds, rng=rng)
+    np.testing.assert_allclose([x0, x1], g["f10b_opt_x"], atol=1e-4)
+    np.testing.assert_allclose([float(f0), float(f1)], g["f10b_opt_f"], rtol=1e-6)
+    gpr = model()
+    acq = BatchOptimizer(bounds, proposer=UniformProposer(bounds), n_restarts_optimizer=3, n_repeats_propose=2, verbose=0)
+    Xo, yl, av = acq.multi_add(gpr, n_points=3, rng=np.random.default_rng(5))
+    np.testing.assert_allclose(Xo, g["f10b_X_opts"], atol=1e-4)
+    np.testing.assert_allclose(yl, g["f10b_y_lies"], rtol=1e-6)
+    np.testing.assert_allclose(av, g["f10b_acq_vals"], rtol=1e-6)
+    assert gpr.n == 60                               # the lies went into a copy
+    with pytest.raises(TypeError):
+        BatchOptimizer(bounds, proposer="uniform")
+    with pytest.raises(ValueError):
+        acq.multi_add(gpr, n_points=0)
+
+
+def test_proposers_draw_in_the_reference_order():
+    from gpry_amd.proposal import UniformProposer, CentroidsProposer, PartialProposer
+    import scipy.stats
+    b = np.array([[-1.0, 2.0], [0.0, 4.0], [3.0, 5.0]])
+    rng, ref = np.random.default_rng(4), np.random.default_rng(4)
+    x = UniformProposer(b).get(rng)
+    np.testing.assert_array_equal(x, scipy.stats.uniform(loc=b[:, 0], scale=b[:, 1] - b[:, 0]).rvs(size=3, random_state=ref))
+
+    class G:
+        X_train = np.random.default_rng(0).uniform(b[:, 0], b[:, 1], (12, 3))
+    c = CentroidsProposer(b)
+    c.update(G())
+    c.update_bounds(b)
+    p = PartialProposer(b, c)
+    pts = np.array([p.get(np.random.default_rng(s)) for s in range(20)])
+    assert np.all(pts >= b[:, 0]) and np.all(pts <= b[:, 1]) and len(np.unique(pts[:, 0])) > 10
+    with pytest.raises(ValueError):
+        PartialProposer(b, c, random_proposal_fraction=1.5)

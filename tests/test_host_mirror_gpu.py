@@ -399,3 +399,58 @@ def test_fixed_theta_appends_grow_the_factor_by_border_rows():
     # a refit afterwards takes the normal route
     gpr.append_to_data(Xq[:2], np.array([0.0, 1.0]), fit_gpr=False)      # fit_classifier=True: pre-processors refit
     assert gpr.n_border_updates == 10
+
+
+def test_f10b_batched_gradients_and_batch_optimizer_vs_reference():
+    """gpry_predict_grad_batch against one reference call per point (F10b, incl. a point on a training
+    point) and against the device's own single-point path; BatchOptimizer on the device with its lies
+    appended as border rows."""
+    from gpry_amd.gp_acquisition import BatchOptimizer
+    from gpry_amd.proposal import UniformProposer
+    g = load_golden("gradients")
+    bounds = g["f10b_bounds"]
+    gpr = make_gpr(bounds, 3, theta=g["f10b_theta"])
+    gpr.append_to_data(g["f10b_X"], g["f10b_y"], fit_gpr=False)
+    m, s, mg, sg = gpr.predict_with_gradients(g["f10b_Xq"])
+    np.testing.assert_allclose(m, g["f10b_mean"], rtol=1e-9)
+    np.testing.assert_allclose(s, g["f10b_std"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(mg, g["f10b_mean_grad"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(sg, g["f10b_std_grad"], rtol=1e-4, atol=1e-6)
+    for i, x in enumerate(g["f10b_Xq"]):             # the one-point entry gives the same numbers
+        m1, s1, mg1, sg1 = gpr.predict(x[None, :], return_std=True, return_mean_grad=True, return_std_grad=True)
+        np.testing.assert_allclose([m[i], s[i]], [m1[0], s1[0]], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(mg[i], mg1, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(sg[i], sg1, rtol=1e-6, atol=1e-9)
+    acq = BatchOptimizer(bounds, proposer=UniformProposer(bounds), n_restarts_optimizer=2, n_repeats_propose=1, verbose=0)
+    rng = np.random.default_rng(9)
+    x0, f0 = acq.optimize_acquisition_function(gpr, 0, bounds=bounds, rng=rng)
+    x1, f1 = acq.optimize_acquisition_function(gpr, 1, bounds=bounds, rng=rng)
+    np.testing.assert_allclose([x0, x1], g["f10b_opt_x"], atol=1e-4)
+    np.testing.assert_allclose([float(f0), float(f1)], g["f10b_opt_f"], rtol=1e-6)
+    acq = BatchOptimizer(bounds, proposer=UniformProposer(bounds), n_restarts_optimizer=3, n_repeats_propose=2, verbose=0)
+    Xo, yl, av = acq.multi_add(gpr, n_points=3, rng=np.random.default_rng(5))
+    np.testing.assert_allclose(Xo, g["f10b_X_opts"], atol=1e-4)
+    np.testing.assert_allclose(yl, g["f10b_y_lies"], rtol=1e-6)
+    np.testing.assert_allclose(av, g["f10b_acq_vals"], rtol=1e-6)
+    assert acq.stats["border_updates"] == 2 and gpr.n == 60
+
+
+@pytest.mark.parametrize("kid,N,d,m", [(0, 300, 4, 5), (1, 500, 3, 130), (2, 1000, 8, 64), (3, 4096, 16, 200)])
+def test_batched_gradients_equal_the_single_point_path(kid, N, d, m):
+    """All four kernels, one and two column tiles of points, ragged N: the batch entry against m calls of
+    gpry_predict_grad / gpry_predict, plus a classifier-rejected and an out-of-trust-region point."""
+    bounds, X, y, Xq = orc.synthetic_like_goldens(N, d, m, seed=N + m)
+    Xq[3] = X[11]
+    gpr = make_gpr(bounds, kid, theta=np.log(np.array([4.0] + [0.3] * d)))
+    gpr.append_to_data(X, y, fit_gpr=False)
+    mean, std, mg, sg = gpr.predict_with_gradients(Xq)
+    mean_p, std_p = gpr.predict(Xq, return_std=True)
+    np.testing.assert_allclose(mean, mean_p, rtol=1e-10, atol=1e-10)
+    C = np.exp(gpr.kernel_.theta[0]) * gpr.preprocessing_y.std_ ** 2
+    assert np.max(np.abs(std ** 2 - std_p ** 2)) <= 1e-11 * C
+    for i in (0, 3, m - 1):
+        mgi, kgi = gpr.device.predict_grad(Xq[i], want_kinv=True)
+        std_y = gpr.preprocessing_y.std_
+        np.testing.assert_allclose(mg[i], mgi * std_y, rtol=1e-9, atol=1e-9 * np.max(np.abs(mgi * std_y)))
+        ref_sg = -kgi / (std[i] / std_y) * std_y * std_y if not np.isclose(std[i], 0) else np.zeros(d)
+        np.testing.assert_allclose(sg[i], ref_sg, rtol=1e-6, atol=1e-8 * max(1.0, np.max(np.abs(ref_sg))))

@@ -393,6 +393,42 @@ def f10_gradients(out):
             out[p + k] = np.array(v)
 
 
+def f10b_batch_optimizer(out):
+    """F10b: BatchOptimizer (gpry/gp_acquisition.py:127-525) -- optimize_acquisition_function runs from the
+    last training point and from proposed starts, the lie-append loop of multi_add -- with a uniform
+    proposer and a seeded generator; plus predict-with-gradients for a batch of points, one reference call
+    per point (the reference has no batched form)."""
+    from gpry.gp_acquisition import BatchOptimizer
+    from gpry.proposal import UniformProposer
+    N, d = 60, 3
+    bounds, X, y, Xq = gauss_problem(N, d, 9, seed=33)
+    Xq[2] = X[7]
+    theta = np.log(np.array([3.0, 0.35, 0.5, 0.25]))
+    out["f10b_bounds"], out["f10b_X"], out["f10b_y"], out["f10b_Xq"], out["f10b_theta"] = bounds, X, y, Xq, theta
+    gpr = make_gpr(bounds, 3, X, y, theta)
+    res = {k: [] for k in ("mean", "std", "mean_grad", "std_grad")}
+    for x in Xq:
+        vals = gpr.predict(x[None, :], return_std=True, return_mean_grad=True, return_std_grad=True)
+        for k, v in zip(("mean", "std", "mean_grad", "std_grad"), (vals[0][0], vals[1][0], vals[2], vals[3])):
+            res[k].append(np.array(v, dtype=float))
+    for k, v in res.items():
+        out["f10b_" + k] = np.array(v)
+    gpr = make_gpr(bounds, 3, X, y, theta)
+    acq = BatchOptimizer(bounds, proposer=UniformProposer(bounds), n_restarts_optimizer=3,
+                         n_repeats_propose=2, verbose=0)
+    Xo, yl, av = acq.multi_add(gpr, n_points=3, rng=np.random.default_rng(5))
+    out["f10b_X_opts"], out["f10b_y_lies"], out["f10b_acq_vals"] = Xo, yl, av
+    out["f10b_n_eval"] = np.array(gpr.n_eval)
+    # one optimiser run on its own: from the last training point (i = 0) and from proposals (i = 1)
+    gpr = make_gpr(bounds, 3, X, y, theta)
+    acq = BatchOptimizer(bounds, proposer=UniformProposer(bounds), n_restarts_optimizer=2,
+                         n_repeats_propose=1, verbose=0)
+    rng = np.random.default_rng(9)
+    x0, f0 = acq.optimize_acquisition_function(gpr, 0, bounds=bounds, rng=rng)
+    x1, f1 = acq.optimize_acquisition_function(gpr, 1, bounds=bounds, rng=rng)
+    out["f10b_opt_x"], out["f10b_opt_f"] = np.array([x0, x1]), np.array([float(f0), float(f1)])
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not mounted; nothing to do")
@@ -403,7 +439,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     groups = {"kernels": [f1_kernels], "factor_lml": [f2_f3_factor_lml],
               "predict": [f4_predict, f5_logexp, f8_append], "fit": [f6_fit, f9_config1],
-              "multi_add": [f7_multi_add], "gradients": [f10_gradients]}
+              "multi_add": [f7_multi_add], "gradients": [f10_gradients, f10b_batch_optimizer]}
     for name, fns in groups.items():
         out = {}
         for fn in fns:
