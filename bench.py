@@ -410,7 +410,11 @@ def main():
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
         comm, dist, comm_kind, n_rccl = connect(args, rank, world, dev)
 
-    acq = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=comm)
+    # --gpus N means N processes with one GPU each: a 1-process run must not pick up the other GPUs of
+    # the node through NORA's in-process device group (its default is every visible GPU)
+    sharded = comm is not None and world > 1
+    acq = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=comm,
+               devices=None if sharded else [local_rank])
     acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
     rng = np.random.default_rng(2)
 
@@ -568,7 +572,7 @@ def main():
     if world > 1 and args.scaling == "strong" and args.extras == "auto":
         ref = None
         if rank == 0:
-            acq1 = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=None)
+            acq1 = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=None, devices=[local_rank])
             acq1.do_MC_sample = acq.do_MC_sample
             X_new, _, _ = acq1.multi_add(gpr, n_points=npts, rng=rng)    # uploads the whole pool
             step(acq1)
