@@ -508,8 +508,9 @@ def main():
         "config": {"workload": ("BASELINE configs[2]" if world == 1 else "BASELINE configs[3]") +
                                ": 16-d correlated-Gaussian posterior, N_train=4096 in every step, "
                                "Matern-5/2, LogExp NORA sweep M=1e6, n_points=16, fit_gpr='simple'" +
-                               ("" if world == 1 else f", candidate pool sharded {world}-way, RCCL shortlist all-gather"),
-                   "N_train": N, "N_train_per_step": n_seen, "Np": Np, "d": d, "M_total": M_total,
+                               ("" if world == 1 else f", candidate pool sharded {world}-way, shortlist all-gather over "
+                                + ("RCCL" if comm_kind == "rccl" else "gloo (RCCL unavailable, --allow-gloo)")),
+                   "N_train": N, "N_train_per_step": list(n_seen), "Np": Np, "d": d, "M_total": M_total,
                    "M_per_gpu": M_rank, "n_points": npts,
                    "kernel": "ConstantKernel*Matern(nu=2.5)", "sharding": f"candidates x{world}",
                    "comm": comm_kind, "rccl_ranks": n_rccl},
