@@ -40,7 +40,9 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
     } else {
         {
             StageScope s(ctx, "potrf");
-            GPRY_TRY(ctx->opt_chol == 2 ? potrf_lower(ctx, A, ctx->Np) : potrf_lower_fused(ctx, A, ctx->Np));
+            const bool overlap = ctx->opt_chol_overlap && !ctx->opt_chol_lookahead && ctx->opt_chol_outer == 0;
+            GPRY_TRY(ctx->opt_chol == 2 ? potrf_lower(ctx, A, ctx->Np)
+                                        : overlap ? potrf_lower_overlap(ctx, A, ctx->Np) : potrf_lower_fused(ctx, A, ctx->Np));
         }
         {
             StageScope s(ctx, "trtri");

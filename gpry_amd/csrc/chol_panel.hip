@@ -11,6 +11,8 @@
 // the 64x64 factor as a dataflow on LDS flags.  LDS images use a row stride of 66 doubles:
 // MFMA fragment reads (16 rows x {k, k+1}) then hit 32 distinct bank pairs.
 #include "common.h"
+#include "gemm_dma_body.h"
+#include <algorithm>
 
 #define PLD 66
 
@@ -445,6 +447,241 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
     }
 }
 
+// The same panel step as a device function (static LDS handed in), used by the fused launch below.  Kept
+// as a second copy on purpose: routed through this function the stand-alone kernel above went from 176
+// VGPRs without scratch to 198 VGPRs + 528 B of scratch per lane, and it is the reference schedule
+// (chol_overlap = 0) that the fused one is compared with bit for bit.
+struct PanelArgs {
+    double* A; int64_t ld, j0, K0, Kfar, n_real;
+    int* info; int* arrive; int target;
+    unsigned long long* dbg; int dbg_block;
+};
+#define PANEL_SMEM_DOUBLES (4 * 64 * PLD + 64 + 8)
+
+// One panel step for the 64-row block `bx` of the panel.  FAR: the columns [Kfar, K0) -- the previous outer
+// block, 128 wide -- have not been applied to this panel by a trailing update yet (the fused schedule
+// leaves that to the panel step so that no trailing tile sits on the panel chain): their product is
+// accumulated from zero over all 128 k and then subtracted, exactly what the trailing update's SYRK tile
+// does (same MFMA sequence, same single rounding of C - acc), so the factor stays bit-identical.
+template <bool FAR>
+__device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* smem, const int bx) {
+    double* __restrict__ A = pa.A;
+    const int64_t ld = pa.ld, j0 = pa.j0, K0 = pa.K0, n_real = pa.n_real;
+    int* info = pa.info; int* arrive = pa.arrive; const int target = pa.target;
+    unsigned long long* dbg = pa.dbg; const int dbg_block = pa.dbg_block;
+    double* sD = smem;
+    double* sB = sD + 64 * PLD;
+    double* sPt = sB + 64 * PLD;
+    double* sPo = sPt + 64 * PLD;
+    double* sRd = sPo + 64 * PLD;
+    int* s_int = reinterpret_cast<int*>(sRd + 64);
+    int& s_bad = s_int[0];
+    int* s_flag = s_int + 2;
+    if (*info != 0) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const bool is_diag = bx == 0;
+    // optional section stamps of one workgroup (dbg != NULL): loads, update, factor, solve, store
+    const bool stamp = dbg != nullptr && bx == dbg_block && t == 0;
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if (stamp) ts[0] = __builtin_amdgcn_s_memtime();
+    const int64_t R = j0 + 64 * (int64_t)bx;
+    const int64_t Kfirst = FAR ? pa.Kfar : K0;     // the chunk that comes in with the first loads
+    const int kprev = (int)(j0 - K0);          // columns of the outer block already factorised: 0, 64, 128, ...
+    if (t == 0) s_bad = 0;
+    {
+        // all four blocks unconditionally (the diagonal workgroup has R == j0 and the first step of an
+        // outer block K0 == j0: those loads repeat D and land in buffers nobody reads): with the loads
+        // behind branches the 3 x 128-byte register sets went through scratch memory
+        double2 rD[8], rB[8], rPt[8], rPo[8];
+        load_block_issue(A + j0 * ld + j0, ld, t, rD);
+        load_block_issue(A + R * ld + j0, ld, t, rB);
+        load_block_issue(A + j0 * ld + Kfirst, ld, t, rPt);
+        load_block_issue(A + R * ld + Kfirst, ld, t, rPo);
+        load_block_commit(sD, t, rD);
+        load_block_commit(sB, t, rB);
+        load_block_commit(sPt, t, rPt);
+        load_block_commit(sPo, t, rPo);
+    }
+    __syncthreads();
+    if (stamp) ts[1] = __builtin_amdgcn_s_memtime();
+    // ---- left-looking update with the previous columns of the outer block, 64 at a time (the first
+    // chunk came in with the loads above; an outer block of 256 columns has up to three)
+    if (FAR) {
+        v4d accD[3], accB[4];
+#pragma unroll
+        for (int q = 0; q < 3; q++) accD[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; q++) accB[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int fc = 0; fc < 2; fc++) {
+            if (fc) {
+                __syncthreads();
+                double2 rPt[8], rPo[8];
+                load_block_issue(A + j0 * ld + Kfirst + 64, ld, t, rPt);
+                load_block_issue(A + R * ld + Kfirst + 64, ld, t, rPo);
+                load_block_commit(sPt, t, rPt);
+                load_block_commit(sPo, t, rPo);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int tl = w + 4 * q;
+                if (tl < 10) {
+                    const int rw = tl < 1 ? 0 : tl < 3 ? 1 : tl < 6 ? 2 : 3;
+                    const int n = tl - rw * (rw + 1) / 2;
+                    accD[q] = mfma_nt16<false>(accD[q], sPt + (rw * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+                }
+            }
+            if (!is_diag) {
+#pragma unroll
+                for (int n = 0; n < 4; n++)
+                    accB[n] = mfma_nt16<false>(accB[n], sPo + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int tl = w + 4 * q;
+            if (tl < 10) {
+                const int rw = tl < 1 ? 0 : tl < 3 ? 1 : tl < 6 ? 2 : 3;
+                const int n = tl - rw * (rw + 1) / 2;
+                double* T = sD + (rw * 16) * PLD + n * 16;
+                v4d v = tile_load(T, lane);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = v[e] - accD[q][e];
+                tile_store(T, v, lane);
+            }
+        }
+        if (!is_diag) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                double* U = sB + (w * 16) * PLD + n * 16;
+                v4d v = tile_load(U, lane);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = v[e] - accB[n][e];
+                tile_store(U, v, lane);
+            }
+        }
+    }
+    for (int c0 = 0; c0 < kprev; c0 += 64) {
+        if (c0 || FAR) {
+            __syncthreads();                       // everybody is done with the previous chunk
+            double2 rPt[8], rPo[8];
+            load_block_issue(A + j0 * ld + K0 + c0, ld, t, rPt);
+            if (!is_diag) load_block_issue(A + R * ld + K0 + c0, ld, t, rPo);
+            load_block_commit(sPt, t, rPt);
+            if (!is_diag) load_block_commit(sPo, t, rPo);
+            __syncthreads();
+        }
+        // D: only the ten 16x16 tiles on and below the diagonal are ever read (the factor works on the
+        // lower triangle); they are dealt round-robin to the waves (3, 3, 2, 2) instead of a full row each
+#pragma unroll 1
+        for (int tl = w; tl < 10; tl += 4) {
+            const int rw = tl < 1 ? 0 : tl < 3 ? 1 : tl < 6 ? 2 : 3;
+            const int n = tl - rw * (rw + 1) / 2;
+            double* T = sD + (rw * 16) * PLD + n * 16;
+            v4d acc = tile_load(T, lane);
+            acc = mfma_nt16<true>(acc, sPt + (rw * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+            tile_store(T, acc, lane);
+        }
+        if (!is_diag) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                double* U = sB + (w * 16) * PLD + n * 16;
+                v4d acb = tile_load(U, lane);
+                acb = mfma_nt16<true>(acb, sPo + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+                tile_store(U, acb, lane);
+            }
+        }
+    }
+    if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (stamp) ts[2] = __builtin_amdgcn_s_memtime();
+    // ---- Cholesky of the 64x64 diagonal block, blocked by 16, as a dataflow between the four waves
+    // (wave w owns block row w) instead of three workgroup barriers per block column:
+    //   for cb < w:  wait chol(cb);  T(w,cb): D[w][cb] <- D[w][cb] L[cb][cb]^-T;  publish;
+    //                for cc in cb+1..w: (cc < w: wait T(cc,cb))  D[w][cc] -= D[w][cb] D[cc][cb]^T
+    //   chol(w); publish;  then (w < 3, off-diagonal workgroups) the own-row solve of column block w.
+    // Wave cb+1 starts chol(cb+1) as soon as ITS row is done, while the rows below still work on block
+    // column cb: the chain is 4 chol16 + 3 (solve + one tile update) = ~35k cycles instead of 44k.
+    // Same operations on every tile in the same order as the barrier version: bit-identical factors.
+    // Flags are LDS words written by lane 0 after a wave fence (LDS requests of a wave retire in order).
+    if (w == 0 && lane < 8) s_flag[lane] = 0;      // [0]: blocks factored, [1 + w]: columns solved by wave w, [5]: own-row blocks solved
+    __syncthreads();
+    {
+        for (int cb = 0; cb < w; cb++) {
+            while (__hip_atomic_load(&s_flag[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(1);
+            trsm16_rows(sD + (w * 16) * PLD + cb * 16, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
+            wave_fence();
+            if (lane == 0) __hip_atomic_store(&s_flag[1 + w], cb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int cc = cb + 1; cc <= w; cc++) {
+                if (cc < w)
+                    while (__hip_atomic_load(&s_flag[1 + cc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(1);
+                double* T = sD + (w * 16) * PLD + cc * 16;
+                v4d acc = tile_load(T, lane);
+                acc = mfma_nt16<true>(acc, sD + (w * 16) * PLD + cb * 16, sD + (cc * 16) * PLD + cb * 16, 16, lane);
+                tile_store(T, acc, lane);
+            }
+            wave_fence();
+        }
+        // a failed pivot (not positive definite) still publishes: nobody may wait forever; the first
+        // failing column wins (the chol16 calls are ordered by the chain itself)
+        const int bad = chol16_wave(sD + (w * 16) * PLD + w * 16, sRd + w * 16, lane);
+        if (bad && lane == 0 && s_bad == 0) s_bad = w * 16 + bad;
+        wave_fence();
+        if (lane == 0) __hip_atomic_store(&s_flag[0], w + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!is_diag && w < 3) {
+            // this wave has nothing left to do in the factor: it solves the workgroup's own rows against
+            // its block column (needs the own-row blocks 0..w-1, solved by the waves before it)
+            while (__hip_atomic_load(&s_flag[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < w) __builtin_amdgcn_s_sleep(1);
+            solve_block_cols(sB, sD, sRd, w, lane);
+            if (lane == 0) __hip_atomic_store(&s_flag[5], w + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (is_diag && t == 0) {
+            int64_t col = j0 + s_bad;                       // 1-based failing column
+            atomicCAS(info, 0, (int)(col <= n_real ? col : n_real));
+        }
+        return;
+    }
+    if (stamp) ts[3] = __builtin_amdgcn_s_memtime();
+    if (is_diag) {
+        if (t == 0)
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+                __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        if (stamp) ts[4] = __builtin_amdgcn_s_memtime();
+        store_block(A + j0 * ld + j0, ld, sD, t, true);
+        if (stamp) {
+            ts[5] = __builtin_amdgcn_s_memtime();
+            for (int i = 0; i < 5; i++) atomicAdd(&dbg[i], ts[i + 1] - ts[i]);
+            atomicAdd(&dbg[5], 1ull);
+        }
+        return;
+    }
+    // ---- X = B Lkk^-T: the column blocks 0..2 were solved inside the factor loop (by the waves
+    // idling there); the last one is done here, wave w on its own 16-row strip
+    {
+        const int cb = 3;
+        double* T = sB + (w * 16) * PLD + cb * 16;
+        v4d acc = tile_load(T, lane);
+        acc = mfma_nt16<true>(acc, sB + (w * 16) * PLD, sD + (cb * 16) * PLD, cb * 16, lane);
+        tile_store(T, acc, lane);
+        wave_fence();
+        trsm16_rows(T, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
+        wave_fence();
+    }
+    __syncthreads();
+    if (stamp) ts[4] = __builtin_amdgcn_s_memtime();
+    store_block(A + R * ld + j0, ld, sB, t, false);
+    if (stamp) {
+        ts[5] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 5; i++) atomicAdd(&dbg[i], ts[i + 1] - ts[i]);
+        atomicAdd(&dbg[5], 1ull);
+    }
+}
+
 // A = L L^T in place (lower; the strict upper triangle is left untouched).  Outer blocks of
 // 128 columns: two fused panel steps, then one MFMA SYRK (K = 128) on the trailing matrix.
 // Trailing update C -= P P^T (lower tiles only) of the rows/cols [r0, Np) x [c0, c0 + nc) with the
@@ -518,6 +755,220 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
         }
     }
     if (rest_pending) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_rest_prev, 0));
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One 64 x 64 tile of a trailing update, C -= A_r P^T with the 128 columns of one panel: both operand
+// images (64 rows x 128 k, row stride 130 doubles: conflict-free fragment reads) sit in LDS at once, each
+// wave owns a 32 x 32 quadrant (2 x 2 MFMA tiles, 32 k-steps).  Per element the same MFMA sequence from a
+// zero accumulator and the same single rounding of C - acc as the 128 x 128 SYRK tile of the separate
+// trailing launches: bit-identical.  Small on purpose: ~10 us, shorter than a panel step, so that tiles
+// riding in a panel launch never set its length (a lone 128 x 128 x 128 tile takes 32-36 us).
+#define S64 130
+struct TileItem { int64_t a_off, b_off, c_off; };
+__device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
+                                                 const int* info) {
+    if (*info != 0) return;
+    double* sA = smem;
+    double* sB = smem + 64 * S64;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const bool diag = it.a_off == it.b_off;
+    const double* Ag = A + it.a_off;
+    const double* Bg = A + it.b_off;
+    // LDS-DMA: one wave instruction moves one 1-KiB row (128 k) of an operand straight into its padded LDS
+    // row -- no staging registers, all 16 (+16) rows of a wave in flight at once
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int row = w * 16 + i;
+        gd_dma16(Ag + (int64_t)row * ld + 2 * lane, sA + row * S64);
+    }
+    if (!diag) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int row = w * 16 + i;
+            gd_dma16(Bg + (int64_t)row * ld + 2 * lane, sB + row * S64);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (diag) sB = sA;
+    __syncthreads();
+    const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
+    v4d acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) acc[mi][ni] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* pa = sA + (wr * 32 + r) * S64 + g;
+    const double* pb = sB + (wc * 32 + r) * S64 + g;
+#pragma unroll 4
+    for (int k0 = 0; k0 < 128; k0 += 4) {
+        const double a0 = pa[k0], a1 = pa[16 * S64 + k0], b0 = pb[k0], b1 = pb[16 * S64 + k0];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    // C/D fragment: row = g + 4q, col = r.  All 16 old values first, then the stores.
+    double* cbase = A + it.c_off + (int64_t)(wr * 32 + g) * ld + wc * 32 + r;
+    double old[2][2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) old[mi][ni][q] = cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16] = old[mi][ni][q] - acc[mi][ni][q];
+}
+
+// Fused step: the first P workgroups are the panel step, the others each take one 64 x 64 tile of an
+// EARLIER panel's trailing update.  The panel chain is one workgroup's latency and leaves most of the GPU
+// idle; the tiles fill it.  In-order launches on one stream: no cross-stream events, and a panel workgroup
+// (135 KB of LDS) never waits behind tile workgroups for a CU because it comes first in the dispatch order.
+__global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const TileItem* __restrict__ items, int P) {
+    __shared__ __attribute__((aligned(16))) double smem[PANEL_SMEM_DOUBLES];
+    const int bx = (int)blockIdx.x;
+    if (bx < P) {
+        if (pa.Kfar < pa.K0) panel_step_body<true>(pa, smem, bx);
+        else panel_step_body<false>(pa, smem, bx);
+    } else {
+        syrk64_tile_body(pa.A, pa.ld, items[bx - P], smem, pa.info);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused schedule (default up to Np = 5120).  Outer blocks of 128 columns (two panel steps).  Panel p's
+// trailing update is cut into 64 x 64 tiles (r, c) in units of 64 rows / columns.  Column c of block
+// bc = c / 2 needs the panels p = 0 .. bc-1 in order, each after panel p is complete:
+//   * p = bc-1 on the FIRST 64 columns of a block (c even) is applied by the panel step itself
+//     (panel_step_body<true>): the only part that sits on the panel chain;
+//   * p = bc-1 on the SECOND 64 columns (c odd) rides in the block's first launch, beside the panel step
+//     that works on the first 64 columns;
+//   * everything older (p <= bc-2) rides in any launch after panel p and before block bc, most urgent
+//     first (slack = launches left - updates left), up to two rounds of the CUs the panel step leaves free.
+// The plan depends on Np only and is cached on the device.  Every element receives the same updates in
+// the same order with the same arithmetic as in potrf_lower_fused with chol_outer = 128: bit-identical
+// factors (tools/ab_chol_overlap.py, tests).  Above Np = 5120 the tiles no longer fit under the panel chain
+// (the 64 x 64 tile is a latency device, not a throughput one): potrf_lower_fused takes over.
+struct OverlapPlan {
+    int64_t Np = 0;
+    TileItem* d_items = nullptr;
+    std::vector<int> first, count;      // per launch: slice of d_items
+};
+void overlap_plan_free(gpry_ctx* ctx) {
+    OverlapPlan* pl = static_cast<OverlapPlan*>(ctx->chol_plan);
+    if (!pl) return;
+    if (pl->d_items) (void)hipFree(pl->d_items);
+    delete pl;
+    ctx->chol_plan = nullptr;
+}
+// returns 1 if no valid plan exists (the caller takes the schedule with separate trailing launches)
+static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
+    if (!ctx->chol_plan) ctx->chol_plan = new OverlapPlan();
+    OverlapPlan& pl = *static_cast<OverlapPlan*>(ctx->chol_plan);
+    if (pl.Np == Np) { *out = &pl; return 0; }
+    if (pl.d_items) { (void)hipFree(pl.d_items); pl.d_items = nullptr; }
+    pl = OverlapPlan();
+    const int nb = (int)(Np / 128), n64 = (int)(Np / 64), nl = 2 * nb;
+    int ncu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+    std::vector<int> done((size_t)n64 * n64, 0), last((size_t)n64 * n64, -1);
+    std::vector<TileItem> items;
+    struct Cand { int slack, c, r, p; };
+    std::vector<Cand> cand;
+    auto item = [&](int r, int c, int p) {
+        TileItem it;
+        it.a_off = (int64_t)r * 64 * Np + (int64_t)p * 128;      // 64 rows of tile row r, the 128 columns of panel p
+        it.b_off = (int64_t)c * 64 * Np + (int64_t)p * 128;
+        it.c_off = (int64_t)r * 64 * Np + (int64_t)c * 64;
+        return it;
+    };
+    for (int l = 0; l < nl; l++) {
+        const int b = l / 2;
+        const int P = (int)((Np - ((int64_t)b * 128 + 64 * (l & 1))) / 64);
+        // a step with the far update (first of a block) lasts ~30 us, the other ~21: room for three / two rounds
+        // of ~9-us tiles on the CUs the panel leaves free
+        const int rounds = (l & 1) ? (ctx->opt_chol_caps & 15) : ((ctx->opt_chol_caps >> 4) & 15);
+        const int cap = rounds * (ncu > P ? ncu - P : 0);
+        cand.clear();
+        // columns not yet factored: c >= 2b (+1 in the block's second launch: its first 64 columns are done)
+        for (int c = 2 * b + (l & 1) > 2 ? 2 * b + (l & 1) : 2; c < n64; c++) {
+            const int bc = c / 2;
+            const int need = (c & 1) ? bc : bc - 1;              // updates that ride (the panel does p = bc-1 for even c)
+            for (int r = c; r < n64; r++) {
+                const int p = done[(size_t)r * n64 + c];
+                if (p >= need || p > b - 1 || last[(size_t)r * n64 + c] >= l) continue;
+                int slack;
+                if ((c & 1) && p == bc - 1) slack = (2 * bc) - l;                           // must run in launch 2 bc
+                else slack = (2 * bc - l) - ((bc - 1) - p);                                  // older updates: before block bc
+                cand.push_back({slack, c, r, p});
+            }
+        }
+        std::sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) {
+            if (x.slack != y.slack) return x.slack < y.slack;
+            if (x.c != y.c) return x.c < y.c;
+            return x.r < y.r;
+        });
+        pl.first.push_back((int)items.size());
+        int n_taken = 0;
+        for (const Cand& q : cand) {
+            if (n_taken >= cap && q.slack > 1) continue;          // not urgent and the launch is full
+            items.push_back(item(q.r, q.c, q.p));
+            done[(size_t)q.r * n64 + q.c] = q.p + 1; last[(size_t)q.r * n64 + q.c] = l;
+            n_taken++;
+        }
+        pl.count.push_back(n_taken);
+        // what the NEXT launch's panel step reads must be complete now
+        const int cnext = (l & 1) ? 2 * (b + 1) : 2 * b + 1;     // the 64-column strip factored next
+        if (cnext >= 2 && cnext < n64) {
+            const int bc = cnext / 2, need = (cnext & 1) ? bc : bc - 1;
+            for (int r = cnext; r < n64; r++)
+                if (done[(size_t)r * n64 + cnext] != need) { pl = OverlapPlan(); return 1; }
+        }
+    }
+    if (!items.empty()) {
+        hipError_t e = hipMalloc((void**)&pl.d_items, items.size() * sizeof(TileItem));
+        if (e == hipSuccess) e = hipMemcpy(pl.d_items, items.data(), items.size() * sizeof(TileItem), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (pl.d_items) (void)hipFree(pl.d_items);
+            pl = OverlapPlan();
+            return gpry_fail(ctx, -2, "Cholesky overlap plan (Np = %lld): %s", (long long)Np, hipGetErrorString(e));
+        }
+    }
+    pl.Np = Np;
+    *out = &pl;
+    return 0;
+}
+
+int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
+    if (Np > (ctx->opt_chol_overlap_max > 0 ? ctx->opt_chol_overlap_max : 5120)) return potrf_lower_fused(ctx, A, Np);
+    OverlapPlan* pl = nullptr;
+    const int prc = overlap_plan_get(ctx, Np, &pl);
+    if (prc == 1) return potrf_lower_fused(ctx, A, Np);
+    if (prc) return prc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
+    int arrivals = 0;
+    unsigned long long* dbg = nullptr;
+    if (ctx->opt_chol_dbg) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); dbg = ctx->dsel + 16; }
+    int l = 0;
+    for (int64_t K0 = 0; K0 < Np; K0 += 128) {
+        for (int s = 0; s < 2; s++, l++) {
+            const int64_t j0 = K0 + 64 * s;
+            const int P = (int)((Np - j0) / 64);
+            arrivals += P;
+            PanelArgs pa = {A, Np, j0, K0, (K0 > 0 && s == 0) ? K0 - 128 : K0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals,
+                            dbg, ctx->opt_chol_dbg - 1};
+            hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + pl->count[l])), dim3(256), 0, st, pa,
+                               pl->d_items + pl->first[l], P);
+        }
+    }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -47,6 +47,9 @@ struct gpry_ctx {
     int64_t opt_predict_small = 2048;  // mean-only gpry_predict of at most this many points: one fused launch
     int opt_chol_outer = 0;      // outer block of the fused Cholesky (0: automatic, else 128 / 256 / ...)
     int opt_chol_dbg = 0;        // k > 0: section stamps of workgroup k-1 of every panel step (read_diag)
+    int opt_chol_overlap = 1;    // 1: trailing-update tiles ride in the panel launches (potrf_lower_overlap)
+    int64_t opt_chol_overlap_max = 0;   // largest Np for that schedule (0: 5120)
+    int opt_chol_caps = 0x32;           // tile rounds per launch: high nibble = first step of a block, low = second
     int opt_chol_lookahead = 0;  // 1: trailing update of the next panel's columns first, the rest on stream2
                                  // (bit-identical; 4.50 vs 4.14 ms at N=4096: cross-stream events cost more than the overlap saves)
 
@@ -127,7 +130,8 @@ struct gpry_ctx {
     int64_t bord_cap = 0;
     int64_t n_border = 0;      // rows appended by border updates since the last full factorisation (diagnostic)
 
-    void* trtri_plan = nullptr;   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
+    void* trtri_plan = nullptr;
+    void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
 
     // host pinned staging
     void* hpin = nullptr; void* hpin_dev = nullptr; int64_t hpin_cap = 0;   // host / device view of the same buffer
@@ -238,7 +242,8 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
 
 // ---- chol.hip ----------------------------------------------------------------------
 int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np);             // info -> ctx->dinfo (unfused v1)
-int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // fused panel steps (default)
+int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // fused panel steps, trailing update as its own launches
+int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);     // panel step + previous trailing tiles in ONE launch (default)
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
 int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np);
 int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha,

@@ -5,6 +5,7 @@
 // per thread: concurrent optimiser restarts drive distinct contexts from distinct host threads
 thread_local char g_last_error[1024] = {0};
 void trtri_plan_free(gpry_ctx* ctx);
+void overlap_plan_free(gpry_ctx* ctx);
 
 int gpry_fail(gpry_ctx* ctx, int code, const char* fmt, ...) {
     va_list ap;
@@ -169,6 +170,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     timers_collect(ctx);
     trtri_plan_free(ctx);
+    overlap_plan_free(ctx);
     void* bufs[] = {ctx->dX, ctx->dXs, ctx->dy, ctx->dnoise, ctx->dA, ctx->dV, ctx->dW, ctx->dW2, ctx->dW3,
                     ctx->dalpha_, ctx->dvec, ctx->dinfo, ctx->dparams, ctx->dXc, ctx->dmask, ctx->dy_all,
                     ctx->dsig_all, ctx->dacq_all, ctx->dKst, ctx->dpart, ctx->dkeys, ctx->dhist,
@@ -205,6 +207,9 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "sweep_dma")) { ctx->opt_sweep_dma = (int)value; return 0; }
     if (!strcmp(key, "sweep_persist")) { ctx->opt_sweep_persist = (int)value; return 0; }
     if (!strcmp(key, "sweep_overlap")) { ctx->opt_sweep_overlap = (int)value; return 0; }
+    if (!strcmp(key, "chol_overlap")) { ctx->opt_chol_overlap = (int)value; return 0; }
+    if (!strcmp(key, "chol_overlap_max")) { ctx->opt_chol_overlap_max = value; return 0; }
+    if (!strcmp(key, "chol_caps")) { ctx->opt_chol_caps = (int)value; overlap_plan_free(ctx); return 0; }
     if (!strcmp(key, "chol_lookahead")) { ctx->opt_chol_lookahead = (int)value; return 0; }
     if (!strcmp(key, "chol_dbg")) { ctx->opt_chol_dbg = (int)value; return 0; }
     if (!strcmp(key, "chol_outer")) {

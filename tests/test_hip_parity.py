@@ -742,3 +742,53 @@ def test_bordered_append_reports_a_non_positive_definite_border(dev):
     assert info == 51                                  # 1-based column of the failing pivot
     with pytest.raises(Exception):
         dev.predict(X[:3], return_std=True)           # no valid factor any more: the caller must refactorise
+
+
+@pytest.mark.parametrize("N", [100, 200, 300, 1100, 2100, 3100, 4096, 5000])
+def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, N):
+    """Default schedule up to Np = 5120: the trailing update is cut into 64 x 64 tiles that ride as extra
+    workgroups in the panel launches (deadline-driven plan), the panel steps apply the previous panel to their
+    own columns themselves.  Same updates, same order, same arithmetic as the schedule with separate trailing
+    launches (outer block 128): the factor must be bit-identical; a non-positive-definite matrix must report
+    the same leading minor."""
+    d = 4
+    rng = np.random.default_rng(N)
+    X = rng.uniform(0, 1, (N, d))
+    y = rng.standard_normal(N)
+    dev.set_affine()
+    dev.set_train(X, y, np.full(N, 1e-5))
+    theta = np.log(np.array([3.0, 0.4, 0.5, 0.6, 0.7]))
+    dev.set_theta(3, theta)
+    try:
+        dev.set_option("chol_overlap", 0)
+        dev.set_option("chol_outer", 128)
+        assert dev.factorize() == 0
+        L0, V0, a0 = dev.get_factor()
+        lml0 = dev.lml(theta, True)
+        dev.set_option("chol_outer", 0)
+        dev.set_option("chol_overlap", 1)
+        for _ in range(2):
+            assert dev.factorize() == 0
+            L1, V1, a1 = dev.get_factor()
+            assert np.array_equal(L0, L1) and np.array_equal(V0, V1) and np.array_equal(a0, a1)
+        lml1 = dev.lml(theta, True)
+        assert lml0[0] == lml1[0] and np.array_equal(lml0[1], lml1[1])
+        K = dev.kernel_train(add_alpha=True)
+        assert relmax(L1 @ L1.T, K) < 1e-13
+        # not positive definite: a duplicated row with zero noise far down the matrix
+        if N >= 300:
+            Xb = X.copy()
+            Xb[N - 7] = Xb[N // 3]
+            alpha = np.full(N, 1e-5)
+            alpha[N - 7] = alpha[N // 3] = -1e-3
+            infos = []
+            for ov, outer in ((0, 128), (1, 0)):
+                dev.set_option("chol_overlap", ov)
+                dev.set_option("chol_outer", outer)
+                dev.set_train(Xb, y, alpha)
+                dev.set_theta(3, theta)
+                infos.append(dev.factorize())
+            assert infos[0] == infos[1] and infos[0] > 0
+    finally:
+        dev.set_option("chol_outer", 0)
+        dev.set_option("chol_overlap", 1)

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Tile rounds per fused Cholesky launch (option chol_caps = 16 * first-step rounds + second-step rounds)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpry_amd import _lib
+dev = _lib.Device(0)
+for N, d in ((2048, 8), (4096, 16)):
+    rng = np.random.default_rng(N)
+    X = rng.uniform(0, 1, (N, d)); y = rng.standard_normal(N)
+    dev.set_train(X, y, np.full(N, 1e-4)); dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
+    for caps in (0x11, 0x21, 0x22, 0x32, 0x33, 0x42, 0x43, 0x53):
+        dev.set_option("chol_caps", caps)
+        assert dev.factorize() == 0
+        dev.timing_reset()
+        for _ in range(6):
+            assert dev.factorize() == 0
+        print(f"N={N} caps {caps >> 4},{caps & 15}: potrf {dev.timing('potrf')[0] / 6 * 1e3:7.1f} us", flush=True)
+        dev.set_option("timing", 0)

@@ -14,6 +14,9 @@ dev.set_train(X, rng.standard_normal(N), np.full(N, 1e-4))
 dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
 assert dev.factorize() == 0
 names = ["loads", "left-looking update", "64x64 factor", "row solve / wait", "store"]
+overlap = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+dev.set_option("chol_overlap", overlap)
+print(f"chol_overlap = {overlap} (s_memtime ticks are 100 MHz: x24 for core cycles at 2.4 GHz)")
 for blk, label in ((1, "diagonal workgroup"), (2, "first off-diagonal workgroup"), (9, "workgroup 8")):
     dev.set_option("chol_dbg", blk)
     dev.read_diag(True)
