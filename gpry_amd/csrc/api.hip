@@ -10,6 +10,18 @@ static int require_model(gpry_ctx* ctx, bool need_factor) {
     return 0;
 }
 
+// temporary device buffer of an entry point: freed on EVERY return path (the error paths of the entry points
+// below used to leak their scratch allocations)
+template <typename T>
+struct TmpBuf {
+    T* p = nullptr;
+    TmpBuf() = default;
+    TmpBuf(const TmpBuf&) = delete;
+    TmpBuf& operator=(const TmpBuf&) = delete;
+    ~TmpBuf() { if (p) (void)hipFree(p); }
+    int alloc(gpry_ctx* ctx, int64_t count) { return dev_alloc(ctx, &p, count); }
+};
+
 static int ensure_part(gpry_ctx* ctx, int64_t need) {
     if (need <= ctx->part_cap) return 0;
     if (ctx->dpart) GPRY_TRY(dev_free(ctx, ctx->dpart));
@@ -87,9 +99,10 @@ int gpry_kernel_cross(gpry_ctx* ctx, const double* Xc_, int64_t M, double* K_out
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return 0;
     int64_t mp = round_up(M, 256);
-    double *dX = nullptr, *dK = nullptr;
-    GPRY_TRY(dev_alloc(ctx, &dX, M * ctx->d));
-    GPRY_TRY(dev_alloc(ctx, &dK, ctx->Np * mp));
+    TmpBuf<double> bX, bK;
+    GPRY_TRY(bX.alloc(ctx, M * ctx->d));
+    GPRY_TRY(bK.alloc(ctx, ctx->Np * mp));
+    double *dX = bX.p, *dK = bK.p;
     HIP_TRY(ctx, hipMemcpyAsync(dX, Xc_, sizeof(double) * M * ctx->d, hipMemcpyHostToDevice, ctx->stream));
     GPRY_TRY(launch_scale_train(ctx));
     int64_t saveM = ctx->sw_M; ctx->sw_M = M;
@@ -101,7 +114,6 @@ int gpry_kernel_cross(gpry_ctx* ctx, const double* Xc_, int64_t M, double* K_out
     GPRY_TRY(copy_out_matrix(ctx, dK, mp, ctx->N, M, tmp.data()));
     for (int64_t j = 0; j < ctx->N; j++)
         for (int64_t m = 0; m < M; m++) K_out[m * ctx->N + j] = tmp[(size_t)j * M + m];
-    GPRY_TRY(dev_free(ctx, dX)); GPRY_TRY(dev_free(ctx, dK));
     return 0;
 }
 
@@ -140,13 +152,13 @@ int gpry_get_factor(gpry_ctx* ctx, double* L, double* V, double* alpha_) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int64_t N = ctx->N;
     if (L) {
-        double* tmp = nullptr;
-        GPRY_TRY(dev_alloc(ctx, &tmp, N * N));
+        TmpBuf<double> bt;
+        GPRY_TRY(bt.alloc(ctx, N * N));
+        double* tmp = bt.p;
         hipLaunchKernelGGL(zero_upper_copy_kernel, dim3((unsigned)((N * N + 255) / 256)), dim3(256), 0,
                            ctx->stream, ctx->dA, tmp, ctx->Np, N);
         HIP_TRY(ctx, hipMemcpyAsync(L, tmp, sizeof(double) * N * N, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        GPRY_TRY(dev_free(ctx, tmp));
     }
     if (V) GPRY_TRY(copy_out_matrix(ctx, ctx->dV, ctx->Np, N, N, V));
     if (alpha_) {
@@ -905,9 +917,11 @@ extern "C" int gpry_sweep_topk(gpry_ctx* ctx, int64_t Kp, const int64_t* exclude
     }
     unsigned nb = (unsigned)((M + 255) / 256);
     hipLaunchKernelGGL(make_keys_kernel, dim3(nb), dim3(256), 0, st, ctx->dacq_all, M, ctx->dkeys);
+    TmpBuf<int64_t> bex;
     int64_t* dex = nullptr;
     if (n_exclude > 0) {
-        GPRY_TRY(dev_alloc(ctx, &dex, n_exclude));
+        GPRY_TRY(bex.alloc(ctx, n_exclude));
+        dex = bex.p;
         HIP_TRY(ctx, hipMemcpyAsync(dex, exclude, sizeof(int64_t) * n_exclude, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(exclude_keys_kernel, dim3((unsigned)((n_exclude + 255) / 256)), dim3(256), 0, st,
                            ctx->dkeys, dex, n_exclude, M);
@@ -915,7 +929,6 @@ extern "C" int gpry_sweep_topk(gpry_ctx* ctx, int64_t Kp, const int64_t* exclude
     *n_out = 0; *bound = -INFINITY;
     if (K <= 0) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (dex) GPRY_TRY(dev_free(ctx, dex));
         return 0;
     }
     SelState s0; memset(&s0, 0, sizeof(s0)); s0.k_rem = (unsigned long long)K;
@@ -935,7 +948,6 @@ extern "C" int gpry_sweep_topk(gpry_ctx* ctx, int64_t Kp, const int64_t* exclude
     unsigned long long cnt[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(cnt, dcnt, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (dex) GPRY_TRY(dev_free(ctx, dex));
     if ((int64_t)cnt[0] != K)
         return gpry_fail(ctx, -4, "topk: selected %llu candidates, expected %lld", cnt[0], (long long)K);
     HIP_TRY(ctx, hipMemcpy(top, ctx->dcand, sizeof(gpry_cand) * K, hipMemcpyDeviceToHost));
@@ -1043,9 +1055,10 @@ int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, 
     }
     const int64_t mp = round_up(m, 128);
     // stage the candidates, build their cross-kernel panel, then U^T = K*  V^T
-    double *dX = nullptr, *dpar = nullptr;
-    GPRY_TRY(dev_alloc(ctx, &dX, m * ctx->d));
-    GPRY_TRY(dev_alloc(ctx, &dpar, 3 * GPRY_MAX_DIM));
+    TmpBuf<double> bX, bpar;
+    GPRY_TRY(bX.alloc(ctx, m * ctx->d));
+    GPRY_TRY(bpar.alloc(ctx, 3 * GPRY_MAX_DIM));
+    double *dX = bX.p, *dpar = bpar.p;
     HIP_TRY(ctx, hipMemcpyAsync(dX, X, sizeof(double) * m * ctx->d, hipMemcpyHostToDevice, st));
     double hpar[3 * GPRY_MAX_DIM];
     for (int k = 0; k < GPRY_MAX_DIM; k++) {
@@ -1080,7 +1093,6 @@ int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, 
         HIP_TRY(ctx, hipMemcpyAsync(var0, ctx->dkbout, sizeof(double) * m, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    GPRY_TRY(dev_free(ctx, dX)); GPRY_TRY(dev_free(ctx, dpar));
     if (first) *first = ctx->kb_n;
     ctx->kb_n += m;
     return 0;
@@ -1114,10 +1126,11 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M % 64 || N % 64 || K % 64) return gpry_fail(ctx, -1, "debug_gemm: dims must be multiples of 64");
     int64_t crow = (epi == EPI_SUMSQ) ? (M + 127) / 128 : M;
-    double *dA = nullptr, *dB = nullptr, *dC = nullptr;
-    GPRY_TRY(dev_alloc(ctx, &dA, (int64_t)M * K));
-    GPRY_TRY(dev_alloc(ctx, &dB, (int64_t)K * N));
-    GPRY_TRY(dev_alloc(ctx, &dC, crow * N));
+    TmpBuf<double> bA, bB, bC;
+    GPRY_TRY(bA.alloc(ctx, (int64_t)M * K));
+    GPRY_TRY(bB.alloc(ctx, (int64_t)K * N));
+    GPRY_TRY(bC.alloc(ctx, crow * N));
+    double *dA = bA.p, *dB = bB.p, *dC = bC.p;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(dA, A, sizeof(double) * M * K, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dB, B, sizeof(double) * K * N, hipMemcpyHostToDevice, st));
@@ -1138,7 +1151,6 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
     }
     HIP_TRY(ctx, hipMemcpyAsync(C, dC, sizeof(double) * crow * N, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    GPRY_TRY(dev_free(ctx, dA)); GPRY_TRY(dev_free(ctx, dB)); GPRY_TRY(dev_free(ctx, dC));
     return 0;
 }
 
@@ -1149,8 +1161,9 @@ extern "C" int gpry_debug_logexp(gpry_ctx* ctx, const double* mu, const double* 
     if (n <= 0) return 0;
     if (!mu || !sigma || !acq) return gpry_fail(ctx, -1, "debug_logexp: mu, sigma and acq must not be NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    double* d = nullptr;
-    GPRY_TRY(dev_alloc(ctx, &d, 3 * n));
+    TmpBuf<double> bd;
+    GPRY_TRY(bd.alloc(ctx, 3 * n));
+    double* d = bd.p;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(d, mu, sizeof(double) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d + n, sigma, sizeof(double) * n, hipMemcpyHostToDevice, st));
@@ -1159,7 +1172,6 @@ extern "C" int gpry_debug_logexp(gpry_ctx* ctx, const double* mu, const double* 
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(acq, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    GPRY_TRY(dev_free(ctx, d));
     return 0;
 }
 

@@ -46,6 +46,9 @@ def default_device_index():
         if os.environ.get(var, "") != "":
             n, idx = _lib.device_count(), int(os.environ[var])
             if n > 0 and idx >= n:
+                if n == 1 and any(os.environ.get(v, "") != "" for v in
+                                  ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+                    return 0        # the launcher already gave this process a GPU of its own
                 if os.environ.get("GPRY_HIP_DEVICE_WRAP", "") == "1":
                     return idx % n
                 raise _lib.GpryHipError(
