@@ -16,7 +16,8 @@ def run(n_cases=60, seed=0, dev=None):
     """Returns (number of violations, worst deviations)."""
     rng = np.random.default_rng(seed)
     dev = dev or _lib.Device(0)
-    worst = {"mean": 0.0, "var": 0.0, "lml": 0.0, "grad": 0.0, "acq": 0.0, "kgrad": 0.0}
+    worst = {"mean": 0.0, "var": 0.0, "lml": 0.0, "grad": 0.0, "acq": 0.0, "kgrad": 0.0, "border_L": 0.0, "border_mean": 0.0,
+             "batch_grad": 0.0}
     bad = 0
     for case in range(n_cases):
         bad += _one_case(case, rng, dev, worst)
@@ -26,7 +27,8 @@ def run(n_cases=60, seed=0, dev=None):
 def _one_case(case, rng, dev, worst):
     bad = 0
     if True:
-        N = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 383, 500, 640, 777, 1024, 1300, 2048]))
+        N = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 383, 500, 640, 777, 1024, 1300, 2048, 2048,
+                            3000, 4096]))
         d = int(rng.integers(1, 33))
         M = int(rng.choice([1, 2, 15, 16, 17, 100, 128, 129, 1000, 3000]))
         kid = int(rng.integers(0, 4))
@@ -111,12 +113,45 @@ def _one_case(case, rng, dev, worst):
         worst["kgrad"] = max(worst["kgrad"], e)
         if e > 1e-10:
             print(f"case {case}: kernel x-gradient err {e:.2e} (N={N} d={d} kid={kid})"); bad += 1
+        # batched x-gradients against the one-point entry (round 2)
+        mb = min(M, int(rng.choice([1, 2, 5, 130])))
+        bm, bs, bmg, bkg = dev.predict_grad_batch(Xc[:mb], True)
+        for i in sorted(set((0, mb - 1))):
+            mg1, kg1 = dev.predict_grad(Xc[i], want_kinv=True)
+            e = max(np.max(np.abs(bmg[i] - mg1)) / max(1e-300, np.max(np.abs(mg1)), 1e-12),
+                    np.max(np.abs(bkg[i] - kg1)) / max(1e-300, np.max(np.abs(kg1)), 1e-9))
+            worst["batch_grad"] = max(worst["batch_grad"], e)
+            Ldg = np.diag(m.L_)
+            if e > max(1e-6, 1e-13 * (Ldg.max() / Ldg.min()) ** 2):      # K^-1 k* in two summation orders: cond(K) eps
+                print(f"case {case}: batched x-gradient differs from the one-point entry by {e:.2e} (N={N} d={d} kid={kid} mb={mb})"); bad += 1
         K = min(M, 40)
         top, bound = dev.sweep_topk(K)
         order = np.lexsort((-np.arange(M), -out["acq"]))
         valid = ~np.isnan(out["acq"][order])
         if not np.array_equal(top["idx"], order[valid][:K][:len(top)]):
             print(f"case {case}: top-k order differs"); bad += 1
+        # bordered append (round 2): the last k rows appended to the factor of the first N - k against the
+        # factor of all N rows that is on the device now
+        if N >= 8 and rng.random() < 0.7:
+            k = int(rng.choice([1, 2, 7, 64, 70]))
+            k = min(k, N - 2)
+            L1 = dev.get_factor(want_V=False, want_alpha=False)[0]
+            m1 = dev.predict(Xc[:min(M, 50)])
+            dev.set_train(m.X_train_[:N - k], m.y_train_[:N - k], m.alpha[:N - k])
+            dev.set_theta(kid, m.theta)
+            if dev.factorize() == 0 and dev.append_rows(m.X_train_[N - k:], m.y_train_[N - k:], m.alpha[N - k:]) == 0:
+                L2 = dev.get_factor(want_V=False, want_alpha=False)[0]
+                m2 = dev.predict(Xc[:min(M, 50)])
+                Ld = np.diag(L1)
+                cond = (Ld.max() / Ld.min()) ** 2
+                e = np.max(np.abs(L2 - L1)) / np.max(np.abs(L1))
+                em = np.max(np.abs(m2 - m1)) / scale
+                worst["border_L"] = max(worst["border_L"], e)
+                worst["border_mean"] = max(worst["border_mean"], em)
+                if e > max(1e-10, 1e-15 * cond) or em > max(1e-7, 1e-14 * cond):
+                    print(f"case {case}: bordered append differs: L {e:.2e} mean {em:.2e} (N={N} k={k} d={d} kid={kid})"); bad += 1
+            else:
+                print(f"case {case}: bordered append failed (N={N} k={k} kid={kid})"); bad += 1
     return bad
 
 
