@@ -767,7 +767,7 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
 // trailing launches: bit-identical.  Small on purpose: ~10 us, shorter than a panel step, so that tiles
 // riding in a panel launch never set its length (a lone 128 x 128 x 128 tile takes 32-36 us).
 #define S64 130
-struct TileItem { int64_t a_off, b_off, c_off; };
+struct TileItem { int64_t a_off, b_off, c_off; int64_t n; };   // n consecutive panels (128 columns apart) in one visit
 __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
                                                  const int* info) {
     if (*info != 0) return;
@@ -775,56 +775,68 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
     double* sB = smem + 64 * S64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const bool diag = it.a_off == it.b_off;
-    const double* Ag = A + it.a_off;
-    const double* Bg = A + it.b_off;
-    // LDS-DMA: one wave instruction moves one 1-KiB row (128 k) of an operand straight into its padded LDS
-    // row -- no staging registers, all 16 (+16) rows of a wave in flight at once
+    const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
+    // C/D fragment: row = g + 4q, col = r.  The 16 old values of this lane stay in registers over the visit.
+    double* cbase = A + it.c_off + (int64_t)(wr * 32 + g) * ld + wc * 32 + r;
+    double val[2][2][4];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int row = w * 16 + i;
-        gd_dma16(Ag + (int64_t)row * ld + 2 * lane, sA + row * S64);
-    }
-    if (!diag) {
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) val[mi][ni][q] = cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16];
+    if (diag) sB = sA;
+    // A lagging tile takes several pending panels in one visit: each one accumulated from zero and subtracted
+    // with one rounding, in order -- the values a store / reload between them would give.
+#pragma unroll 1
+    for (int u = 0; u < (int)it.n; u++) {
+        const double* Ag = A + it.a_off + (int64_t)u * 128;
+        const double* Bg = A + it.b_off + (int64_t)u * 128;
+        if (u) __syncthreads();                 // everybody has read the previous panel's images
+        // LDS-DMA: one wave instruction moves one 1-KiB row (128 k) of an operand straight into its padded LDS
+        // row -- no staging registers, all 16 (+16) rows of a wave in flight at once
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int row = w * 16 + i;
-            gd_dma16(Bg + (int64_t)row * ld + 2 * lane, sB + row * S64);
+            gd_dma16(Ag + (int64_t)row * ld + 2 * lane, sA + row * S64);
         }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (diag) sB = sA;
-    __syncthreads();
-    const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
-    v4d acc[2][2];
+        if (!diag) {
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++)
+            for (int i = 0; i < 16; i++) {
+                const int row = w * 16 + i;
+                gd_dma16(Bg + (int64_t)row * ld + 2 * lane, sB + row * S64);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        v4d acc[2][2];
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) acc[mi][ni] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double* pa = sA + (wr * 32 + r) * S64 + g;
-    const double* pb = sB + (wc * 32 + r) * S64 + g;
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) acc[mi][ni] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const double* pa = sA + (wr * 32 + r) * S64 + g;
+        const double* pb = sB + (wc * 32 + r) * S64 + g;
 #pragma unroll 4
-    for (int k0 = 0; k0 < 128; k0 += 4) {
-        const double a0 = pa[k0], a1 = pa[16 * S64 + k0], b0 = pb[k0], b1 = pb[16 * S64 + k0];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        for (int k0 = 0; k0 < 128; k0 += 4) {
+            const double a0 = pa[k0], a1 = pa[16 * S64 + k0], b0 = pb[k0], b1 = pb[16 * S64 + k0];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) val[mi][ni][q] = val[mi][ni][q] - acc[mi][ni][q];
     }
-    // C/D fragment: row = g + 4q, col = r.  All 16 old values first, then the stores.
-    double* cbase = A + it.c_off + (int64_t)(wr * 32 + g) * ld + wc * 32 + r;
-    double old[2][2][4];
 #pragma unroll
     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
         for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) old[mi][ni][q] = cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16];
-#pragma unroll
-    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16] = old[mi][ni][q] - acc[mi][ni][q];
+            for (int q = 0; q < 4; q++) cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16] = val[mi][ni][q];
 }
 
 // Fused step: the first P workgroups are the panel step, the others each take one 64 x 64 tile of an
@@ -851,7 +863,9 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
 //   * p = bc-1 on the SECOND 64 columns (c odd) rides in the block's first launch, beside the panel step
 //     that works on the first 64 columns;
 //   * everything older (p <= bc-2) rides in any launch after panel p and before block bc, most urgent
-//     first (slack = launches left - updates left), up to two rounds of the CUs the panel step leaves free.
+//     first (slack = launches left - updates left), two / one rounds of the CUs the panel step leaves free
+//     (chol_caps); a tile far from its deadline waits until two panels are pending and applies both in one
+//     visit (chol_multi), C staying in registers in between.
 // The plan depends on Np only and is cached on the device.  Every element receives the same updates in
 // the same order with the same arithmetic as in potrf_lower_fused with chol_outer = 128: bit-identical
 // factors (tools/ab_chol_overlap.py, tests).  Above Np = 5120 the tiles no longer fit under the panel chain
@@ -880,20 +894,20 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
     std::vector<int> done((size_t)n64 * n64, 0), last((size_t)n64 * n64, -1);
     std::vector<TileItem> items;
-    struct Cand { int slack, c, r, p; };
+    struct Cand { int slack, c, r, p, n; };
     std::vector<Cand> cand;
-    auto item = [&](int r, int c, int p) {
+    auto item = [&](int r, int c, int p, int n) {
         TileItem it;
         it.a_off = (int64_t)r * 64 * Np + (int64_t)p * 128;      // 64 rows of tile row r, the 128 columns of panel p
         it.b_off = (int64_t)c * 64 * Np + (int64_t)p * 128;
         it.c_off = (int64_t)r * 64 * Np + (int64_t)c * 64;
+        it.n = n;
         return it;
     };
+    const int multi = ctx->opt_chol_multi;       // panels per visit of a lagging tile (1: one visit per update)
     for (int l = 0; l < nl; l++) {
         const int b = l / 2;
         const int P = (int)((Np - ((int64_t)b * 128 + 64 * (l & 1))) / 64);
-        // a step with the far update (first of a block) lasts ~30 us, the other ~21: room for three / two rounds
-        // of ~9-us tiles on the CUs the panel leaves free
         const int rounds = (l & 1) ? (ctx->opt_chol_caps & 15) : ((ctx->opt_chol_caps >> 4) & 15);
         const int cap = rounds * (ncu > P ? ncu - P : 0);
         cand.clear();
@@ -904,10 +918,14 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
             for (int r = c; r < n64; r++) {
                 const int p = done[(size_t)r * n64 + c];
                 if (p >= need || p > b - 1 || last[(size_t)r * n64 + c] >= l) continue;
+                const int avail = (need < b ? need : b) - p;     // panels p .. p + avail - 1 are complete and wanted
                 int slack;
                 if ((c & 1) && p == bc - 1) slack = (2 * bc) - l;                           // must run in launch 2 bc
                 else slack = (2 * bc - l) - ((bc - 1) - p);                                  // older updates: before block bc
-                cand.push_back({slack, c, r, p});
+                int n = avail < multi ? avail : multi;
+                // far tiles wait until `multi` panels are pending (fewer, longer visits); near ones cannot
+                if (n < multi && slack > 2 * multi) continue;
+                cand.push_back({slack, c, r, p, n});
             }
         }
         std::sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) {
@@ -919,8 +937,8 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
         int n_taken = 0;
         for (const Cand& q : cand) {
             if (n_taken >= cap && q.slack > 1) continue;          // not urgent and the launch is full
-            items.push_back(item(q.r, q.c, q.p));
-            done[(size_t)q.r * n64 + q.c] = q.p + 1; last[(size_t)q.r * n64 + q.c] = l;
+            items.push_back(item(q.r, q.c, q.p, q.n));
+            done[(size_t)q.r * n64 + q.c] = q.p + q.n; last[(size_t)q.r * n64 + q.c] = l;
             n_taken++;
         }
         pl.count.push_back(n_taken);

@@ -9,11 +9,12 @@ for N, d in ((2048, 8), (4096, 16)):
     rng = np.random.default_rng(N)
     X = rng.uniform(0, 1, (N, d)); y = rng.standard_normal(N)
     dev.set_train(X, y, np.full(N, 1e-4)); dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
-    for caps in (0x11, 0x21, 0x22, 0x32, 0x33, 0x42, 0x43, 0x53):
+    for multi, caps in ((1, 0x32), (2, 0x32), (2, 0x22), (2, 0x21), (3, 0x32), (3, 0x22), (3, 0x21), (4, 0x22)):
+        dev.set_option("chol_multi", multi)
         dev.set_option("chol_caps", caps)
         assert dev.factorize() == 0
         dev.timing_reset()
         for _ in range(6):
             assert dev.factorize() == 0
-        print(f"N={N} caps {caps >> 4},{caps & 15}: potrf {dev.timing('potrf')[0] / 6 * 1e3:7.1f} us", flush=True)
+        print(f"N={N} multi {multi} caps {caps >> 4},{caps & 15}: potrf {dev.timing('potrf')[0] / 6 * 1e3:7.1f} us", flush=True)
         dev.set_option("timing", 0)
