@@ -102,13 +102,16 @@ int gpry_group_create(int n, const int* devices, gpry_ctx* adopt0, gpry_group** 
         }
         g->members.push_back(c);
     }
-    // RCCL between the members only if every member has a device of its own (a communicator cannot
-    // hold one device twice); GPRY_GROUP_TRANSPORT=host keeps the exchange on the host
+    // The shortlists are a few KB that the HOST needs (it ranks them): by default every member copies its
+    // records out and the host merges.  GPRY_GROUP_TRANSPORT=rccl routes them through an in-process RCCL
+    // all-gather between the members' devices instead (only if every member has a device of its own: a
+    // communicator cannot hold one device twice) -- opt-in, because that path cannot be exercised on the
+    // 1-GPU development boxes and an unmodified Runner reaches the group by default.
     bool distinct = n > 1;
     for (int i = 0; i < n && distinct; i++)
         for (int k = 0; k < i; k++) if (devices[i] == devices[k]) { distinct = false; break; }
     const char* env = getenv("GPRY_GROUP_TRANSPORT");
-    if (distinct && !(env && !strcmp(env, "host"))) {
+    if (distinct && env && !strcmp(env, "rccl")) {
         g->comms.assign(n, nullptr);
         ncclResult_t r = ncclCommInitAll(g->comms.data(), n, devices);
         if (r != ncclSuccess) {

@@ -227,9 +227,10 @@ int gpry_comm_barrier(gpry_comm* comm);
  * shortlists merged with the hold-back rule that keeps the descending stream exact
  * (gpry/gp_acquisition.py:1148-1191 merges per-rank pools).  adopt0 (nullable): an existing context
  * on devices[0] becomes member 0 and stays owned by the caller (it must hold the factorised model;
- * gpry_group_set_model leaves it alone).  If all devices are distinct the shortlist records travel
- * by an in-process RCCL all-gather (ncclCommInitAll; transport 1), otherwise -- or with
- * GPRY_GROUP_TRANSPORT=host, or if RCCL fails to initialise -- through the host (transport 0). */
+ * gpry_group_set_model leaves it alone).  The shortlist records (a few KB that the host ranks) are
+ * copied out by every member and merged on the host (transport 0); with GPRY_GROUP_TRANSPORT=rccl and
+ * all devices distinct they travel by an in-process RCCL all-gather instead (ncclCommInitAll;
+ * transport 1; falls back to 0, with the reason in the error text, if RCCL declines). */
 int gpry_group_create(int n, const int* devices, gpry_ctx* adopt0, gpry_group** out);
 int gpry_group_destroy(gpry_group* group);
 int gpry_group_size(gpry_group* group, int* n, int* transport);
