@@ -570,9 +570,8 @@ def main():
 
     # ---- strong scaling: the same cycle on ONE GPU of this node, measured in this very run, so
     # that the line carries its own speed-up (whole cycle and device sweep)
-    if world > 1 and args.scaling == "strong" and args.extras == "auto":
-        ref = None
-        if rank == 0:
+    if world > 1 and args.scaling == "strong" and args.extras == "auto" and rank == 0:
+        try:      # an exception here must not leave the other ranks waiting at the barrier below
             acq1 = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=None, devices=[local_rank])
             acq1.do_MC_sample = acq.do_MC_sample
             X_new, _, _ = acq1.multi_add(gpr, n_points=npts, rng=rng)    # uploads the whole pool
@@ -585,12 +584,13 @@ def main():
             dev.sync()
             one_ms = (time.perf_counter() - t1) / 2 * 1e3
             one_sweep = sum(dev.timing(k)[0] for k in ("cross_build", "sweep_gemm", "sweep_finish")) / 2
-            ref = {"one_gpu_ms_per_step": one_ms, "one_gpu_device_sweep_ms": one_sweep,
-                   "cycle_speedup": one_ms / ms_per_step,
-                   "device_sweep_speedup": one_sweep / sweep_ms if sweep_ms else None,
-                   "note": "1-GPU figures: rank 0 alone, whole pool, 2 steps after the timed region"}
-        if rank == 0:
-            result["scaling_check"] = ref
+            result["scaling_check"] = {
+                "one_gpu_ms_per_step": one_ms, "one_gpu_device_sweep_ms": one_sweep,
+                "cycle_speedup": one_ms / ms_per_step,
+                "device_sweep_speedup": one_sweep / sweep_ms if sweep_ms else None,
+                "note": "1-GPU figures: rank 0 alone, whole pool, 2 steps after the timed region"}
+        except Exception as e:
+            result["scaling_check"] = {"error": repr(e)}
     if rank == 0 and world == 1 and args.extras == "auto":
         try:
             result["refit_extras"] = refit_extras(bounds, gpr.X_train_all.copy(), gpr.y_train_all.copy())
