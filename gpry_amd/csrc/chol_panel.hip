@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused schedule (default up to Np = 5120).  Outer blocks of 128 columns (two panel steps).  Panel p's
+// Fused schedule (default up to Np = 7168).  Outer blocks of 128 columns (two panel steps).  Panel p's
 // trailing update is cut into 64 x 64 tiles (r, c) in units of 64 rows / columns.  Column c of block
 // bc = c / 2 needs the panels p = 0 .. bc-1 in order, each after panel p is complete:
 //   * p = bc-1 on the FIRST 64 columns of a block (c even) is applied by the panel step itself
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
 //     visit (chol_multi), C staying in registers in between.
 // The plan depends on Np only and is cached on the device.  Every element receives the same updates in
 // the same order with the same arithmetic as in potrf_lower_fused with chol_outer = 128: bit-identical
-// factors (tools/ab_chol_overlap.py, tests).  Above Np = 5120 the tiles no longer fit under the panel chain
+// factors (tools/ab_chol_overlap.py, tests).  Above Np = 7168 the tiles no longer fit under the panel chain
 // (the 64 x 64 tile is a latency device, not a throughput one): potrf_lower_fused takes over.
 struct OverlapPlan {
     int64_t Np = 0;
@@ -965,7 +965,7 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
 }
 
 int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
-    if (Np > (ctx->opt_chol_overlap_max > 0 ? ctx->opt_chol_overlap_max : 5120)) return potrf_lower_fused(ctx, A, Np);
+    if (Np > (ctx->opt_chol_overlap_max > 0 ? ctx->opt_chol_overlap_max : 7168)) return potrf_lower_fused(ctx, A, Np);
     OverlapPlan* pl = nullptr;
     const int prc = overlap_plan_get(ctx, Np, &pl);
     if (prc == 1) return potrf_lower_fused(ctx, A, Np);

@@ -77,7 +77,7 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *              "timing" = 0/1 per-stage HIP-event timers (gpry_timing_get); off by default, switched on by
  *                         gpry_timing_reset
  *              "predict_split" = 0/1 split-K contraction for gpry_predict batches of 5 ... a few thousand points
- *              "chol_overlap" = 0/1 trailing-update tiles ride in the Cholesky panel launches (default 1, Np <= 5120)
+ *              "chol_overlap" = 0/1 trailing-update tiles ride in the Cholesky panel launches (default 1, Np <= 7168)
  * Everything else is an A/B switch of the measurements quoted in DESIGN.md (defaults are the
  * measured best): "sweep_dma" 0..3, "sweep_persist", "sweep_overlap", "sweep_tilemap", "sweep_colouter", "chol_outer",
  * "chol_lookahead", "chol_overlap_max", "chol_caps", "split_k", "gemm_dma", "syrk_lds", "lauum_lds", "lauum_split",

@@ -744,9 +744,9 @@ def test_bordered_append_reports_a_non_positive_definite_border(dev):
         dev.predict(X[:3], return_std=True)           # no valid factor any more: the caller must refactorise
 
 
-@pytest.mark.parametrize("N", [100, 200, 300, 1100, 2100, 3100, 4096, 5000])
+@pytest.mark.parametrize("N", [100, 200, 300, 1100, 2100, 3100, 4096, 5000, 6100])
 def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, N):
-    """Default schedule up to Np = 5120: the trailing update is cut into 64 x 64 tiles that ride as extra
+    """Default schedule up to Np = 7168: the trailing update is cut into 64 x 64 tiles that ride as extra
     workgroups in the panel launches (deadline-driven plan), the panel steps apply the previous panel to their
     own columns themselves.  Same updates, same order, same arithmetic as the schedule with separate trailing
     launches (outer block 128): the factor must be bit-identical; a non-positive-definite matrix must report
