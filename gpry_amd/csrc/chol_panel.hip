@@ -767,7 +767,7 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
 // trailing launches: bit-identical.  Small on purpose: ~10 us, shorter than a panel step, so that tiles
 // riding in a panel launch never set its length (a lone 128 x 128 x 128 tile takes 32-36 us).
 #define S64 130
-struct TileItem { int64_t a_off, b_off, c_off; int64_t n; };   // n consecutive panels (128 columns apart) in one visit
+struct TileItem { int64_t a_off, b_off, c_off; int32_t n, pair; };   // n consecutive panels (128 columns apart) in one visit; pair: 128 rows
 __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
                                                  const int* info) {
     if (*info != 0) return;
@@ -839,6 +839,82 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
             for (int q = 0; q < 4; q++) cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16] = val[mi][ni][q];
 }
 
+// The same for TWO row blocks at once (128 x 64 outputs; option chol_pair, OFF by default): one B image serves
+// both, the read-modify-write and the workgroup's fixed costs are paid once per two tiles.  Costed at +36 % tile
+// throughput per CU; measured 9-11 % SLOWER at N = 4096 ... 8192 (tools/ab_chol_caps.py): the half-wave DMA
+// pieces and the two extra barriers per panel cost more than the shared image saves.  Kept as the A/B switch.  The operands do not fit LDS at full depth (128 x 130 + 64 x 130 doubles),
+// so a panel goes through in two k-halves of 64 (row stride 66), accumulated in ascending k as before:
+// bit-identical to two 64 x 64 visits.  DMA: a 64-k row segment is 512 B = half a wave instruction (lanes 0-31).
+#define S66 66
+__device__ __forceinline__ void syrk128x64_tile_body(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
+                                                     const int* info) {
+    if (*info != 0) return;
+    double* sA = smem;                    // 128 rows x 66
+    double* sB = smem + 128 * S66;        // 64 rows x 66
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
+    double* cbase = A + it.c_off + (int64_t)(wr * 64 + g) * ld + wc * 32 + r;
+    double val[4][2][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) val[mi][ni][q] = cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16];
+#pragma unroll 1
+    for (int u = 0; u < it.n; u++) {
+        v4d acc[4][2];
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) acc[mi][ni] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const double* Ag = A + it.a_off + (int64_t)u * 128 + h * 64;
+            const double* Bg = A + it.b_off + (int64_t)u * 128 + h * 64;
+            if (u | h) __syncthreads();            // everybody has read the previous images
+            if (lane < 32) {
+#pragma unroll
+                for (int i = 0; i < 32; i++) {      // wave w: rows w*32 .. w*32+31 of A
+                    const int row = w * 32 + i;
+                    gd_dma16(Ag + (int64_t)row * ld + 2 * lane, sA + row * S66);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {      // rows w*16 .. w*16+15 of B
+                    const int row = w * 16 + i;
+                    gd_dma16(Bg + (int64_t)row * ld + 2 * lane, sB + row * S66);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const double* pa = sA + (wr * 64 + r) * S66 + g;
+            const double* pb = sB + (wc * 32 + r) * S66 + g;
+#pragma unroll 2
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const double b0 = pb[k0], b1 = pb[16 * S66 + k0];
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++) {
+                    const double a = pa[mi * 16 * S66 + k0];
+                    acc[mi][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[mi][0], 0, 0, 0);
+                    acc[mi][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[mi][1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) val[mi][ni][q] = val[mi][ni][q] - acc[mi][ni][q];
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16] = val[mi][ni][q];
+}
+
 // Fused step: the first P workgroups are the panel step, the others each take one 64 x 64 tile of an
 // EARLIER panel's trailing update.  The panel chain is one workgroup's latency and leaves most of the GPU
 // idle; the tiles fill it.  In-order launches on one stream: no cross-stream events, and a panel workgroup
@@ -850,7 +926,9 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
         if (pa.Kfar < pa.K0) panel_step_body<true>(pa, smem, bx);
         else panel_step_body<false>(pa, smem, bx);
     } else {
-        syrk64_tile_body(pa.A, pa.ld, items[bx - P], smem, pa.info);
+        const TileItem it = items[bx - P];
+        if (it.pair) syrk128x64_tile_body(pa.A, pa.ld, it, smem, pa.info);
+        else syrk64_tile_body(pa.A, pa.ld, it, smem, pa.info);
     }
 }
 
@@ -896,14 +974,16 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
     std::vector<TileItem> items;
     struct Cand { int slack, c, r, p, n; };
     std::vector<Cand> cand;
-    auto item = [&](int r, int c, int p, int n) {
+    auto item = [&](int r, int c, int p, int n, int pair) {
         TileItem it;
-        it.a_off = (int64_t)r * 64 * Np + (int64_t)p * 128;      // 64 rows of tile row r, the 128 columns of panel p
+        it.a_off = (int64_t)r * 64 * Np + (int64_t)p * 128;      // 64 (pair: 128) rows from tile row r, the 128 columns of panel p
         it.b_off = (int64_t)c * 64 * Np + (int64_t)p * 128;
         it.c_off = (int64_t)r * 64 * Np + (int64_t)c * 64;
-        it.n = n;
+        it.n = n; it.pair = pair;
         return it;
     };
+    const bool pairing = ctx->opt_chol_pair != 0;
+    std::vector<int> cidx((size_t)n64 * n64, -1);        // (r, c) -> position in `cand` of this launch
     const int multi = ctx->opt_chol_multi;       // panels per visit of a lagging tile (1: one visit per update)
     for (int l = 0; l < nl; l++) {
         const int b = l / 2;
@@ -935,12 +1015,35 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
         });
         pl.first.push_back((int)items.size());
         int n_taken = 0;
-        for (const Cand& q : cand) {
+        for (size_t i = 0; i < cand.size(); i++) cidx[(size_t)cand[i].r * n64 + cand[i].c] = (int)i;
+        std::vector<char> used(cand.size(), 0);
+        for (size_t i = 0; i < cand.size(); i++) {
+            if (used[i]) continue;
+            const Cand& q = cand[i];
             if (n_taken >= cap && q.slack > 1) continue;          // not urgent and the launch is full
-            items.push_back(item(q.r, q.c, q.p, q.n));
+            // the row block below, same column, same pending panels: one 128 x 64 visit for both
+            int partner = -1;
+            if (pairing && q.r + 1 < n64) {
+                const int j = cidx[(size_t)(q.r + 1) * n64 + q.c];
+                if (j >= 0 && !used[j] && cand[j].p == q.p && cand[j].n == q.n) partner = j;
+            }
+            if (partner < 0 && pairing && q.r - 1 >= q.c) {
+                const int j = cidx[(size_t)(q.r - 1) * n64 + q.c];
+                if (j >= 0 && !used[j] && cand[j].p == q.p && cand[j].n == q.n) partner = j;
+            }
+            used[i] = 1;
+            int r0 = q.r;
+            if (partner >= 0) {
+                used[partner] = 1;
+                const Cand& q2 = cand[partner];
+                r0 = q.r < q2.r ? q.r : q2.r;
+                done[(size_t)q2.r * n64 + q2.c] = q2.p + q2.n; last[(size_t)q2.r * n64 + q2.c] = l;
+            }
+            items.push_back(item(r0, q.c, q.p, q.n, partner >= 0 ? 1 : 0));
             done[(size_t)q.r * n64 + q.c] = q.p + q.n; last[(size_t)q.r * n64 + q.c] = l;
             n_taken++;
         }
+        for (size_t i = 0; i < cand.size(); i++) cidx[(size_t)cand[i].r * n64 + cand[i].c] = -1;
         pl.count.push_back(n_taken);
         // what the NEXT launch's panel step reads must be complete now
         const int cnext = (l & 1) ? 2 * (b + 1) : 2 * b + 1;     // the 64-column strip factored next

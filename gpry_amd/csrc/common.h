@@ -49,6 +49,7 @@ struct gpry_ctx {
     int opt_chol_dbg = 0;        // k > 0: section stamps of workgroup k-1 of every panel step (read_diag)
     int opt_chol_overlap = 1;    // 1: trailing-update tiles ride in the panel launches (potrf_lower_overlap)
     int64_t opt_chol_overlap_max = 0;   // largest Np for that schedule (0: 7168; measured: -10 % at 6144, -1 % at 7168, +3 % at 8192)
+    int opt_chol_pair = 0;              // 1: two row blocks of a column in one 128 x 64 visit (measured 9-11 % SLOWER: off)
     int opt_chol_multi = 2;             // panels a lagging trailing tile applies per visit
     int opt_chol_caps = 0x21;           // tile rounds per launch: high nibble = first step of a block, low = second
     int opt_chol_lookahead = 0;  // 1: trailing update of the next panel's columns first, the rest on stream2

@@ -209,6 +209,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "sweep_overlap")) { ctx->opt_sweep_overlap = (int)value; return 0; }
     if (!strcmp(key, "chol_overlap")) { ctx->opt_chol_overlap = (int)value; return 0; }
     if (!strcmp(key, "chol_overlap_max")) { ctx->opt_chol_overlap_max = value; return 0; }
+    if (!strcmp(key, "chol_pair")) { ctx->opt_chol_pair = (int)value; overlap_plan_free(ctx); return 0; }
     if (!strcmp(key, "chol_multi")) {
         if (value < 1 || value > 4) return gpry_fail(ctx, -1, "chol_multi must be in 1..4");
         ctx->opt_chol_multi = (int)value; overlap_plan_free(ctx); return 0;
