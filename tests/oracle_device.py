@@ -125,6 +125,23 @@ class OracleDevice:
                 kg = np.dot(Kt, np.dot(V.T.dot(V), G))[0]
         return (mg, kg, G) if want_kgrad else (mg, kg)
 
+    def predict_grad_batch(self, X, want_kinv=True):
+        X = np.atleast_2d(np.asarray(X, dtype=float))
+        mean, std = self.predict(X, return_std=True)
+        both = [self.predict_grad(x, want_kinv=want_kinv) for x in X]
+        return mean, std, np.array([b[0] for b in both]), np.array([b[1] for b in both])
+
+    def append_rows(self, Xnew_, ynew_, alphanew):
+        """Bordered update stands in as a refactorisation of the enlarged set (same numbers to rounding)."""
+        X_ = np.vstack([self.X_, np.atleast_2d(Xnew_)])
+        y_ = np.append(self.y_, ynew_)
+        a = np.append(self.alpha, np.broadcast_to(alphanew, (len(np.atleast_1d(ynew_)),)))
+        theta, kid = self.theta, self.kid
+        self.set_train(X_, y_, a)
+        self.theta, self.kid = theta, kid
+        self.n_border = getattr(self, "n_border", 0) + 1
+        return self.factorize()
+
     def sweep_logexp(self, X, zeta, baseline, sigma_n, mask=None, M=None, want=("y", "sigma", "acq")):
         if X is None:
             X = self._pool

@@ -407,3 +407,26 @@ def test_proposers_draw_in_the_reference_order():
     assert np.all(pts >= b[:, 0]) and np.all(pts <= b[:, 1]) and len(np.unique(pts[:, 0])) > 10
     with pytest.raises(ValueError):
         PartialProposer(b, c, random_proposal_fraction=1.5)
+
+
+def test_predict_with_gradients_and_border_path_of_the_mirror_on_the_cpu_double():
+    """F10b through the host mirror with the oracle-backed double: the batch entry reproduces one reference call per
+    point (scalings, zero-std rule), and a fixed-theta append with frozen pre-processors goes through
+    ``append_rows`` while one that refits the pre-processors does not."""
+    from gpry_amd.kernels import clone
+    g = load_golden("gradients")
+    gpr = make_gpr(g["f10b_bounds"], 3)
+    k = clone(gpr.kernel)
+    k.theta = g["f10b_theta"]
+    gpr.kernel_, gpr._fitted = k, True
+    gpr.append_to_data(g["f10b_X"][:50], g["f10b_y"][:50], fit_gpr=False)
+    gpr.predict(g["f10b_Xq"][:1])                                   # brings the device factor up to date
+    gpr.append_to_data(g["f10b_X"][50:55], g["f10b_y"][50:55], fit_gpr=False, fit_classifier=False)
+    assert gpr.device.n_border == 1 and gpr.n_border_updates == 1 and gpr.device.N == 55
+    gpr.append_to_data(g["f10b_X"][55:], g["f10b_y"][55:], fit_gpr=False)           # pre-processors refit: full path
+    assert gpr.device.n_border == 1 and gpr.n == 60
+    m, s, mg, sg = gpr.predict_with_gradients(g["f10b_Xq"])
+    np.testing.assert_allclose(m, g["f10b_mean"], rtol=1e-9)
+    np.testing.assert_allclose(s, g["f10b_std"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(mg, g["f10b_mean_grad"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(sg, g["f10b_std_grad"], rtol=1e-4, atol=1e-6)
