@@ -454,3 +454,35 @@ def test_batched_gradients_equal_the_single_point_path(kid, N, d, m):
         np.testing.assert_allclose(mg[i], mgi * std_y, rtol=1e-9, atol=1e-9 * np.max(np.abs(mgi * std_y)))
         ref_sg = -kgi / (std[i] / std_y) * std_y * std_y if not np.isclose(std[i], 0) else np.zeros(d)
         np.testing.assert_allclose(sg[i], ref_sg, rtol=1e-6, atol=1e-8 * max(1.0, np.max(np.abs(ref_sg))))
+
+
+@pytest.mark.timeout(900)
+def test_config4_one_gpu_share_of_the_restart_farm_at_full_size(monkeypatch):
+    """BASELINE configs[4] as one GPU of eight sees it: N=8192, d=20, Matern-5/2, 4 of the 32 restarts (the first
+    from the current theta), through the farm entry over a 1-rank RCCL communicator.  The restarts shared by three
+    device contexts must select, bit for bit, what the reference's sequential loop selects; the optimum must be
+    one: its LML is the device's own LML at that theta and the gradient vanishes on the free hyper-parameters."""
+    import bench
+    from gpry_amd import _lib
+    from gpry_amd.parallel import fit_gpr_parallel
+    N, d = 8192, 20
+    bounds, X, y, _, _ = bench.synthetic(N, d, 8)
+    out = {}
+    for n_ctx in ("3", "1"):
+        monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", n_ctx)
+        gpr = make_gpr(bounds, 3, n_restarts_optimizer=4, random_state=3, noise_level=1e-2)
+        gpr.append_to_data(X[:N - d], y[:N - d], fit_gpr="simple")
+        comm = _lib.RcclComm(gpr.device, 1, 0, _lib.RcclComm.unique_id())
+        e0 = gpr.n_eval_loglike
+        lml, best, lmls = fit_gpr_parallel(gpr, X[N - d:], y[N - d:], comm=comm, fit="full", n_restarts=4)
+        comm.close()
+        out[n_ctx] = (gpr.kernel_.theta.copy(), lml, gpr.n_eval_loglike - e0)
+        assert gpr.n == N and best == 0 and lml == gpr.log_marginal_likelihood_value_
+        if n_ctx == "3":
+            val, grad = gpr.log_marginal_likelihood(gpr.kernel_.theta, eval_gradient=True)
+            assert abs(val - lml) <= 1e-9 * abs(lml)
+            kb = gpr.kernel_.bounds
+            free = (gpr.kernel_.theta > kb[:, 0] + 1e-6) & (gpr.kernel_.theta < kb[:, 1] - 1e-6)
+            assert free.sum() >= d // 2 and np.max(np.abs(grad[free])) <= 1e-2 * max(1.0, abs(lml)) ** 0.5
+    np.testing.assert_array_equal(out["3"][0], out["1"][0])
+    assert out["3"][1] == out["1"][1] and out["3"][2] == out["1"][2] and out["3"][2] > 10
