@@ -152,3 +152,31 @@ def test_group_applies_device_gates_on_every_member():
     for a, b in zip(res[0], res[1]):
         np.testing.assert_array_equal(a, b)
     assert np.isneginf(res[1][3]).sum() > 100           # the gates did mask candidates
+
+
+@pytest.mark.timeout(900)
+def test_config3_at_full_size_sharded_eight_ways_equals_one_context():
+    """BASELINE configs[3] logic at full size on one GPU: N=4096, d=16, M=1e6 candidates sharded over 8 contexts
+    (125 000 candidates = 4 launches each, model replicated and factorised on every member, shortlists merged
+    with the hold-back rule): proposals, lies, acquisition values, the ranked pool and the y / sigma arrays of
+    all 1e6 candidates must equal the one-context run bit for bit."""
+    import bench
+    from gpry_amd.gp_acquisition import NORA
+    N, d, M, npts = 4096, 16, 1_000_000, 16
+    bounds, X, y, Xc, _ = bench.synthetic(N, d, M)
+    theta = np.log(np.array([4.0] + [0.3] * d))
+    res = {}
+    for name, devices in (("one", [0]), ("eight", [0] * 8)):
+        gpr = make_gpr(bounds, 3, theta=theta, noise_level=1e-2)
+        gpr.append_to_data(X, y, fit_gpr=False)
+        acq = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, devices=devices)
+        acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+        out = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(2))
+        sample = acq.last_MC_sample()
+        res[name] = (out, acq.pool.acq_cond.copy(), sample[1], sample[2], acq.stats["sweep_contexts"])
+    assert res["one"][4] == 1 and res["eight"][4] == 8
+    for a, b in zip(res["one"][0], res["eight"][0]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res["one"][1], res["eight"][1])
+    np.testing.assert_array_equal(res["one"][2], res["eight"][2])
+    np.testing.assert_array_equal(res["one"][3], res["eight"][3])
