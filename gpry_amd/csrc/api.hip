@@ -269,7 +269,7 @@ __global__ void logexp_kernel(const double* __restrict__ mu, const double* __res
 // per candidate: reduce the partials, apply the reference's post-processing chain
 // (gpry/gpr.py:1180-1231) and LogExp.f (gpry/acquisition_functions.py:1068-1074)
 __global__ void sweep_finish_kernel(const double* __restrict__ mean_part, const double* __restrict__ ss_part,
-                                    int nt, int64_t ldp, int64_t m0, int64_t mc, const uint8_t* __restrict__ mask,
+                                    int nt_mean, int nt, int64_t ldp, int64_t m0, int64_t mc, const uint8_t* __restrict__ mask,
                                     double* __restrict__ y_all, double* __restrict__ sig_all,
                                     double* __restrict__ acq_all, FinishParams fp) {
     int64_t ml = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,7 +277,7 @@ __global__ void sweep_finish_kernel(const double* __restrict__ mean_part, const 
     int64_t m = m0 + ml;
     double mu_ = 0.0;
 #pragma unroll 8
-    for (int t = 0; t < nt; t++) mu_ += mean_part[(int64_t)t * ldp + ml];
+    for (int t = 0; t < nt_mean; t++) mu_ += mean_part[(int64_t)t * ldp + ml];
     double y = mu_ * fp.y_std + fp.y_mean;
     y = fmin(y, fp.clip_hi);
     unsigned mk = mask ? mask[m] : 0u;
@@ -370,7 +370,11 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
         GPRY_TRY(dev_alloc(ctx, &ctx->dKst, nbuf * Np * chunk));
         ctx->kst_cap = nbuf * Np * chunk;
     }
-    const int64_t part_stride = 2 * (int64_t)nt * chunk;
+    // gpry_predict with a few hundred points: the panel comes from the small-batch kernel, which leaves
+    // four mean partials per 128 training rows (kernel_build.hip: cross_build_small_kernel)
+    const bool small_build = allow_split && M <= 512;
+    const int nt_mean = small_build ? 4 * nt : nt;
+    const int64_t part_stride = (int64_t)(nt_mean + nt) * chunk;
     GPRY_TRY(ensure_part(ctx, nbuf * part_stride));
     FinishParams fp;
     fp.C = exp(ctx->theta[0]); fp.y_mean = ctx->tf.y_mean; fp.y_std = ctx->tf.y_std;
@@ -389,7 +393,7 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
         const int b = overlap ? (int)(c & 1) : 0;
         double* Kst = ctx->dKst + (int64_t)b * Np * chunk;
         double* mean_part = ctx->dpart + (int64_t)b * part_stride;
-        double* ss_part = mean_part + (int64_t)nt * chunk;
+        double* ss_part = mean_part + (int64_t)nt_mean * chunk;
         if (overlap) {
             if (c >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_free[b], 0));
             {
@@ -398,6 +402,9 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
             }
             HIP_TRY(ctx, hipEventRecord(ctx->ev_built[b], ctx->stream2));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[b], 0));
+        } else if (small_build) {
+            StageScope s(ctx, "cross_build");
+            GPRY_TRY(launch_cross_build_small(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
         } else {
             StageScope s(ctx, "cross_build");
             GPRY_TRY(launch_cross_build(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
@@ -447,7 +454,7 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
         {
             StageScope s(ctx, "sweep_finish");
             hipLaunchKernelGGL(sweep_finish_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream,
-                               mean_part, ss_part, nt, mcp, m0, mc, have_mask ? ctx->dmask : nullptr,
+                               mean_part, ss_part, nt_mean, nt, mcp, m0, mc, have_mask ? ctx->dmask : nullptr,
                                ctx->dy_all, ctx->dsig_all, ctx->dacq_all, fp);
             HIP_TRY(ctx, hipGetLastError());
         }
@@ -655,7 +662,9 @@ int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_
     const int nt = (int)(Np / 128), d = ctx->d, dpad = ctx->dpad;
     const bool need_u = want_kinv || std != nullptr;
     // workspace: points | k* panel (Np x mp) | U | W | mean partials (nt x mp) | |u|^2 (mp) | gradients (m x 2 dpad)
-    const int64_t need = round_up(m * d, 2) + 3 * Np * mp + (int64_t)nt * mp + mp + m * 2 * dpad;
+    const bool small_build = mp <= 512;
+    const int ntm = small_build ? 4 * nt : nt;      // mean partials per point
+    const int64_t need = round_up(m * d, 2) + 3 * Np * mp + (int64_t)ntm * mp + mp + m * 2 * dpad;
     if (need > ctx->g_cap) {
         if (ctx->dG) GPRY_TRY(dev_free(ctx, ctx->dG));
         ctx->dG = nullptr; ctx->g_cap = 0;
@@ -667,12 +676,13 @@ int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_
     double* Um = Kst + Np * mp;
     double* Wm = Um + Np * mp;
     double* mpart = Wm + Np * mp;
-    double* ss = mpart + (int64_t)nt * mp;
+    double* ss = mpart + (int64_t)ntm * mp;
     double* gout = ss + mp;
     HIP_TRY(ctx, hipMemcpyAsync(dXb, X, sizeof(double) * m * d, hipMemcpyHostToDevice, st));
     StageScope scope(ctx, "predict_grad_batch");
     const int64_t saveM = ctx->sw_M; ctx->sw_M = m;
-    int rc = launch_cross_build(ctx, dXb, 0, mp, mp, Kst, mpart, 1);
+    int rc = small_build ? launch_cross_build_small(ctx, dXb, 0, mp, mp, Kst, mpart, 1)
+                         : launch_cross_build(ctx, dXb, 0, mp, mp, Kst, mpart, 1);
     ctx->sw_M = saveM;
     if (rc) return rc;
     auto splits = [&](int64_t tiles) { int n = 1; while (n < 16 && tiles * n * 2 <= 1024 && Np / (n * 2) >= 64) n *= 2; return n; };
@@ -694,8 +704,8 @@ int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_
         GPRY_TRY(gemm_f64_launch(ctx, g, true, false, EPI_STORE));
     }
     GPRY_TRY(launch_gradx_batch(ctx, dXb, m, 1, want_kinv ? Wm : nullptr, mp, gout));
-    std::vector<double> hm((size_t)nt * mp), hs((size_t)mp), hg((size_t)m * 2 * dpad);
-    HIP_TRY(ctx, hipMemcpyAsync(hm.data(), mpart, sizeof(double) * nt * mp, hipMemcpyDeviceToHost, st));
+    std::vector<double> hm((size_t)ntm * mp), hs((size_t)mp), hg((size_t)m * 2 * dpad);
+    HIP_TRY(ctx, hipMemcpyAsync(hm.data(), mpart, sizeof(double) * ntm * mp, hipMemcpyDeviceToHost, st));
     if (need_u) HIP_TRY(ctx, hipMemcpyAsync(hs.data(), ss, sizeof(double) * mp, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(hg.data(), gout, sizeof(double) * m * 2 * dpad, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -703,7 +713,7 @@ int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_
     for (int64_t i = 0; i < m; i++) {
         if (mean) {
             double mu_ = 0.0;
-            for (int t = 0; t < nt; t++) mu_ += hm[(size_t)t * mp + i];
+            for (int t = 0; t < ntm; t++) mu_ += hm[(size_t)t * mp + i];
             mean[i] = fmin(mu_ * ctx->tf.y_std + ctx->tf.y_mean, ctx->tf.clip_hi);
         }
         if (std) {
@@ -1077,7 +1087,8 @@ int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, 
         ctx->kst_cap = Np * mp;
     }
     int64_t saveM = ctx->sw_M; ctx->sw_M = m;
-    int rc = launch_cross_build(ctx, dX, 0, mp, mp, ctx->dKst, nullptr, 1);
+    int rc = mp <= 512 ? launch_cross_build_small(ctx, dX, 0, mp, mp, ctx->dKst, nullptr, 1)
+                       : launch_cross_build(ctx, dX, 0, mp, mp, ctx->dKst, nullptr, 1);
     ctx->sw_M = saveM;
     if (rc) return rc;
     GemmArgs g = {};

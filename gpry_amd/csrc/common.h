@@ -231,6 +231,8 @@ int launch_kernel_rows(gpry_ctx* ctx, int64_t row0, int k, int64_t ldk, double* 
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
                        int64_t ldk, double* Kst, double* mean_part, int raw_affine,
                        hipStream_t st = nullptr);
+int launch_cross_build_small(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk,
+                             double* Kst, double* mean_part, int raw_affine);     // 4 x (Np/128) mean partials
 int launch_predict_mean_small(gpry_ctx* ctx, const double* Xc, int64_t M, int nsplit, double* part_out);
 int launch_gates(gpry_ctx* ctx, const double* Xc, int64_t M, uint8_t* mask);
 int launch_predict_small_std(gpry_ctx* ctx, const double* Xc, int M, double* kstar, double* mean_part,

@@ -379,6 +379,81 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
     if (in_chunk && mean_part) mean_part[(int64_t)jc * mc + ml] = macc;
 }
 
+// The same panel for a SMALL batch (a few hundred points: gpry_predict / gpry_predict_grad_batch): with one
+// candidate per thread and 128 training rows per workgroup the launch has Np/128 workgroups whose four waves
+// walk 128 rows each at a lone wave's FP64 rate (36 us whatever the batch size).  Here a workgroup is 64
+// candidates x 4 row groups of 32 training rows: four times as many workgroups, loops four times shorter.
+// Mean partials: one per (128-row chunk, row group): mean_part[(jc * 4 + rg) * mc + ml].
+template <int DP, int KID>
+__global__ __launch_bounds__(256) void cross_build_small_kernel(
+    const double* __restrict__ Xc, int64_t M, int64_t m0, int64_t mc,
+    const double* __restrict__ Xs, const double* __restrict__ alpha_,
+    double* __restrict__ Kst, int64_t ldk, double* __restrict__ mean_part,
+    KernParams kp, AffParams ap) {
+    __shared__ double Xl[128 * DP];
+    __shared__ double al[128];
+    const int t = threadIdx.x, rg = t >> 6;
+    const int64_t ml = (int64_t)blockIdx.x * 64 + (t & 63);
+    const int64_t m = m0 + ml;
+    const int jc = blockIdx.y;
+    for (int e = t; e < 128 * DP; e += 256) {
+        int row = e / DP, k = e - row * DP;
+        Xl[e] = (k < kp.dpad) ? Xs[((int64_t)jc * 128 + row) * kp.dpad + k] : 0.0;
+    }
+    if (t < 128) al[t] = alpha_ ? alpha_[jc * 128 + t] : 0.0;
+    double xs[DP];
+#pragma unroll
+    for (int k = 0; k < DP; k++) {
+        double v = 0.0;
+        if (k < kp.d && m < M) {
+            v = Xc[m * kp.d + k];
+            if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
+            v = v / ap.ls[k];
+        }
+        xs[k] = v;
+    }
+    __syncthreads();
+    double macc = 0.0;
+    const bool in_chunk = ml < mc;
+    const int64_t left = kp.N - (int64_t)jc * 128;
+    const int nvalid = left >= 128 ? 128 : (left > 0 ? (int)left : 0);
+    for (int jj = rg * 32; jj < rg * 32 + 32; jj++) {
+        double v = 0.0;
+        if (jj < nvalid) {
+            double r2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < DP; k++) {
+                double df = xs[k] - Xl[jj * DP + k];
+                r2 = fma(df, df, r2);
+            }
+            v = kp.C * corr_r2_fast<KID>(r2);
+            macc = fma(al[jj], v, macc);
+        }
+        if (in_chunk) Kst[((int64_t)jc * 128 + jj) * ldk + ml] = v;
+    }
+    if (in_chunk && mean_part) mean_part[((int64_t)jc * 4 + rg) * mc + ml] = macc;
+}
+// mean_part then holds 4 * (Np / 128) partials per candidate (row stride mc)
+int launch_cross_build_small(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk,
+                             double* Kst, double* mean_part, int raw_affine) {
+    hipStream_t st = ctx->stream;
+    KernParams kp = make_kp(ctx);
+    kp.has_aff = raw_affine && ctx->tf.has_x_affine;
+    AffParams ap = make_ap(ctx, kp.has_aff);
+    dim3 grid((unsigned)((mc + 63) / 64), (unsigned)(ctx->Np / 128));
+    int64_t M = ctx->sw_M;
+    if (ctx->d > 32) return gpry_fail(ctx, -1, "d > 32 is not supported");
+#define CS2(DP, KID) hipLaunchKernelGGL((cross_build_small_kernel<DP, KID>), grid, dim3(256), 0, st, Xc, M, \
+                                        m0, mc, ctx->dXs, ctx->dalpha_, Kst, ldk, mean_part, kp, ap)
+#define CS4(KID) { if (ctx->d <= 4) CS2(4, KID); else if (ctx->d <= 8) CS2(8, KID); \
+                   else if (ctx->d <= 16) CS2(16, KID); else if (ctx->d <= 24) CS2(24, KID); else CS2(32, KID); }
+    DISPATCH_KID(ctx->kernel_id, CS4)
+#undef CS4
+#undef CS2
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk,
                        double* Kst, double* mean_part, int raw_affine, hipStream_t st) {
     if (!st) st = ctx->stream;
