@@ -544,6 +544,34 @@ def main():
                               "frac": tf / F64_MFMA_PEAK_TFLOPS, "avg_ms": po_ms / po_n, "calls": po_n,
                               "flops_per_call": float(Np) ** 3 / 3.0,
                               "factor_chain_tflops": float(Np) ** 3 / (chain_ms * 1e-3) / 1e12}
+    if rank == 0 and po_n:
+        # From Np = 4096 on the first three quarters of V = L^-1 run on a second stream underneath the
+        # panel chain of potrf (csrc/chol.hip: trtri_pipeline_*): the `potrf` stage above then contains
+        # the price of sharing the GPU, the `trtri` stage only what is left after it.  Quote the same
+        # evaluation with the serial chain beside it (outside the timed region).
+        try:
+            import time as _time
+            th = np.array(gpr.kernel_.theta, dtype=float)
+            serial = {}
+            for pipe in (0, 1):
+                dev.set_option("factor_pipeline", pipe)
+                for _ in range(2):
+                    dev.lml(th, True)
+                dev.timing_reset()
+                t0 = _time.perf_counter()
+                for _ in range(8):
+                    dev.lml(th, True)
+                wall = (_time.perf_counter() - t0) / 8 * 1e3
+                serial[pipe] = {"lml_grad_wall_ms": wall,
+                                **{k + "_ms": dev.timing(k)[0] / max(dev.timing(k)[1], 1) for k in ("potrf", "trtri", "lauum")}}
+            dev.set_option("timing", 0)
+            result["cholesky"]["serial_chain"] = serial[0]
+            result["cholesky"]["pipelined_chain"] = serial[1]
+            result["cholesky"]["potrf_alone_tflops"] = (float(Np) ** 3 / 3.0) / (serial[0]["potrf_ms"] * 1e-3) / 1e12
+        except Exception as e:
+            result["cholesky"]["serial_chain_error"] = repr(e)
+        finally:
+            dev.set_option("factor_pipeline", 1)
     if rank == 0:
         # the build is one 40-us launch per LML evaluation: two events around a single launch also
         # time the dispatch gap, so quote the steady-state duration (50 launches back to back) too

@@ -50,6 +50,15 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
         StageScope s(ctx, "potrf");
         GPRY_TRY(rocsolver_potrf_trtri(ctx, A, V, ctx->Np, 1));
     } else {
+        // V = L^-1 phase by phase on stream2 while the panel chain is still running (chol.hip); "trtri" then
+        // times what is left of it after potrf
+        bool piped = false;
+        if (ctx->opt_factor_pipeline && ctx->opt_chol == 0 && !ctx->opt_chol_lookahead &&
+            ctx->Np >= ctx->opt_factor_pipeline_min) {
+            const int rc = trtri_pipeline_begin(ctx, A, V, T, ctx->Np);
+            if (rc < 0) return rc;
+            piped = rc == 0;
+        }
         {
             StageScope s(ctx, "potrf");
             const bool overlap = ctx->opt_chol_overlap && !ctx->opt_chol_lookahead && ctx->opt_chol_outer == 0;
@@ -58,7 +67,8 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
         }
         {
             StageScope s(ctx, "trtri");
-            GPRY_TRY(trtri_lower(ctx, A, V, T, ctx->Np));
+            if (piped) GPRY_TRY(trtri_pipeline_finish(ctx));
+            else GPRY_TRY(trtri_lower(ctx, A, V, T, ctx->Np));
         }
     }
     if (!info_host) return 0;      // the caller fetches dinfo itself, together with its results

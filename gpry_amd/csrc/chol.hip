@@ -7,6 +7,7 @@
 // runs in LDS / registers.  Matrices are padded to a multiple of 128 with an identity
 // block, so no kernel needs edge handling.
 #include "common.h"
+#include <algorithm>
 #include <dlfcn.h>
 
 // ------------------------------------------------------------------------------------
@@ -164,11 +165,24 @@ static int build_tree(int lo, int hi, std::vector<TriNode>& out) {
 }
 
 // cached per-Np batch descriptors of the trtri recursion
+// The same recursion cut into phases for the pipelined factor chain (trtri_pipeline_*): phase p holds what
+// can run once the first `blocks_done` 64-column blocks of L are final.
+struct TrtriPhaseLevel {
+    int lev = 0;                            // index into the per-level arrays of the plan
+    int64_t t_first = 0, v_first = 0;       // offsets into d_phase_items
+    int n_t = 0, n_v = 0, mM_t = 0, mN_t = 0, mM_v = 0, mN_v = 0;
+};
+struct TrtriPhase {
+    int blocks_done = 0, diag_lo = 0, diag_hi = 0;
+    std::vector<TrtriPhaseLevel> levels;
+};
 struct TrtriPlan {
     int64_t Np = 0;
     std::vector<GemmBatchItem*> d_t, d_v;   // per level
     std::vector<int> count, maxM, maxN;
     std::vector<int> aligned;               // per level: every item is a multiple of 128 in M, N and K
+    std::vector<TrtriPhase> phases;         // empty: too few blocks to cut
+    GemmBatchItem* d_phase_items = nullptr;
 };
 // the plan lives in its context (ctx->trtri_plan): distinct contexts may be driven from distinct threads
 void trtri_plan_free(gpry_ctx* ctx) {
@@ -176,6 +190,7 @@ void trtri_plan_free(gpry_ctx* ctx) {
     if (!pl) return;
     for (auto p : pl->d_t) if (p) (void)hipFree(p);
     for (auto p : pl->d_v) if (p) (void)hipFree(p);
+    if (pl->d_phase_items) (void)hipFree(pl->d_phase_items);
     delete pl;
     ctx->trtri_plan = nullptr;
 }
@@ -186,6 +201,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
     if (pl.Np == Np) { *out = &pl; return 0; }
     for (auto p : pl.d_t) if (p) (void)hipFree(p);
     for (auto p : pl.d_v) if (p) (void)hipFree(p);
+    if (pl.d_phase_items) (void)hipFree(pl.d_phase_items);
     pl = TrtriPlan();       // Np = 0: an incomplete plan is never taken for a finished one
     std::vector<TriNode> nodes;
     int nlev = build_tree(0, (int)(Np / 64), nodes);
@@ -226,8 +242,112 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
         pl.count.push_back((int)bt.size()); pl.maxM.push_back(mM); pl.maxN.push_back(mN);
         pl.aligned.push_back(al);
     }
+    // Phases: checkpoints at the split points of the top two tree levels (quarters of the matrix for a
+    // power-of-two block count).  Diagonal block b is ready once b + 1 blocks of L are final, the product
+    // T = L21 V11 of a node once `mid` blocks are (columns lo..mid of L are final for ALL rows after their
+    // panel step, and V11 is complete by then), its V21 = -V22 T once `hi` blocks are.
+    const int nblk = (int)(Np / 64);
+    if (nblk >= 8) {
+        const TriNode root = nodes.back();
+        std::vector<int> cps = {root.mid, nblk};
+        for (auto& nd : nodes) {
+            if (nd.lo == root.lo && nd.hi == root.mid) cps.push_back(nd.mid);
+            if (nd.lo == root.mid && nd.hi == root.hi) cps.push_back(nd.mid);
+        }
+        std::sort(cps.begin(), cps.end());
+        cps.erase(std::unique(cps.begin(), cps.end()), cps.end());
+        auto phase_of = [&](int blocks) { size_t p = 0; while (cps[p] < blocks) p++; return p; };
+        std::vector<GemmBatchItem> all;
+        int dlo = 0;
+        for (size_t p = 0; p < cps.size(); p++) {
+            TrtriPhase ph;
+            ph.blocks_done = cps[p]; ph.diag_lo = dlo; ph.diag_hi = cps[p]; dlo = cps[p];
+            for (int lev = 1; lev <= nlev; lev++) {
+                TrtriPhaseLevel pv; pv.lev = lev - 1;
+                std::vector<GemmBatchItem> bt, bv;
+                for (auto& nd : nodes) {
+                    if (nd.level != lev) continue;
+                    int64_t lo = nd.lo * 64, mid = nd.mid * 64, hi = nd.hi * 64;
+                    int m = (int)(hi - mid), n = (int)(mid - lo);
+                    if (phase_of(nd.mid) == p) {
+                        GemmBatchItem a;
+                        a.a_off = mid * Np + lo; a.b_off = lo * Np + lo; a.c_off = mid * Np + lo;
+                        a.M = m; a.N = n; a.K = n; a.pad = 0;
+                        bt.push_back(a);
+                        if (m > pv.mM_t) pv.mM_t = m;
+                        if (n > pv.mN_t) pv.mN_t = n;
+                    }
+                    if (phase_of(nd.hi) == p) {
+                        GemmBatchItem b;
+                        b.a_off = mid * Np + mid; b.b_off = mid * Np + lo; b.c_off = mid * Np + lo;
+                        b.M = m; b.N = n; b.K = m; b.pad = 0;
+                        bv.push_back(b);
+                        if (m > pv.mM_v) pv.mM_v = m;
+                        if (n > pv.mN_v) pv.mN_v = n;
+                    }
+                }
+                if (bt.empty() && bv.empty()) continue;
+                pv.n_t = (int)bt.size(); pv.n_v = (int)bv.size();
+                pv.t_first = (int64_t)all.size(); all.insert(all.end(), bt.begin(), bt.end());
+                pv.v_first = (int64_t)all.size(); all.insert(all.end(), bv.begin(), bv.end());
+                ph.levels.push_back(pv);
+            }
+            pl.phases.push_back(ph);
+        }
+        hipError_t e = hipMalloc(&pl.d_phase_items, all.size() * sizeof(GemmBatchItem));
+        if (e == hipSuccess) e = hipMemcpy(pl.d_phase_items, all.data(), all.size() * sizeof(GemmBatchItem), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            for (auto p : pl.d_t) if (p) (void)hipFree(p);
+            for (auto p : pl.d_v) if (p) (void)hipFree(p);
+            if (pl.d_phase_items) (void)hipFree(pl.d_phase_items);
+            pl = TrtriPlan();
+            return gpry_fail(ctx, -2, "trtri plan (Np = %lld): %s", (long long)Np, hipGetErrorString(e));
+        }
+    }
     pl.Np = Np;             // committed only once every level is on the device
     *out = &pl;
+    return 0;
+}
+
+// split-K factor of a level: from the figures of the WHOLE level, also when only part of its items is
+// launched (pipelined chain), so that every product is summed in the same order in both schedules
+static int trtri_level_nsplit(gpry_ctx* ctx, const TrtriPlan* pl, size_t lev) {
+    // the top levels are a handful of long tiles: split their K range so that the launch fills
+    // the GPU (512 resident workgroups) and its critical path shrinks accordingly
+    const int tm = (pl->maxM[lev] + 127) / 128, tn = (pl->maxN[lev] + 127) / 128;
+    const int64_t tiles = (int64_t)tm * tn * pl->count[lev];
+    int nsplit = 1;
+    if (ctx->opt_split_k && pl->maxN[lev] >= 512) {
+        while (nsplit < 4 && tiles * nsplit * 2 <= 1024 && pl->maxN[lev] / (nsplit * 2) >= 128) nsplit *= 2;
+    }
+    if (ctx->opt_trtri_split_cap > 0 && nsplit > ctx->opt_trtri_split_cap) nsplit = ctx->opt_trtri_split_cap;
+    return nsplit;
+}
+
+// one level's pair of batched products (all of the level, or the part of it that belongs to a phase)
+static int trtri_level_products(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np, int nsplit, int aligned,
+                                const GemmBatchItem* d_t, int n_t, int mM_t, int mN_t,
+                                const GemmBatchItem* d_v, int n_v, int mM_v, int mN_v, hipStream_t st) {
+    double* sbuf = nullptr;
+    if (nsplit > 1) GPRY_TRY(gemm_split_scratch(ctx, nsplit, Np * Np, &sbuf));
+    if (n_t > 0) {
+        GemmArgs g = {};
+        g.A = L; g.lda = Np; g.B = V; g.ldb = Np; g.C = T; g.ldc = Np;
+        g.M = mM_t; g.N = mN_t; g.K = 0;
+        g.kmode = KM_B_LOWER; g.lower_only = 0; g.tile_map = TM_ROWMAJOR;
+        g.batch = d_t; g.n_batch = n_t; g.info = ctx->dinfo; g.stream = st;
+        g.nsplit = nsplit; g.split_buf = sbuf; g.split_stride = Np * Np; g.dma_ok = aligned;
+        GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_STORE));
+    }
+    if (n_v > 0) {
+        GemmArgs h = {};
+        h.A = V; h.lda = Np; h.B = T; h.ldb = Np; h.C = V; h.ldc = Np;
+        h.M = mM_v; h.N = mN_v; h.K = 0;
+        h.kmode = KM_A_LOWER; h.lower_only = 0; h.tile_map = TM_ROWMAJOR;
+        h.batch = d_v; h.n_batch = n_v; h.info = ctx->dinfo; h.stream = st;
+        h.nsplit = nsplit; h.split_buf = sbuf; h.split_stride = Np * Np; h.dma_ok = aligned;
+        GPRY_TRY(gemm_f64_launch(ctx, h, false, false, EPI_STORE_NEG));
+    }
     return 0;
 }
 
@@ -249,33 +369,103 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
     }
     TrtriPlan* pl = nullptr;
     GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
-    for (size_t lev = 0; lev < pl->count.size(); lev++) {
-        // the top levels are a handful of long tiles: split their K range so that the launch fills
-        // the GPU (512 resident workgroups) and its critical path shrinks accordingly
-        const int tm = (pl->maxM[lev] + 127) / 128, tn = (pl->maxN[lev] + 127) / 128;
-        const int64_t tiles = (int64_t)tm * tn * pl->count[lev];
-        int nsplit = 1;
-        if (ctx->opt_split_k && pl->maxN[lev] >= 512) {
-            while (nsplit < 4 && tiles * nsplit * 2 <= 1024 && pl->maxN[lev] / (nsplit * 2) >= 128) nsplit *= 2;
-        }
-        if (ctx->opt_trtri_split_cap > 0 && nsplit > ctx->opt_trtri_split_cap) nsplit = ctx->opt_trtri_split_cap;
-        double* sbuf = nullptr;
-        if (nsplit > 1) GPRY_TRY(gemm_split_scratch(ctx, nsplit, Np * Np, &sbuf));
-        GemmArgs g = {};
-        g.A = L; g.lda = Np; g.B = V; g.ldb = Np; g.C = T; g.ldc = Np;
-        g.M = pl->maxM[lev]; g.N = pl->maxN[lev]; g.K = 0;
-        g.kmode = KM_B_LOWER; g.lower_only = 0; g.tile_map = TM_ROWMAJOR;
-        g.batch = pl->d_t[lev]; g.n_batch = pl->count[lev]; g.info = ctx->dinfo;
-        g.nsplit = nsplit; g.split_buf = sbuf; g.split_stride = Np * Np; g.dma_ok = pl->aligned[lev];
-        GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_STORE));
-        GemmArgs h = {};
-        h.A = V; h.lda = Np; h.B = T; h.ldb = Np; h.C = V; h.ldc = Np;
-        h.M = pl->maxM[lev]; h.N = pl->maxN[lev]; h.K = 0;
-        h.kmode = KM_A_LOWER; h.lower_only = 0; h.tile_map = TM_ROWMAJOR;
-        h.batch = pl->d_v[lev]; h.n_batch = pl->count[lev]; h.info = ctx->dinfo;
-        h.nsplit = nsplit; h.split_buf = sbuf; h.split_stride = Np * Np; h.dma_ok = pl->aligned[lev];
-        GPRY_TRY(gemm_f64_launch(ctx, h, false, false, EPI_STORE_NEG));
+    for (size_t lev = 0; lev < pl->count.size(); lev++)
+        GPRY_TRY(trtri_level_products(ctx, L, V, T, Np, trtri_level_nsplit(ctx, pl, lev), pl->aligned[lev],
+                                      pl->d_t[lev], pl->count[lev], pl->maxM[lev], pl->maxN[lev],
+                                      pl->d_v[lev], pl->count[lev], pl->maxM[lev], pl->maxN[lev], st));
+    return 0;
+}
+
+// ---- V = L^-1 underneath the Cholesky factorisation --------------------------------------------
+// The panel chain of potrf is latency-bound and leaves most of the GPU idle (13.8 % of the matrix pipe at
+// N = 4096), and three quarters of V = L^-1 depend on columns of L that are final long before the last
+// panel: after every checkpoint (a quarter of the blocks) the potrf loop calls trtri_pipeline_step, which
+// records an event on the main stream and queues that phase's products on stream2.  The last phase runs on
+// the main stream once both are done.  Same products, same split-K factors, same operands as trtri_lower:
+// V is bit-identical (tests/test_hip_parity.py::test_pipelined_factor_chain_is_bit_identical).
+// The side work is not free for the chain: a panel-step workgroup needs a whole CU's LDS (135 KB) and waits
+// while the CUs hold GEMM workgroups of the side stream (potrf 1.70 -> 1.94 ms at N = 4096, V = L^-1 after it
+// 0.87 -> 0.49 ms: LML+gradient 3.35 -> 3.22 ms; 7.20 -> 6.94 at 6144, 13.9 -> 13.5 at 8192; neutral at 3072, a loss below
+// that (default from Np = 4096; tools/ab_factor_pipeline.py).  A lowest-priority side stream changes nothing (no CU is held free
+// for the urgent kernel); a side stream masked to 64 / 128 / 192 CUs (hipExtStreamCreateWithCUMask) doubles
+// the time of the potrf launches themselves (4.2 / 3.7 / 3.7 ms): not kept.
+struct TrtriPipe {
+    const double* L = nullptr; double* V = nullptr; double* T = nullptr;
+    int64_t Np = 0; TrtriPlan* pl = nullptr; size_t next = 0; bool active = false;
+    hipStream_t side = nullptr;     // where the early phases run (ctx->stream2)
+};
+static TrtriPipe* pipe_of(gpry_ctx* ctx) {
+    if (!ctx->trtri_pipe) ctx->trtri_pipe = new TrtriPipe();
+    return static_cast<TrtriPipe*>(ctx->trtri_pipe);
+}
+void trtri_pipe_free(gpry_ctx* ctx) {
+    delete static_cast<TrtriPipe*>(ctx->trtri_pipe);
+    ctx->trtri_pipe = nullptr;
+}
+static int trtri_phase_run(gpry_ctx* ctx, TrtriPipe* pp, size_t p, hipStream_t st) {
+    const TrtriPlan* pl = pp->pl;
+    const TrtriPhase& ph = pl->phases[p];
+    if (ph.diag_hi > ph.diag_lo)
+        GPRY_TRY(launch_trtri_diag_range(ctx, pp->L, pp->V, pp->Np, ph.diag_lo, ph.diag_hi - ph.diag_lo, st));
+    for (const TrtriPhaseLevel& pv : ph.levels)
+        GPRY_TRY(trtri_level_products(ctx, pp->L, pp->V, pp->T, pp->Np, trtri_level_nsplit(ctx, pl, (size_t)pv.lev),
+                                      pl->aligned[pv.lev], pl->d_phase_items + pv.t_first, pv.n_t, pv.mM_t, pv.mN_t,
+                                      pl->d_phase_items + pv.v_first, pv.n_v, pv.mM_v, pv.mN_v, st));
+    return 0;
+}
+// returns 1 when the chain is not cut for this size (the caller runs trtri_lower after potrf)
+int trtri_pipeline_begin(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np) {
+    TrtriPipe* pp = pipe_of(ctx);
+    pp->active = false;
+    if (!ctx->stream2) return 1;
+    TrtriPlan* pl = nullptr;
+    GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
+    if (pl->phases.size() < 2) return 1;
+    while (ctx->ev_pool.size() < pl->phases.size() + 2) {
+        hipEvent_t ev;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->ev_pool.push_back(ev);
     }
+    // the split-K scratch is shared by all phases: size it before anything is queued
+    int maxsplit = 1;
+    for (size_t lev = 0; lev < pl->count.size(); lev++) {
+        const int ns = trtri_level_nsplit(ctx, pl, lev);
+        if (ns > maxsplit) maxsplit = ns;
+    }
+    double* sbuf = nullptr;
+    if (maxsplit > 1) GPRY_TRY(gemm_split_scratch(ctx, maxsplit, Np * Np, &sbuf));
+    pp->L = L; pp->V = V; pp->T = T; pp->Np = Np; pp->pl = pl; pp->next = 0; pp->active = true;
+    pp->side = ctx->stream2;
+    // V may still be read by work queued earlier on the main stream
+    hipEvent_t ev0 = ctx->ev_pool[pl->phases.size()];
+    HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(pp->side, ev0, 0));
+    HIP_TRY(ctx, hipMemsetAsync(V, 0, sizeof(double) * Np * Np, pp->side));
+    return 0;
+}
+// called by the potrf loops after the launch that makes 64-column block `blocks_done - 1` of L final
+int trtri_pipeline_step(gpry_ctx* ctx, int blocks_done) {
+    TrtriPipe* pp = static_cast<TrtriPipe*>(ctx->trtri_pipe);
+    if (!pp || !pp->active) return 0;
+    const TrtriPlan* pl = pp->pl;
+    if (pp->next + 1 >= pl->phases.size() || pl->phases[pp->next].blocks_done != blocks_done) return 0;
+    hipEvent_t ev = ctx->ev_pool[pp->next];
+    HIP_TRY(ctx, hipEventRecord(ev, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(pp->side, ev, 0));
+    GPRY_TRY(trtri_phase_run(ctx, pp, pp->next, pp->side));
+    pp->next++;
+    return 0;
+}
+int trtri_pipeline_finish(gpry_ctx* ctx) {
+    TrtriPipe* pp = static_cast<TrtriPipe*>(ctx->trtri_pipe);
+    if (!pp || !pp->active) return gpry_fail(ctx, -1, "trtri_pipeline_finish without begin");
+    pp->active = false;
+    const TrtriPlan* pl = pp->pl;
+    // phases the potrf loop did not reach (it returned early): run them now, in order
+    hipEvent_t evd = ctx->ev_pool[pl->phases.size() + 1];
+    HIP_TRY(ctx, hipEventRecord(evd, pp->side));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, evd, 0));
+    for (; pp->next < pl->phases.size(); pp->next++) GPRY_TRY(trtri_phase_run(ctx, pp, pp->next, ctx->stream));
     return 0;
 }
 

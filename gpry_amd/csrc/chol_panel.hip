@@ -282,6 +282,13 @@ int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hip
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+// diagonal blocks blk0 .. blk0 + nblk - 1 only (pipelined factor chain, chol.hip)
+int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st) {
+    const int64_t off = (int64_t)blk0 * 64 * (Np + 1);
+    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)nblk), dim3(256), 0, st, L + off, V + off, Np, ctx->dinfo);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
 
 // `arrive` / `target`: the diagonal workgroup overwrites D with its factor in place, while every
 // other workgroup of the launch reads D.  Workgroups count in on `arrive` once their loads have
@@ -735,6 +742,7 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
             if (ctx->opt_chol_dbg) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); dbg = ctx->dsel + 16; }
             hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), 0, st, A, Np, j0, K0, ctx->N, ctx->dinfo,
                                ctx->dinfo + 2, arrivals, dbg, ctx->opt_chol_dbg - 1);
+            GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));
         }
         const int64_t r0 = K0 + ob;
         if (r0 >= Np) break;
@@ -1088,6 +1096,7 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
                             dbg, ctx->opt_chol_dbg - 1};
             hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + pl->count[l])), dim3(256), 0, st, pa,
                                pl->d_items + pl->first[l], P);
+            GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));
         }
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -133,6 +133,9 @@ struct gpry_ctx {
     int64_t n_border = 0;      // rows appended by border updates since the last full factorisation (diagnostic)
 
     void* trtri_plan = nullptr;
+    void* trtri_pipe = nullptr;   // state of a pipelined factor chain in flight (chol.hip)
+    int opt_factor_pipeline = 1;  // 1: V = L^-1 phases run on stream2 underneath potrf
+    int opt_factor_pipeline_min = 4096;   // from this Np on (neutral at 3072, a loss at 2048: tools/ab_factor_pipeline.py)
     void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
 
     // host pinned staging
@@ -217,6 +220,7 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
 int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
 // gemm_dma.hip: LDS-DMA staged, software-pipelined variant for 128-aligned products (NN, NT, TN)
 int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st);   // chol_panel.hip
+int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st);
 bool gemm_dma_usable(const GemmArgs& g, int M, int N, int K);
 int gemm_dma_launch_product(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi, dim3 grid);
 int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g);   // sweep_gemm.hip (LDS-DMA staging)
@@ -249,6 +253,11 @@ int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np);             // info -> ct
 int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // fused panel steps, trailing update as its own launches
 int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);     // panel step + previous trailing tiles in ONE launch (default)
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
+// V = L^-1 queued phase by phase underneath potrf (chol.hip); begin returns 1 when the size is not cut
+int trtri_pipeline_begin(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
+int trtri_pipeline_step(gpry_ctx* ctx, int blocks_done);
+int trtri_pipeline_finish(gpry_ctx* ctx);
+void trtri_pipe_free(gpry_ctx* ctx);
 int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np);
 int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha,
                 int64_t Np);

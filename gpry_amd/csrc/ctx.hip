@@ -170,6 +170,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     timers_collect(ctx);
     trtri_plan_free(ctx);
+    trtri_pipe_free(ctx);
     overlap_plan_free(ctx);
     void* bufs[] = {ctx->dX, ctx->dXs, ctx->dy, ctx->dnoise, ctx->dA, ctx->dV, ctx->dW, ctx->dW2, ctx->dW3,
                     ctx->dalpha_, ctx->dvec, ctx->dinfo, ctx->dparams, ctx->dXc, ctx->dmask, ctx->dy_all,
@@ -228,6 +229,8 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "lauum_split")) { ctx->opt_lauum_split = (int)value; return 0; }
     if (!strcmp(key, "trtri_split_cap")) { ctx->opt_trtri_split_cap = (int)value; return 0; }
     if (!strcmp(key, "trtri_diag_v1")) { ctx->opt_trtri_diag_v1 = (int)value; return 0; }
+    if (!strcmp(key, "factor_pipeline")) { ctx->opt_factor_pipeline = (int)value; return 0; }
+    if (!strcmp(key, "factor_pipeline_min")) { ctx->opt_factor_pipeline_min = (int)value; return 0; }
     if (!strcmp(key, "lauum_lds")) { ctx->opt_lauum_lds = (int)value; return 0; }
     if (!strcmp(key, "syrk_lds")) { ctx->opt_syrk_lds = (int)value; return 0; }
     if (!strcmp(key, "predict_small")) { ctx->opt_predict_small = (int64_t)value; return 0; }

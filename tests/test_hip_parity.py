@@ -792,3 +792,54 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
     finally:
         dev.set_option("chol_outer", 0)
         dev.set_option("chol_overlap", 1)
+
+
+@pytest.mark.parametrize("N", [1000, 1100, 2100, 4096, 5000, 6100, 7300])
+def test_pipelined_factor_chain_is_bit_identical(dev, N):
+    """V = L^-1 queued phase by phase on a second stream underneath the Cholesky panel chain
+    (``factor_pipeline=1``, default from Np = 4096): same products, same split-K factors, same operands as
+    the serial chain -- L, V, alpha_, the LML and its gradient must be bit-identical, on power-of-two and
+    ragged block counts, with both Cholesky schedules, and a non-positive-definite matrix must report the
+    same leading minor."""
+    d = 5
+    rng = np.random.default_rng(N + 1)
+    X = rng.uniform(0, 1, (N, d))
+    y = rng.standard_normal(N)
+    dev.set_affine()
+    dev.set_train(X, y, np.full(N, 1e-5))
+    theta = np.log(np.array([3.0, 0.4, 0.5, 0.6, 0.7, 0.8]))
+    dev.set_theta(3, theta)
+    try:
+        dev.set_option("factor_pipeline_min", 0)        # default: from Np = 4096 on
+        for overlap in (1, 0):
+            dev.set_option("chol_overlap", overlap)
+            dev.set_option("factor_pipeline", 0)
+            assert dev.factorize() == 0
+            L0, V0, a0 = dev.get_factor()
+            lml0 = dev.lml(theta, True)
+            dev.set_option("factor_pipeline", 1)
+            for _ in range(3):
+                assert dev.factorize() == 0
+                L1, V1, a1 = dev.get_factor()
+                assert np.array_equal(L0, L1) and np.array_equal(V0, V1) and np.array_equal(a0, a1)
+                lml1 = dev.lml(theta, True)
+                assert lml0[0] == lml1[0] and np.array_equal(lml0[1], lml1[1])
+        Vd = np.tril(V1)[:N, :N]
+        Ld = np.tril(L1)[:N, :N]
+        assert relmax(Vd @ Ld, np.eye(N)) < 1e-9
+        Xb = X.copy()
+        Xb[N - 7] = Xb[N // 3]
+        alpha = np.full(N, 1e-5)
+        alpha[N - 7] = alpha[N // 3] = -1e-3
+        infos = []
+        for pipe in (0, 1):
+            dev.set_option("factor_pipeline", pipe)
+            dev.set_train(Xb, y, alpha)
+            dev.set_theta(3, theta)
+            infos.append(dev.factorize())
+        assert infos[0] == infos[1] and infos[0] > 0
+    finally:
+        dev.set_option("chol_overlap", 1)
+        dev.set_option("factor_pipeline", 1)
+        dev.set_option("factor_pipeline_min", 4096)
+
