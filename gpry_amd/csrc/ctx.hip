@@ -1,5 +1,6 @@
 // Context, memory, options, timing and micro-benchmarks for libgpry_hip.so.
 #include "common.h"
+#include <string>
 #include <stdarg.h>
 
 // per thread: concurrent optimiser restarts drive distinct contexts from distinct host threads
@@ -159,6 +160,27 @@ int gpry_ctx_create(int device, gpry_ctx** out) {
         if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipEventCreate"); }
     if (hipMalloc((void**)&ctx->dinfo, 16 * sizeof(int)) != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipMalloc info"); }
     (void)hipMemset(ctx->dinfo, 0, 16 * sizeof(int));
+    // GPRY_HIP_OPTIONS="key=value,key=value": options for every context of the process (A/B runs of
+    // unmodified callers; an unknown key or a malformed entry fails the creation loudly)
+    if (const char* env = getenv("GPRY_HIP_OPTIONS")) {
+        std::string all(env);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(pos, end - pos);
+            pos = end + 1;
+            if (item.empty()) continue;
+            const size_t eq = item.find('=');
+            char* tail = nullptr;
+            const long long v = eq == std::string::npos ? 0 : strtoll(item.c_str() + eq + 1, &tail, 10);
+            if (eq == std::string::npos || eq == 0 || tail == item.c_str() + eq + 1 || *tail != '\0' ||
+                gpry_ctx_set_option(ctx, item.substr(0, eq).c_str(), (int64_t)v) != 0) {
+                (void)gpry_ctx_destroy(ctx);
+                return gpry_fail(nullptr, -1, "GPRY_HIP_OPTIONS: bad entry '%s'", item.c_str());
+            }
+        }
+    }
     *out = ctx;
     return 0;
 }

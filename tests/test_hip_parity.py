@@ -843,3 +843,18 @@ def test_pipelined_factor_chain_is_bit_identical(dev, N):
         dev.set_option("factor_pipeline", 1)
         dev.set_option("factor_pipeline_min", 4096)
 
+
+
+def test_options_from_the_environment(monkeypatch):
+    """``GPRY_HIP_OPTIONS="key=value,..."`` reaches every new context (A/B runs of unmodified callers); a
+    malformed entry or an unknown key fails the creation loudly instead of being ignored."""
+    from gpry_amd import _lib
+    monkeypatch.setenv("GPRY_HIP_OPTIONS", "factor_pipeline=0,chol_overlap=1")
+    d = _lib.Device(0)
+    d.close()
+    for bad in ("factor_pipeline", "no_such_option=1", "chol_overlap=x", "=3"):
+        monkeypatch.setenv("GPRY_HIP_OPTIONS", bad)
+        with pytest.raises(_lib.GpryHipError, match="GPRY_HIP_OPTIONS"):
+            _lib.Device(0)
+    monkeypatch.delenv("GPRY_HIP_OPTIONS")
+    _lib.Device(0).close()
