@@ -122,7 +122,12 @@ def _one_case(case, rng, dev, worst):
                     np.max(np.abs(bkg[i] - kg1)) / max(1e-300, np.max(np.abs(kg1)), 1e-9))
             worst["batch_grad"] = max(worst["batch_grad"], e)
             Ldg = np.diag(m.L_)
-            if e > max(1e-6, 1e-13 * (Ldg.max() / Ldg.min()) ** 2):      # K^-1 k* in two summation orders: cond(K) eps
+            tol = max(1e-6, 1e-13 * (Ldg.max() / Ldg.min()) ** 2)         # K^-1 k* in two summation orders: cond(K) eps
+            if e > tol:
+                # the diagonal ratio underestimates cond(K) (low-dimensional RBF cases by orders of magnitude):
+                # settle it with the singular values of L before calling it a violation
+                tol = max(tol, 1e-13 * float(np.linalg.cond(np.tril(m.L_))) ** 2)
+            if e > tol:
                 print(f"case {case}: batched x-gradient differs from the one-point entry by {e:.2e} (N={N} d={d} kid={kid} mb={mb})"); bad += 1
         K = min(M, 40)
         top, bound = dev.sweep_topk(K)
