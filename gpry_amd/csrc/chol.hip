@@ -554,7 +554,8 @@ int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, doub
 // out[0] = sum_i log L_ii (i < n_real), out[1] = sum_i z_i^2   (single workgroup)
 __global__ __launch_bounds__(1024) void logdet_quad_kernel(const double* __restrict__ L, int64_t ld,
                                                            const double* __restrict__ z,
-                                                           int64_t n_real, double* __restrict__ out) {
+                                                           int64_t n_real, double* __restrict__ out,
+                                                           const int* __restrict__ info, double* __restrict__ info_out) {
     __shared__ double r0[1024], r1[1024];
     const int t = threadIdx.x;
     double a = 0.0, b = 0.0;
@@ -565,12 +566,21 @@ __global__ __launch_bounds__(1024) void logdet_quad_kernel(const double* __restr
         if (t < s) { r0[t] += r0[t + s]; r1[t] += r1[t + s]; }
         __syncthreads();
     }
-    if (t == 0) { out[0] = r0[0]; out[1] = r1[0]; }
+    if (t == 0) {
+        out[0] = r0[0]; out[1] = r1[0];
+        // last kernel of a value-only evaluation: the factorisation status travels with the results
+        if (info_out) {     // after the results (the host may be polling info_out[0] in mapped memory)
+            info_out[1] = (double)info[1];
+            __threadfence_system();
+            info_out[0] = (double)info[0];
+        }
+    }
 }
 
-int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np, double* out2_dev) {
+int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np, double* out2_dev, double* info_out) {
     (void)Np;
-    hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(1024), 0, ctx->stream, L, ctx->Np, z, ctx->N, out2_dev);
+    hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(1024), 0, ctx->stream, L, ctx->Np, z, ctx->N, out2_dev,
+                       ctx->dinfo, info_out);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

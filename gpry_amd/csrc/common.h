@@ -134,6 +134,7 @@ struct gpry_ctx {
 
     void* trtri_plan = nullptr;
     void* trtri_pipe = nullptr;   // state of a pipelined factor chain in flight (chol.hip)
+    int opt_host_poll = 1;        // small calls poll their results in the mapped staging buffer instead of waiting on the stream
     int opt_factor_pipeline = 1;  // 1: V = L^-1 phases run on stream2 underneath potrf
     int opt_factor_pipeline_min = 4096;   // from this Np on (neutral at 3072, a loss at 2048: tools/ab_factor_pipeline.py)
     void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
@@ -246,7 +247,7 @@ int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, 
 int launch_gradx_batch(gpry_ctx* ctx, const double* Xb, int64_t m, int raw_affine, const double* Wm, int64_t ldw,
                        double* out);
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
-                      double* grad_out_dev);
+                      double* grad_out_dev, double* info_out);   // info_out (nullable): dinfo[0..1] as doubles
 
 // ---- chol.hip ----------------------------------------------------------------------
 int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np);             // info -> ctx->dinfo (unfused v1)
@@ -262,7 +263,7 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np);
 int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha,
                 int64_t Np);
 int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np,
-                    double* out2_dev);
+                    double* out2_dev, double* info_out);         // info_out (nullable): dinfo[0..1] as doubles
 int rocsolver_potrf_trtri(gpry_ctx* ctx, double* A, double* V, int64_t Np, int want_v);
 
 int ensure_capacity(gpry_ctx* ctx, int64_t N, int d);
