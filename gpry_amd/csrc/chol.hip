@@ -242,17 +242,27 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
         pl.count.push_back((int)bt.size()); pl.maxM.push_back(mM); pl.maxN.push_back(mN);
         pl.aligned.push_back(al);
     }
-    // Phases: checkpoints at the split points of the top two tree levels (quarters of the matrix for a
-    // power-of-two block count).  Diagonal block b is ready once b + 1 blocks of L are final, the product
+    // Phases: checkpoints at 1/4, 1/2 and 3/4 of the blocks (see below).  Diagonal block b is ready once b + 1 blocks of L are final, the product
     // T = L21 V11 of a node once `mid` blocks are (columns lo..mid of L are final for ALL rows after their
     // panel step, and V11 is complete by then), its V21 = -V22 T once `hi` blocks are.
     const int nblk = (int)(Np / 64);
     if (nblk >= 8) {
         const TriNode root = nodes.back();
         std::vector<int> cps = {root.mid, nblk};
-        for (auto& nd : nodes) {
-            if (nd.lo == root.lo && nd.hi == root.mid) cps.push_back(nd.mid);
-            if (nd.lo == root.mid && nd.hi == root.hi) cps.push_back(nd.mid);
+        for (auto& nd : nodes)
+            if (nd.lo == root.lo && nd.hi == root.mid) cps.push_back(nd.mid);      // first quarter
+        // ... and the split points down the right spine of the tree while a node has at least `spine` blocks:
+        // by default only 3/4.  Going on to 7/8, 15/16, ... leaves less for after the last panel on paper, but the
+        // small phases are chains of 5-20 us launches that start one or two panel steps before the end and are
+        // not finished when potrf is (exposed V = L^-1 at N = 4096: 0.49 ms with 3/4, 0.55 with 7/8, 0.62 with
+        // 15/16, 0.68 down to the last block; tools/ab_factor_pipeline.py).
+        const int spine = ctx->opt_factor_pipeline_spine > 0 ? ctx->opt_factor_pipeline_spine : nblk / 2;
+        for (int lo = root.mid, hi = root.hi; hi - lo >= spine && hi - lo > 1;) {
+            int mid = -1;
+            for (auto& nd : nodes) if (nd.lo == lo && nd.hi == hi) mid = nd.mid;
+            if (mid < 0) break;
+            cps.push_back(mid);
+            lo = mid;
         }
         std::sort(cps.begin(), cps.end());
         cps.erase(std::unique(cps.begin(), cps.end()), cps.end());

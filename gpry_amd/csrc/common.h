@@ -135,6 +135,7 @@ struct gpry_ctx {
     void* trtri_plan = nullptr;
     void* trtri_pipe = nullptr;   // state of a pipelined factor chain in flight (chol.hip)
     int opt_host_poll = 1;        // small calls poll their results in the mapped staging buffer instead of waiting on the stream
+    int opt_factor_pipeline_spine = 0;    // > 0: checkpoints down the right spine of the tree while a node has >= this many blocks (0: half of all)
     int opt_factor_pipeline = 1;  // 1: V = L^-1 phases run on stream2 underneath potrf
     int opt_factor_pipeline_min = 4096;   // from this Np on (neutral at 3072, a loss at 2048: tools/ab_factor_pipeline.py)
     void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)   // cached batch descriptors of the V = L^-1 recursion (chol.hip)

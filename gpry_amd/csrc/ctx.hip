@@ -253,6 +253,10 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "trtri_diag_v1")) { ctx->opt_trtri_diag_v1 = (int)value; return 0; }
     if (!strcmp(key, "host_poll")) { ctx->opt_host_poll = (int)value; return 0; }
     if (!strcmp(key, "factor_pipeline")) { ctx->opt_factor_pipeline = (int)value; return 0; }
+    if (!strcmp(key, "factor_pipeline_spine")) {
+        if (value < 0) return gpry_fail(ctx, -1, "factor_pipeline_spine must be >= 0");
+        ctx->opt_factor_pipeline_spine = (int)value; trtri_plan_free(ctx); return 0;
+    }
     if (!strcmp(key, "factor_pipeline_min")) { ctx->opt_factor_pipeline_min = (int)value; return 0; }
     if (!strcmp(key, "lauum_lds")) { ctx->opt_lauum_lds = (int)value; return 0; }
     if (!strcmp(key, "syrk_lds")) { ctx->opt_syrk_lds = (int)value; return 0; }
