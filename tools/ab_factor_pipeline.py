@@ -15,7 +15,7 @@ for N, d in [(int(a), 8 if int(a) < 4096 else (16 if int(a) < 8192 else 20)) for
     theta = np.log(np.array([4.0] + [0.3] * d))
     dev.set_theta(3, theta)
     ref = None
-    for rep in range(1):
+    for rep in range(2):
         for pipe, spine in ((0, 0), (1, 0), (1, 16), (1, 8), (1, 2)):
             dev.set_option("factor_pipeline", pipe)
             dev.set_option("factor_pipeline_spine", spine)
