@@ -1,8 +1,6 @@
 // C-ABI entry points of the GP hot path (include/gpry_hip.h): factor, LML, predict,
 // fused NORA sweep, shortlist selection and Kriging-believer support.
 #include "common.h"
-#include <atomic>
-#include <chrono>
 #include <algorithm>
 
 static int require_model(gpry_ctx* ctx, bool need_factor) {
@@ -31,27 +29,6 @@ static int ensure_part(gpry_ctx* ctx, int64_t need) {
     GPRY_TRY(dev_alloc(ctx, &ctx->dpart, need));
     ctx->part_cap = need;
     return 0;
-}
-
-// Results that the device writes into the pinned, device-mapped staging buffer, every double exactly once: the
-// host marks them NaN before the launch and polls until none is left -- ~18 us less per call than
-// hipStreamSynchronize, which remains the fallback (option "host_poll" = 0, a time limit, or a result that IS
-// NaN).  Whatever is still queued on the stream behind the producing kernel is ordered by the stream.
-static void poll_mark(double* p, int64_t n) {
-    for (int64_t k = 0; k < n; k++) p[k] = NAN;
-}
-static bool poll_filled(gpry_ctx* ctx, const double* p, int64_t n, double limit_s) {
-    if (!ctx->opt_host_poll) return false;
-    volatile const double* v = p;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (long spin = 1;; spin++) {
-        int64_t k = n - 1;
-        for (; k >= 0; k--) if (v[k] != v[k]) break;
-        if (k < 0) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
-        __builtin_ia32_pause();
-        if ((spin & 1023) == 0 &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) return false;
-    }
 }
 
 // copy a device matrix with leading dimension ld to a dense host rows x cols array
@@ -218,19 +195,19 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     // middle (every kernel behind a failed factorisation either exits on *dinfo != 0 or works on
     // values nobody reads); status and results come back together at the end.
     // Results and factorisation status land in the pinned, device-mapped staging buffer: the last kernels
-    // of the evaluation write them there themselves (two copy-out operations and the gap between them
-    // were 20 us of a 200-us evaluation at small N).
+    // of the evaluation write them there themselves (no copy-out operations behind the evaluation).
     constexpr int RES_INFO = 2 + 1 + GPRY_MAX_DIM;      // [logdet/2, quad, grad (1 + d) ..., info0, info1]
     int rc = ensure_pinned(ctx, 4096);
     double* hres = static_cast<double*>(ctx->hpin);
-    double* dout = static_cast<double*>(ctx->hpin_dev);
+    double* dres = static_cast<double*>(ctx->hpin_dev);     // the same buffer as the device sees it
+    double* dout = ctx->dvec + 2 * ctx->Np;                 // device copy: [logdet/2, quad, grad...]
     if (rc == 0) { hres[RES_INFO] = -1.0; hres[RES_INFO + 1] = -1.0; }      // "not written" marker
     if (rc == 0) rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, nullptr);
     double* dz = ctx->dvec;                 // z = V y
     double* da = ctx->dvec + ctx->Np;       // alpha
     if (rc == 0) {
         rc = solve_alpha(ctx, ctx->dW2, ctx->dy, dz, da, ctx->Np);
-        if (rc == 0) rc = logdet_and_quad(ctx, ctx->dW, dz, ctx->Np, dout, want_grad ? nullptr : dout + RES_INFO);
+        if (rc == 0) rc = logdet_and_quad(ctx, ctx->dW, dz, ctx->Np, dout, want_grad ? nullptr : dres, RES_INFO);
         if (rc == 0 && want_grad) {
             {
                 StageScope s(ctx, "lauum");
@@ -238,7 +215,7 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
             }
             if (rc == 0) {
                 StageScope s(ctx, "lml_traces");
-                rc = launch_lml_traces(ctx, ctx->dW3, da, dout + 2, dout + RES_INFO);
+                rc = launch_lml_traces(ctx, ctx->dW3, da, dout + 2, dout, dres, RES_INFO);
             }
         }
     }
@@ -250,23 +227,11 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     double host[2 + 1 + GPRY_MAX_DIM];
     int hinfo[2] = {0, 0};
     if (rc == 0) {
-        // The status word is the LAST thing the evaluation writes (after a system-scope fence behind the results):
-        // polling it in the mapped buffer returns ~18 us earlier than hipStreamSynchronize (180 -> 162 us per
-        // LML+gradient call at N = 128; tools/latency_lml.py), the stream wait remains the fallback.  What is
-        // still queued behind it (the restore of the scaled coordinates) is ordered by the stream.
-        bool seen = false;
-        if (ctx->opt_host_poll) {
-            volatile double* vres = hres;
-            const auto t0 = std::chrono::steady_clock::now();
-            for (long spin = 1; !seen; spin++) {
-                seen = vres[RES_INFO] >= 0.0;
-                if (seen) break;
-                __builtin_ia32_pause();
-                if ((spin & 4095) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
-            }
-            std::atomic_thread_fence(std::memory_order_acquire);
-        }
-        hipError_t e = seen ? hipSuccess : hipStreamSynchronize(ctx->stream);
+        // (Polling the status word in the mapped buffer instead of waiting for the stream returns 15 us earlier and is
+        // WRONG: inbound PCIe writes to different cache lines are not ordered here -- the host saw the status before
+        // the last gradient entries in 2 % of the evaluations, tests/tools/stress_concurrent_fit.py; a loop over
+        // hipStreamQuery is correct and no faster than hipStreamSynchronize.)
+        hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = gpry_fail(ctx, -2, "lml: %s", hipGetErrorString(e));
         else if (hres[RES_INFO] < 0.0) rc = gpry_fail(ctx, -2, "lml: the evaluation did not deliver its status");
         else {
@@ -574,9 +539,8 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         char* hd = (char*)ctx->hpin_dev;           // the same buffer as the device sees it
         memcpy(h, X, sizeof(double) * M * ctx->d);
         double* hp = (double*)(h + xb);
-        poll_mark(hp, M * nsplit);
         GPRY_TRY(launch_predict_mean_small(ctx, (const double*)hd, M, nsplit, (double*)(hd + xb)));
-        if (!poll_filled(ctx, hp, M * nsplit, 0.05)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         for (int64_t m = 0; m < M; m++) {
             double mu_ = 0.0;
             for (int sidx = 0; sidx < nsplit; sidx++) mu_ += hp[m * nsplit + sidx];
@@ -604,10 +568,9 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         memcpy(h, X, sizeof(double) * M * ctx->d);
         double* hm = (double*)(h + xb);
         double* hs = hm + M * nmb;
-        poll_mark(hm, M * (nmb + nsb));
         GPRY_TRY(launch_predict_small_std(ctx, (const double*)hd, (int)M, ctx->dG, (double*)(hd + xb),
                                           (double*)(hd + xb) + M * nmb));
-        if (!poll_filled(ctx, hm, M * (nmb + nsb), 0.05)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const double C = exp(ctx->theta[0]);
         for (int64_t m = 0; m < M; m++) {
             double mu_ = 0.0, ss = 0.0;
@@ -641,14 +604,8 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         ctx->dXc = (double*)hd; ctx->dmask = (uint8_t*)(hd + xb);
         ctx->dy_all = (double*)(hd + xb + mb); ctx->dsig_all = (double*)(hd + xb + mb + ob);
         ctx->dacq_all = (double*)(hd + xb + mb + 2 * ob);
-        double* hy = (double*)(h + xb + mb);
-        double* hsd = (double*)(h + xb + mb + ob);
-        poll_mark(hy, M);
-        if (std) poll_mark(hsd, M);
         int rc = run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0, true);
-        hipError_t e = hipSuccess;
-        if (rc != 0 || !poll_filled(ctx, hy, M, 0.2) || (std && !poll_filled(ctx, hsd, M, 0.2)))
-            e = hipStreamSynchronize(ctx->stream);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
         ctx->dXc = sv.X; ctx->dmask = sv.m; ctx->dy_all = sv.y; ctx->dsig_all = sv.s; ctx->dacq_all = sv.a; ctx->sw_cap = sv.cap;
         ctx->sw_M = 0;                       // the staging buffer is not a resident candidate set
         if (rc) return rc;

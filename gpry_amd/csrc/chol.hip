@@ -171,6 +171,7 @@ struct TrtriPhaseLevel {
     int lev = 0;                            // index into the per-level arrays of the plan
     int64_t t_first = 0, v_first = 0;       // offsets into d_phase_items
     int n_t = 0, n_v = 0, mM_t = 0, mN_t = 0, mM_v = 0, mN_v = 0;
+    GemmPartsPlan sk_t, sk_v;               // stream-K plans of this subset (levels with seg_t > 0)
 };
 struct TrtriPhase {
     int blocks_done = 0, diag_lo = 0, diag_hi = 0;
@@ -183,14 +184,27 @@ struct TrtriPlan {
     std::vector<int> aligned;               // per level: every item is a multiple of 128 in M, N and K
     std::vector<TrtriPhase> phases;         // empty: too few blocks to cut
     GemmBatchItem* d_phase_items = nullptr;
+    // stream-K (gemm_dma.hip) for the aligned levels with blocks >= 512: segment length per level and product,
+    // taken from the WHOLE level so that a phase's subset is cut exactly like the full launch
+    std::vector<int> seg_t, seg_v;          // per level; 0: the level is launched tile by tile
+    std::vector<GemmPartsPlan> sk_t, sk_v;  // per level: the full launch
+    GemmPartsPlan sk_lauum;                 // K^-1 = V^T V
+    int seg_lauum = 0;
+    void release() {
+        for (auto p : d_t) if (p) (void)hipFree(p);
+        for (auto p : d_v) if (p) (void)hipFree(p);
+        if (d_phase_items) (void)hipFree(d_phase_items);
+        for (auto& q : sk_t) gemm_parts_plan_free(&q);
+        for (auto& q : sk_v) gemm_parts_plan_free(&q);
+        for (auto& ph : phases) for (auto& pv : ph.levels) { gemm_parts_plan_free(&pv.sk_t); gemm_parts_plan_free(&pv.sk_v); }
+        gemm_parts_plan_free(&sk_lauum);
+    }
 };
 // the plan lives in its context (ctx->trtri_plan): distinct contexts may be driven from distinct threads
 void trtri_plan_free(gpry_ctx* ctx) {
     TrtriPlan* pl = static_cast<TrtriPlan*>(ctx->trtri_plan);
     if (!pl) return;
-    for (auto p : pl->d_t) if (p) (void)hipFree(p);
-    for (auto p : pl->d_v) if (p) (void)hipFree(p);
-    if (pl->d_phase_items) (void)hipFree(pl->d_phase_items);
+    pl->release();
     delete pl;
     ctx->trtri_plan = nullptr;
 }
@@ -199,10 +213,10 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
     if (!ctx->trtri_plan) ctx->trtri_plan = new TrtriPlan();
     TrtriPlan& pl = *static_cast<TrtriPlan*>(ctx->trtri_plan);
     if (pl.Np == Np) { *out = &pl; return 0; }
-    for (auto p : pl.d_t) if (p) (void)hipFree(p);
-    for (auto p : pl.d_v) if (p) (void)hipFree(p);
-    if (pl.d_phase_items) (void)hipFree(pl.d_phase_items);
+    pl.release();
     pl = TrtriPlan();       // Np = 0: an incomplete plan is never taken for a finished one
+    int slots = 512;        // two GEMM workgroups per CU
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) slots = 2 * prop.multiProcessorCount; }
     std::vector<TriNode> nodes;
     int nlev = build_tree(0, (int)(Np / 64), nodes);
     for (int lev = 1; lev <= nlev; lev++) {
@@ -233,14 +247,32 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
         if (e != hipSuccess) {      // drop the partial plan: the next call starts over
             if (dt) (void)hipFree(dt);
             if (dv) (void)hipFree(dv);
-            for (auto p : pl.d_t) if (p) (void)hipFree(p);
-            for (auto p : pl.d_v) if (p) (void)hipFree(p);
+            pl.release();
             pl = TrtriPlan();
             return gpry_fail(ctx, -2, "trtri plan (Np = %lld): %s", (long long)Np, hipGetErrorString(e));
         }
         pl.d_t.push_back(dt); pl.d_v.push_back(dv);
         pl.count.push_back((int)bt.size()); pl.maxM.push_back(mM); pl.maxN.push_back(mN);
         pl.aligned.push_back(al);
+        // stream-K for the levels whose launches have few, long tiles
+        pl.seg_t.push_back(0); pl.seg_v.push_back(0);
+        pl.sk_t.emplace_back(); pl.sk_v.emplace_back();
+        if (al && mN >= 512) {
+            std::vector<GemmShape> st_, sv_;
+            for (auto& a : bt) st_.push_back({a.M, a.N, a.K});
+            for (auto& b : bv) sv_.push_back({b.M, b.N, b.K});
+            pl.seg_t.back() = gemm_parts_segment(KM_B_LOWER, 0, st_, slots);
+            pl.seg_v.back() = gemm_parts_segment(KM_A_LOWER, 0, sv_, slots);
+            int rc = gemm_parts_plan_build(ctx, KM_B_LOWER, 0, st_, pl.seg_t.back(), &pl.sk_t.back());
+            if (rc == 0) rc = gemm_parts_plan_build(ctx, KM_A_LOWER, 0, sv_, pl.seg_v.back(), &pl.sk_v.back());
+            if (rc) { pl.release(); pl = TrtriPlan(); return rc; }
+        }
+    }
+    {   // K^-1 = V^T V: lower tiles, k >= max(i, j) * 128
+        std::vector<GemmShape> sh = {{(int)Np, (int)Np, (int)Np}};
+        pl.seg_lauum = gemm_parts_segment(KM_AT_LOWER_B_LOWER, 1, sh, slots);
+        int rc = gemm_parts_plan_build(ctx, KM_AT_LOWER_B_LOWER, 1, sh, pl.seg_lauum, &pl.sk_lauum);
+        if (rc) { pl.release(); pl = TrtriPlan(); return rc; }
     }
     // Phases: checkpoints at 1/4, 1/2 and 3/4 of the blocks (see below).  Diagonal block b is ready once b + 1 blocks of L are final, the product
     // T = L21 V11 of a node once `mid` blocks are (columns lo..mid of L are final for ALL rows after their
@@ -297,6 +329,14 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
                     }
                 }
                 if (bt.empty() && bv.empty()) continue;
+                if (pl.seg_t[lev - 1] > 0) {
+                    std::vector<GemmShape> st_, sv_;
+                    for (auto& a : bt) st_.push_back({a.M, a.N, a.K});
+                    for (auto& b : bv) sv_.push_back({b.M, b.N, b.K});
+                    int rc = gemm_parts_plan_build(ctx, KM_B_LOWER, 0, st_, pl.seg_t[lev - 1], &pv.sk_t);
+                    if (rc == 0) rc = gemm_parts_plan_build(ctx, KM_A_LOWER, 0, sv_, pl.seg_v[lev - 1], &pv.sk_v);
+                    if (rc) { ph.levels.push_back(pv); pl.phases.push_back(ph); pl.release(); pl = TrtriPlan(); return rc; }
+                }
                 pv.n_t = (int)bt.size(); pv.n_v = (int)bv.size();
                 pv.t_first = (int64_t)all.size(); all.insert(all.end(), bt.begin(), bt.end());
                 pv.v_first = (int64_t)all.size(); all.insert(all.end(), bv.begin(), bv.end());
@@ -307,9 +347,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
         hipError_t e = hipMalloc(&pl.d_phase_items, all.size() * sizeof(GemmBatchItem));
         if (e == hipSuccess) e = hipMemcpy(pl.d_phase_items, all.data(), all.size() * sizeof(GemmBatchItem), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
-            for (auto p : pl.d_t) if (p) (void)hipFree(p);
-            for (auto p : pl.d_v) if (p) (void)hipFree(p);
-            if (pl.d_phase_items) (void)hipFree(pl.d_phase_items);
+            pl.release();
             pl = TrtriPlan();
             return gpry_fail(ctx, -2, "trtri plan (Np = %lld): %s", (long long)Np, hipGetErrorString(e));
         }
@@ -337,7 +375,23 @@ static int trtri_level_nsplit(gpry_ctx* ctx, const TrtriPlan* pl, size_t lev) {
 // one level's pair of batched products (all of the level, or the part of it that belongs to a phase)
 static int trtri_level_products(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np, int nsplit, int aligned,
                                 const GemmBatchItem* d_t, int n_t, int mM_t, int mN_t,
-                                const GemmBatchItem* d_v, int n_v, int mM_v, int mN_v, hipStream_t st) {
+                                const GemmBatchItem* d_v, int n_v, int mM_v, int mN_v, hipStream_t st,
+                                const GemmPartsPlan* sk_t = nullptr, const GemmPartsPlan* sk_v = nullptr) {
+    if (sk_t && sk_v && ctx->opt_gemm_streamk) {       // stream-K launches (gemm_dma.hip)
+        if (n_t > 0) {
+            GemmArgs g = {};
+            g.A = L; g.lda = Np; g.B = V; g.ldb = Np; g.C = T; g.ldc = Np;
+            g.kmode = KM_B_LOWER; g.batch = d_t; g.n_batch = n_t; g.info = ctx->dinfo; g.stream = st;
+            GPRY_TRY(gemm_dma_parts_launch(ctx, g, false, false, EPI_STORE, *sk_t, Np * Np));
+        }
+        if (n_v > 0) {
+            GemmArgs h = {};
+            h.A = V; h.lda = Np; h.B = T; h.ldb = Np; h.C = V; h.ldc = Np;
+            h.kmode = KM_A_LOWER; h.batch = d_v; h.n_batch = n_v; h.info = ctx->dinfo; h.stream = st;
+            GPRY_TRY(gemm_dma_parts_launch(ctx, h, false, false, EPI_STORE_NEG, *sk_v, Np * Np));
+        }
+        return 0;
+    }
     double* sbuf = nullptr;
     if (nsplit > 1) GPRY_TRY(gemm_split_scratch(ctx, nsplit, Np * Np, &sbuf));
     if (n_t > 0) {
@@ -382,7 +436,8 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
     for (size_t lev = 0; lev < pl->count.size(); lev++)
         GPRY_TRY(trtri_level_products(ctx, L, V, T, Np, trtri_level_nsplit(ctx, pl, lev), pl->aligned[lev],
                                       pl->d_t[lev], pl->count[lev], pl->maxM[lev], pl->maxN[lev],
-                                      pl->d_v[lev], pl->count[lev], pl->maxM[lev], pl->maxN[lev], st));
+                                      pl->d_v[lev], pl->count[lev], pl->maxM[lev], pl->maxN[lev], st,
+                                      pl->seg_t[lev] > 0 ? &pl->sk_t[lev] : nullptr, pl->seg_t[lev] > 0 ? &pl->sk_v[lev] : nullptr));
     return 0;
 }
 
@@ -420,7 +475,8 @@ static int trtri_phase_run(gpry_ctx* ctx, TrtriPipe* pp, size_t p, hipStream_t s
     for (const TrtriPhaseLevel& pv : ph.levels)
         GPRY_TRY(trtri_level_products(ctx, pp->L, pp->V, pp->T, pp->Np, trtri_level_nsplit(ctx, pl, (size_t)pv.lev),
                                       pl->aligned[pv.lev], pl->d_phase_items + pv.t_first, pv.n_t, pv.mM_t, pv.mN_t,
-                                      pl->d_phase_items + pv.v_first, pv.n_v, pv.mM_v, pv.mN_v, st));
+                                      pl->d_phase_items + pv.v_first, pv.n_v, pv.mM_v, pv.mN_v, st,
+                                      pl->seg_t[pv.lev] > 0 ? &pv.sk_t : nullptr, pl->seg_t[pv.lev] > 0 ? &pv.sk_v : nullptr));
     return 0;
 }
 // returns 1 when the chain is not cut for this size (the caller runs trtri_lower after potrf)
@@ -441,6 +497,14 @@ int trtri_pipeline_begin(gpry_ctx* ctx, const double* L, double* V, double* T, i
     for (size_t lev = 0; lev < pl->count.size(); lev++) {
         const int ns = trtri_level_nsplit(ctx, pl, lev);
         if (ns > maxsplit) maxsplit = ns;
+    }
+    if (ctx->opt_gemm_streamk) {
+        for (auto& q : pl->sk_t) if (q.max_slices > maxsplit) maxsplit = q.max_slices;
+        for (auto& q : pl->sk_v) if (q.max_slices > maxsplit) maxsplit = q.max_slices;
+        for (auto& ph : pl->phases) for (auto& pv : ph.levels) {
+            if (pv.sk_t.max_slices > maxsplit) maxsplit = pv.sk_t.max_slices;
+            if (pv.sk_v.max_slices > maxsplit) maxsplit = pv.sk_v.max_slices;
+        }
     }
     double* sbuf = nullptr;
     if (maxsplit > 1) GPRY_TRY(gemm_split_scratch(ctx, maxsplit, Np * Np, &sbuf));
@@ -481,6 +545,15 @@ int trtri_pipeline_finish(gpry_ctx* ctx) {
 
 // K^-1 = V^T V, lower triangle only (the traces kernel reads Kinv[max(i,j)][min(i,j)]).
 int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
+    if (ctx->opt_gemm_streamk && Np >= 512) {      // stream-K (gemm_dma.hip): the plan lives with the V = L^-1 plan
+        TrtriPlan* pl = nullptr;
+        GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
+        GemmArgs g = {};
+        g.A = V; g.lda = Np; g.B = V; g.ldb = Np; g.C = Kinv; g.ldc = Np;
+        g.M = (int)Np; g.N = (int)Np; g.K = (int)Np;
+        g.kmode = KM_AT_LOWER_B_LOWER; g.lower_only = 1; g.info = ctx->dinfo;
+        return gemm_dma_parts_launch(ctx, g, true, false, EPI_STORE, pl->sk_lauum, Np * Np);
+    }
     GemmArgs g = {};
     g.A = V; g.lda = Np; g.B = V; g.ldb = Np; g.C = Kinv; g.ldc = Np;
     g.M = (int)Np; g.N = (int)Np; g.K = (int)Np;
@@ -565,7 +638,8 @@ int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, doub
 __global__ __launch_bounds__(1024) void logdet_quad_kernel(const double* __restrict__ L, int64_t ld,
                                                            const double* __restrict__ z,
                                                            int64_t n_real, double* __restrict__ out,
-                                                           const int* __restrict__ info, double* __restrict__ info_out) {
+                                                           const int* __restrict__ info, double* __restrict__ host_res,
+                                                           int info_at) {
     __shared__ double r0[1024], r1[1024];
     const int t = threadIdx.x;
     double a = 0.0, b = 0.0;
@@ -578,19 +652,20 @@ __global__ __launch_bounds__(1024) void logdet_quad_kernel(const double* __restr
     }
     if (t == 0) {
         out[0] = r0[0]; out[1] = r1[0];
-        // last kernel of a value-only evaluation: the factorisation status travels with the results
-        if (info_out) {     // after the results (the host may be polling info_out[0] in mapped memory)
-            info_out[1] = (double)info[1];
-            __threadfence_system();
-            info_out[0] = (double)info[0];
+        // last kernel of a value-only evaluation: results and factorisation status also go straight into the mapped
+        // host buffer (read by the host after the stream wait)
+        if (host_res) {
+            host_res[0] = r0[0]; host_res[1] = r1[0];
+            host_res[info_at] = (double)info[0]; host_res[info_at + 1] = (double)info[1];
         }
     }
 }
 
-int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np, double* out2_dev, double* info_out) {
+int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np, double* out2_dev, double* host_res,
+                    int info_at) {
     (void)Np;
     hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(1024), 0, ctx->stream, L, ctx->Np, z, ctx->N, out2_dev,
-                       ctx->dinfo, info_out);
+                       ctx->dinfo, host_res, info_at);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

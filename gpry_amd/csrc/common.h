@@ -134,8 +134,8 @@ struct gpry_ctx {
 
     void* trtri_plan = nullptr;
     void* trtri_pipe = nullptr;   // state of a pipelined factor chain in flight (chol.hip)
-    int opt_host_poll = 1;        // small calls poll their results in the mapped staging buffer instead of waiting on the stream
     int opt_factor_pipeline_spine = 0;    // > 0: checkpoints down the right spine of the tree while a node has >= this many blocks (0: half of all)
+    int opt_gemm_streamk = 1;     // V = L^-1 levels >= 512 and K^-1 = V^T V as stream-K launches (gemm_dma.hip)
     int opt_factor_pipeline = 1;  // 1: V = L^-1 phases run on stream2 underneath potrf
     int opt_factor_pipeline_min = 4096;   // from this Np on (neutral at 3072, a loss at 2048: tools/ab_factor_pipeline.py)
     void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
@@ -217,6 +217,23 @@ struct GemmArgs {
     int dma_ok;            // batched launches: 1 = every item meets gemm_dma_usable (checked by the caller)
     int skip_reduce;       // split-K: leave the slices in split_buf (the caller reduces them itself)
 };
+// ---- stream-K launches of the DMA engine (gemm_dma.hip): the (tile, k) space of a launch is cut into segments of
+// equal length, one workgroup per segment; a segment is a list of parts (tile, share of the tile's k-range).
+struct GemmPart { int bz, ti, tj, lo, hi, slice; };     // lo / hi: slab pairs (32 k) within the tile's own k-range
+struct GemmRedTile { int bz, ti, tj, nslice; };         // tiles whose product arrives in nslice >= 2 partial slices
+struct GemmPartsPlan {
+    GemmPart* d_parts = nullptr; int* d_first = nullptr; GemmRedTile* d_red = nullptr;
+    int nwg = 0, nred = 0, max_slices = 0;
+};
+struct GemmShape { int M, N, K; };
+// segment length (slab pairs) that gives `slots` segments over all tiles of the shapes
+int gemm_parts_segment(int kmode, int lower_only, const std::vector<GemmShape>& shapes, int slots);
+// plan for one launch (items = batch items in order; a non-batched launch has one); frees nothing on failure
+int gemm_parts_plan_build(gpry_ctx* ctx, int kmode, int lower_only, const std::vector<GemmShape>& items, int seg_pairs,
+                          GemmPartsPlan* out);
+void gemm_parts_plan_free(GemmPartsPlan* pl);
+int gemm_dma_parts_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi, const GemmPartsPlan& pl,
+                          int64_t slice_stride);
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
 int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
@@ -248,7 +265,8 @@ int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, 
 int launch_gradx_batch(gpry_ctx* ctx, const double* Xb, int64_t m, int raw_affine, const double* Wm, int64_t ldw,
                        double* out);
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
-                      double* grad_out_dev, double* info_out);   // info_out (nullable): dinfo[0..1] as doubles
+                      double* grad_out_dev, const double* lq_dev, double* host_res, int info_at);
+// host_res (nullable, mapped host memory): [logdet/2, quad, grad...] and dinfo[0..1] as doubles at info_at, status last
 
 // ---- chol.hip ----------------------------------------------------------------------
 int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np);             // info -> ctx->dinfo (unfused v1)
@@ -264,7 +282,7 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np);
 int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha,
                 int64_t Np);
 int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np,
-                    double* out2_dev, double* info_out);         // info_out (nullable): dinfo[0..1] as doubles
+                    double* out2_dev, double* host_res, int info_at);   // host_res: as above, value-only evaluation
 int rocsolver_potrf_trtri(gpry_ctx* ctx, double* A, double* V, int64_t Np, int want_v);
 
 int ensure_capacity(gpry_ctx* ctx, int64_t N, int d);

@@ -75,8 +75,13 @@ __device__ __forceinline__ void gd_mma_row(v4d (&acc)[4][4], const GdFrag& f, in
 // One output tile (or split-K share of it) of the product; `smem` = 2 x (A image + B image) doubles of LDS,
 // bx / by / bz = the block coordinates the tile map, the split-K share and the batch item are taken from
 // (the kernel passes its own block index; the fused Cholesky step of chol_panel.hip passes a tile number).
+// `part` (nullable): stream-K launch (gemm_dma_parts_kernel) -- the tile, the share of its k-range (in slab pairs,
+// relative to the tile's own range) and the slice of g.split_buf the partial product goes to (slice < 0: the whole
+// range, final epilogue straight into C) come from the part instead of from the block coordinates.
 template <bool AT, bool BT, int EPI>
-__device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* smem, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* smem, const int bx, const int by, const int bz_,
+                                                   const GemmPart* part = nullptr) {
+    const int bz = part ? part->bz : bz_;
     constexpr bool AKC = !AT, BKC = BT;
     constexpr int A_SZ = AKC ? KC_DOUBLES : MC_DOUBLES, B_SZ = BKC ? KC_DOUBLES : MC_DOUBLES;
     constexpr int BUF_SZ = A_SZ + B_SZ;
@@ -91,7 +96,8 @@ __device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* sm
     }
     const int tiles_m = M / BM, tiles_n = N / BN;
     int ti, tj;
-    {
+    if (part) { ti = part->ti; tj = part->tj; }
+    else {
         const int b = bx;
         if ((g.tile_map & 15) == TM_SWEEP) {
             const int a = (g.tile_map >> 4) & 15, c = 6 - a;
@@ -135,7 +141,13 @@ __device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* sm
     else if (g.kmode == KM_AT_LOWER_B_LOWER) kbeg = min(K, max(row0, col0));
     else if (g.kmode == KM_B_UPPER) kend = min(K, col0 + BN);
     else if (g.kmode == KM_AT_LOWER) kbeg = min(K, row0);
-    if (g.nsplit > 1) {      // split-K over grid.y, in units of slab pairs
+    bool partial = g.nsplit > 1;
+    if (part) {
+        kend = kbeg + part->hi * 2 * BK;
+        kbeg = kbeg + part->lo * 2 * BK;
+        partial = part->slice >= 0;
+        if (partial) C = g.split_buf + (int64_t)part->slice * g.split_stride + (C - g.C);
+    } else if (g.nsplit > 1) {      // split-K over grid.y, in units of slab pairs
         const int all = (kend - kbeg) / (2 * BK);
         const int per = (all + g.nsplit - 1) / g.nsplit;
         const int lo = min(all, by * per), hi = min(all, lo + per);
@@ -260,7 +272,7 @@ __device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* sm
 #pragma unroll
     for (int mh = 0; mh < 4; mh += 2) {
         double old[2][4][4];
-        if (EPI == EPI_SUB && g.nsplit <= 1) {
+        if (EPI == EPI_SUB && !partial) {
 #pragma unroll
             for (int m2 = 0; m2 < 2; m2++)
 #pragma unroll
@@ -277,7 +289,7 @@ __device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* sm
                 for (int q = 0; q < 4; q++) {
                     double* p = cbase + (int64_t)((mh + m2) * 16 + 4 * q) * g.ldc + ni * 16;
                     const double v = acc[mh + m2][ni][q];
-                    if (EPI == EPI_STORE || g.nsplit > 1) *p = v;
+                    if (EPI == EPI_STORE || partial) *p = v;
                     else if (EPI == EPI_STORE_NEG) *p = -v;
                     else *p = old[m2][ni][q] - v;
                 }

@@ -578,8 +578,8 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
 // one workgroup per hyperparameter: strided partial sums then a fixed LDS tree
 __global__ __launch_bounds__(256) void reduce_traces_kernel(const double* __restrict__ part, int64_t ntile,
                                                             int stride, double* __restrict__ out,
-                                                            const int* __restrict__ info, double* __restrict__ info_out,
-                                                            int* __restrict__ done) {
+                                                            const int* __restrict__ info, const double* __restrict__ lq,
+                                                            double* __restrict__ host_res, int info_at) {
     __shared__ double red[256];
     const int k = blockIdx.x, t = threadIdx.x;
     double s = 0.0;
@@ -592,23 +592,20 @@ __global__ __launch_bounds__(256) void reduce_traces_kernel(const double* __rest
     }
     if (t == 0) {
         out[k] = 0.5 * red[0];
-        // Last kernel of an evaluation with gradient: the factorisation status travels with the results, written by
-        // the workgroup that finishes LAST (the host may be polling the status word in mapped memory: it must not
-        // become visible before every gradient entry is).
-        if (info_out) {
-            __threadfence_system();
-            const int prev = atomicAdd(done, 1);
-            if (prev == (int)gridDim.x - 1) {
-                *done = 0;
-                info_out[1] = (double)info[1];
-                __threadfence_system();
-                info_out[0] = (double)info[0];
+        // last kernel of an evaluation with gradient: results and factorisation status also go straight into the
+        // mapped host buffer (read by the host after the stream wait: no copy-out operations)
+        if (host_res) {
+            host_res[2 + k] = 0.5 * red[0];
+            if (k == 0) {
+                host_res[0] = lq[0]; host_res[1] = lq[1];
+                host_res[info_at] = (double)info[0]; host_res[info_at + 1] = (double)info[1];
             }
         }
     }
 }
 
-int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, double* grad_out_dev, double* info_out) {
+int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, double* grad_out_dev, const double* lq_dev,
+                      double* host_res, int info_at) {
     KernParams kp = make_kp(ctx);
     int64_t nb = ctx->Np / 64;
     int64_t ntile = nb * (nb + 1) / 2;
@@ -629,7 +626,7 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, do
 #undef LT2
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(reduce_traces_kernel, dim3((unsigned)(ctx->d + 1)), dim3(256), 0, ctx->stream,
-                       ctx->dpart, ntile, DPsel + 1, grad_out_dev, ctx->dinfo, info_out, ctx->dinfo + 8);
+                       ctx->dpart, ntile, DPsel + 1, grad_out_dev, ctx->dinfo, lq_dev, host_res, info_at);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -80,8 +80,6 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *              "chol_overlap" = 0/1 trailing-update tiles ride in the Cholesky panel launches (default 1, Np <= 7168)
  *              "factor_pipeline" = 0/1 V = L^-1 is queued phase by phase on a second stream underneath the
  *                                  Cholesky panel chain (default 1, from "factor_pipeline_min" = 4096 on; bit-identical)
- *              "host_poll" = 0/1 small calls (gpry_lml, gpry_predict up to 4096 points) poll their results in the
- *                            pinned, device-mapped staging buffer instead of waiting on the stream (default 1)
  * Everything else is an A/B switch of the measurements quoted in DESIGN.md (defaults are the
  * measured best): "sweep_dma" 0..3, "sweep_persist", "sweep_overlap", "sweep_tilemap", "sweep_colouter", "chol_outer",
  * "chol_lookahead", "chol_overlap_max", "chol_caps", "split_k", "gemm_dma", "syrk_lds", "lauum_lds", "lauum_split",

@@ -16,9 +16,9 @@ for N, d in [(int(a), 8 if int(a) < 4096 else (16 if int(a) < 8192 else 20)) for
     dev.set_theta(3, theta)
     ref = None
     for rep in range(2):
-        for pipe, spine in ((0, 0), (1, 0), (1, 16), (1, 8), (1, 2)):
+        for pipe, spine in ((0, 0), (1, 0), (0, -1), (1, -1)):
             dev.set_option("factor_pipeline", pipe)
-            dev.set_option("factor_pipeline_spine", spine)
+            dev.set_option("gemm_streamk", 1 if spine < 0 else 0)
             for _ in range(3):
                 assert dev.factorize() == 0
                 dev.lml(theta, True)
@@ -38,8 +38,8 @@ for N, d in [(int(a), 8 if int(a) < 4096 else (16 if int(a) < 8192 else 20)) for
             V = dev.get_factor(want_alpha=False)[1]
             if ref is None:
                 ref = V
-            print(f"N={N:5d} factor_pipeline={pipe} spine>={spine:4d}: factorize {tf:7.3f} ms  lml+grad {tl:7.3f} ms   stage timers us: "
-                  f"potrf {t['potrf']:8.1f} trtri {t['trtri']:7.1f} lauum {t['lauum']:7.1f}   V bit-identical: {np.array_equal(V, ref)}", flush=True)
+            print(f"N={N:5d} factor_pipeline={pipe} stream-K {int(spine < 0)}: factorize {tf:7.3f} ms  lml+grad {tl:7.3f} ms   stage timers us: "
+                  f"potrf {t['potrf']:8.1f} trtri {t['trtri']:7.1f} lauum {t['lauum']:7.1f}   V bit-identical to the first: {np.array_equal(V, ref)}  max |dV| {np.max(np.abs(V - ref)):.1e}", flush=True)
 dev.set_option("factor_pipeline", 1)
 dev.set_option("factor_pipeline_min", 4096)
-dev.set_option("factor_pipeline_spine", 0)
+dev.set_option("gemm_streamk", 1)
