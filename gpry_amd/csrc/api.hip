@@ -1179,7 +1179,17 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
         GPRY_TRY(gemm_split_scratch(ctx, nsplit, (int64_t)crow * N, &g.split_buf));
         g.nsplit = nsplit; g.split_stride = (int64_t)crow * N;
     }
-    {
+    const int seg = (tile_map >> 16) & 0xfff;     // test hook: bits 16..27 = stream-K segment length in slab pairs
+    if (seg > 0) {
+        if (M % 128 || N % 128 || K % 32) return gpry_fail(ctx, -1, "debug_gemm: stream-K needs M, N multiples of 128, K of 32");
+        GemmPartsPlan pl;
+        std::vector<GemmShape> sh = {{M, N, K}};
+        GPRY_TRY(gemm_parts_plan_build(ctx, kmode, lower_only, sh, seg, &pl));
+        int rc = gemm_dma_parts_launch(ctx, g, a_trans != 0, b_trans != 0, epi, pl, (int64_t)crow * N);
+        if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = gpry_fail(ctx, -2, "debug_gemm: stream-K launch failed");
+        gemm_parts_plan_free(&pl);
+        if (rc) return rc;
+    } else {
         StageScope s(ctx, "debug_gemm");
         GPRY_TRY(gemm_f64_launch(ctx, g, a_trans != 0, b_trans != 0, epi));
     }

@@ -545,7 +545,11 @@ int trtri_pipeline_finish(gpry_ctx* ctx) {
 
 // K^-1 = V^T V, lower triangle only (the traces kernel reads Kinv[max(i,j)][min(i,j)]).
 int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
-    if (ctx->opt_gemm_streamk && Np >= 512) {      // stream-K (gemm_dma.hip): the plan lives with the V = L^-1 plan
+    // Stream-K (gemm_dma.hip) while the launch has few tiles per workgroup slot: 509 -> 430 us at Np = 4096 (528
+    // tiles), but 1243 -> 1300 us at 6144 (1176 tiles) and 2830 -> 3000 us at 8192 (2080), where one workgroup per
+    // tile already fills the GPU for several rounds and the longest-first tile order keeps the tail short
+    // (tools/ab_factor_pipeline.py).  The plan lives with the V = L^-1 plan.
+    if (ctx->opt_gemm_streamk && Np >= 512 && (Np / 128) * (Np / 128 + 1) / 2 <= 1024) {
         TrtriPlan* pl = nullptr;
         GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
         GemmArgs g = {};

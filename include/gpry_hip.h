@@ -290,7 +290,8 @@ int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* value);
  * C(MxN) op= A(MxK) B(KxN); a_trans: A given as K x M; b_trans: B given as N x K;
  * epi 0 store, 1 store -AB, 2 C -= AB, 3 per-128-row-tile column sums of squares
  * (C is then ceil(M/128) x N); kmode 0 full (see csrc/common.h for the others).
- * M, N, K must be multiples of 64. */
+ * M, N, K must be multiples of 64.  tile_map: bits 0..7 the tile map, bits 8..11 a uniform split-K factor,
+ * bits 16..27 > 0: a stream-K launch with segments of that many slab pairs (32 k; M, N multiples of 128). */
 int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, double* C, int M, int N,
                     int K, int a_trans, int b_trans, int epi, int kmode, int lower_only,
                     int tile_map);

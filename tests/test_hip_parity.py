@@ -858,3 +858,28 @@ def test_options_from_the_environment(monkeypatch):
             _lib.Device(0)
     monkeypatch.delenv("GPRY_HIP_OPTIONS")
     _lib.Device(0).close()
+
+
+@pytest.mark.parametrize("seg", [1, 3, 7, 20, 1000])
+def test_stream_k_gemm_matches_numpy(dev, seg):
+    """Stream-K launches of the DMA engine (V = L^-1 levels and K^-1 = V^T V): the (tile, k) space cut into
+    segments of `seg` slab pairs -- parts that start and end inside tiles, whole tiles, tiles in one part -- in the
+    three layouts and triangular modes the factor chain uses, both store epilogues."""
+    rng = np.random.default_rng(40 + seg)
+    n = 640
+    L = np.tril(rng.standard_normal((n, n)))
+    G = rng.standard_normal((n, n))
+    hook = seg << 16
+    # T = L21 V11: B lower (k >= tj * 128);  V21 = -V22 T: A lower (k < (ti + 1) * 128), negated store
+    assert relmax(dev.debug_gemm(G, L, None, n, n, n, kmode=2, tile_map=hook), G @ L) < 1e-14
+    assert relmax(dev.debug_gemm(L, G, None, n, n, n, kmode=1, epi=1, tile_map=hook), -(L @ G)) < 1e-14
+    # K^-1 = V^T V, lower tiles only
+    C0 = rng.standard_normal((n, n))
+    got = dev.debug_gemm(L, L, C0, n, n, n, a_trans=1, kmode=3, lower_only=True, tile_map=hook)
+    assert relmax(np.tril(got), np.tril(L.T @ L)) < 1e-14
+    np.testing.assert_array_equal(got[:128, 128:], C0[:128, 128:])        # upper tiles are not touched
+    # rectangular, full k-range, NT layout
+    A = rng.standard_normal((256, 384))
+    B = rng.standard_normal((384, 512))
+    assert relmax(dev.debug_gemm(A, np.ascontiguousarray(B.T), None, 256, 512, 384, b_trans=1, tile_map=hook), A @ B) < 1e-14
+
