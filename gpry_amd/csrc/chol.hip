@@ -377,7 +377,7 @@ static int trtri_level_products(gpry_ctx* ctx, const double* L, double* V, doubl
                                 const GemmBatchItem* d_t, int n_t, int mM_t, int mN_t,
                                 const GemmBatchItem* d_v, int n_v, int mM_v, int mN_v, hipStream_t st,
                                 const GemmPartsPlan* sk_t = nullptr, const GemmPartsPlan* sk_v = nullptr) {
-    if (sk_t && sk_v && ctx->opt_gemm_streamk) {       // stream-K launches (gemm_dma.hip)
+    if (sk_t && sk_v && Np <= ctx->opt_gemm_streamk) {       // stream-K launches (gemm_dma.hip)
         if (n_t > 0) {
             GemmArgs g = {};
             g.A = L; g.lda = Np; g.B = V; g.ldb = Np; g.C = T; g.ldc = Np;
@@ -498,7 +498,7 @@ int trtri_pipeline_begin(gpry_ctx* ctx, const double* L, double* V, double* T, i
         const int ns = trtri_level_nsplit(ctx, pl, lev);
         if (ns > maxsplit) maxsplit = ns;
     }
-    if (ctx->opt_gemm_streamk) {
+    if (Np <= ctx->opt_gemm_streamk) {
         for (auto& q : pl->sk_t) if (q.max_slices > maxsplit) maxsplit = q.max_slices;
         for (auto& q : pl->sk_v) if (q.max_slices > maxsplit) maxsplit = q.max_slices;
         for (auto& ph : pl->phases) for (auto& pv : ph.levels) {
@@ -545,11 +545,12 @@ int trtri_pipeline_finish(gpry_ctx* ctx) {
 
 // K^-1 = V^T V, lower triangle only (the traces kernel reads Kinv[max(i,j)][min(i,j)]).
 int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
-    // Stream-K (gemm_dma.hip) while the launch has few tiles per workgroup slot: 509 -> 430 us at Np = 4096 (528
-    // tiles), but 1243 -> 1300 us at 6144 (1176 tiles) and 2830 -> 3000 us at 8192 (2080), where one workgroup per
-    // tile already fills the GPU for several rounds and the longest-first tile order keeps the tail short
-    // (tools/ab_factor_pipeline.py).  The plan lives with the V = L^-1 plan.
-    if (ctx->opt_gemm_streamk && Np >= 512 && (Np / 128) * (Np / 128 + 1) / 2 <= 1024) {
+    // Stream-K (gemm_dma.hip) up to Np = gemm_streamk (default 5632), i.e. while the launch has few tiles per
+    // workgroup slot: 509 -> 430 us at Np = 4096 (528 tiles), 871 -> 793 at 5120, but 1243 -> 1300 us at 6144 (1176
+    // tiles) and 2830 -> 3000 us at 8192 (2080), where one workgroup per tile already fills the GPU for several
+    // rounds and the longest-first tile order keeps the tail short (tools/ab_factor_pipeline.py; giving every XCD a
+    // contiguous run of segments instead of every eighth changes nothing).  The plan lives with the V = L^-1 plan.
+    if (Np >= 512 && Np <= ctx->opt_gemm_streamk) {
         TrtriPlan* pl = nullptr;
         GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
         GemmArgs g = {};

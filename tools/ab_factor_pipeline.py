@@ -18,7 +18,7 @@ for N, d in [(int(a), 8 if int(a) < 4096 else (16 if int(a) < 8192 else 20)) for
     for rep in range(2):
         for pipe, spine in ((0, 0), (1, 0), (0, -1), (1, -1)):
             dev.set_option("factor_pipeline", pipe)
-            dev.set_option("gemm_streamk", 1 if spine < 0 else 0)
+            dev.set_option("gemm_streamk", 1 << 20 if spine < 0 else 0)
             for _ in range(3):
                 assert dev.factorize() == 0
                 dev.lml(theta, True)
@@ -42,4 +42,4 @@ for N, d in [(int(a), 8 if int(a) < 4096 else (16 if int(a) < 8192 else 20)) for
                   f"potrf {t['potrf']:8.1f} trtri {t['trtri']:7.1f} lauum {t['lauum']:7.1f}   V bit-identical to the first: {np.array_equal(V, ref)}  max |dV| {np.max(np.abs(V - ref)):.1e}", flush=True)
 dev.set_option("factor_pipeline", 1)
 dev.set_option("factor_pipeline_min", 4096)
-dev.set_option("gemm_streamk", 1)
+dev.set_option("gemm_streamk", 5632)
