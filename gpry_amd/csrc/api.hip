@@ -1120,6 +1120,18 @@ int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, 
     g.C = ctx->dU + ctx->kb_n * Np; g.ldc = Np;
     g.M = (int)mp; g.N = (int)Np; g.K = (int)Np;
     g.kmode = KM_B_UPPER; g.lower_only = 0; g.tile_map = TM_ROWMAJOR;
+    {   // a shortlist is a few hundred points: 2 x Np/128 tiles, the longest walks all Np/16 slabs alone (0.8 ms
+        // at Np = 4096): split the k-ranges so that the launch fills the GPU (as gpry_predict does, section 4.5)
+        // The factor depends on Np ONLY: the conditioned variances must not depend on how many points were
+        // registered together (a sharded pool merges a different number of shortlist points than one context
+        // selects, and the proposals are compared bit for bit, tests/test_group_gpu.py).
+        int ns = 1;
+        while (ns < 8 && Np / (ns * 2) >= 256) ns *= 2;
+        if (ns > 1) {
+            GPRY_TRY(gemm_split_scratch(ctx, ns, mp * Np, &g.split_buf));
+            g.nsplit = ns; g.split_stride = mp * Np;
+        }
+    }
     GPRY_TRY(gemm_f64_launch(ctx, g, true, true, EPI_STORE));
     if (var0) {
         hipLaunchKernelGGL(kb_var0_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, ctx->dU, Np, ctx->kb_n, m,
