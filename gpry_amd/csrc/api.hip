@@ -1151,13 +1151,17 @@ int gpry_kb_gram(gpry_ctx* ctx, int64_t p, double* G, double* kvec, int64_t* n) 
     if (p < 0 || p >= ctx->kb_n) return gpry_fail(ctx, -1, "kb_gram: index %lld out of range [0, %lld)", (long long)p, (long long)ctx->kb_n);
     hipStream_t st = ctx->stream;
     int64_t nn = ctx->kb_n;
+    // the two result vectors go straight into the pinned, device-mapped staging buffer (no copy-out operations:
+    // the ranking calls this once per accepted point, 15 times per cycle)
+    GPRY_TRY(ensure_pinned(ctx, (int64_t)sizeof(double) * 2 * nn));
+    double* hres = static_cast<double*>(ctx->hpin);
+    double* dres = static_cast<double*>(ctx->hpin_dev);
     hipLaunchKernelGGL(kb_gram_kernel, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, st, ctx->dU, ctx->Np, nn, p,
-                       ctx->Np, ctx->dXkb, ctx->dpad, ctx->kernel_id, exp(ctx->theta[0]), ctx->dkbout,
-                       ctx->dkbout + ctx->kb_cap);
+                       ctx->Np, ctx->dXkb, ctx->dpad, ctx->kernel_id, exp(ctx->theta[0]), dres, dres + nn);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(G, ctx->dkbout, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(kvec, ctx->dkbout + ctx->kb_cap, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(G, hres, sizeof(double) * nn);
+    memcpy(kvec, hres + nn, sizeof(double) * nn);
     if (n) *n = nn;
     return 0;
 }
