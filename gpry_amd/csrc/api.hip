@@ -917,6 +917,16 @@ __global__ void select_emit_kernel(const unsigned long long* __restrict__ keys, 
     if ((threadIdx.x & 63) == 0 && best_below) atomicMax(&counters[1], best_below);
 }
 
+// all sweep results as shortlist records (small pools: selected on the host)
+__global__ void cand_records_kernel(const double* __restrict__ acq, const double* __restrict__ y, const double* __restrict__ sig,
+                                    int64_t M, gpry_cand* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    gpry_cand c;
+    c.acq = acq[i]; c.y = y[i]; c.sigma = sig ? sig[i] : 0.0; c.idx = i;
+    out[i] = c;
+}
+
 static double key_to_acq(unsigned long long k) {
     unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
     double a; memcpy(&a, &b, 8); return a;
@@ -933,6 +943,49 @@ extern "C" int gpry_sweep_topk(gpry_ctx* ctx, int64_t Kp, const int64_t* exclude
     if (M > 0xFFFFFFFFll) return gpry_fail(ctx, -1, "topk: M too large");
     StageScope scope(ctx, "topk");
     hipStream_t st = ctx->stream;
+    if (M <= ctx->opt_topk_host) {
+        // Small pools (the first iterations of a run: a few thousand candidates): the radix select is 28 dependent
+        // launches (0.22 ms whatever M is); one kernel writes all M records into the pinned, device-mapped staging
+        // buffer and the host selects -- same total order (acq desc, idx desc; NaN first), same bound.
+        GPRY_TRY(ensure_pinned(ctx, (int64_t)sizeof(gpry_cand) * M));
+        gpry_cand* hrec = static_cast<gpry_cand*>(ctx->hpin);
+        hipLaunchKernelGGL(cand_records_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, ctx->dacq_all,
+                           ctx->dy_all, ctx->dsig_all, M, static_cast<gpry_cand*>(ctx->hpin_dev));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        std::vector<int64_t> ex;
+        for (int64_t e = 0; e < n_exclude; e++) if (exclude[e] >= 0 && exclude[e] < M) ex.push_back(exclude[e]);
+        std::sort(ex.begin(), ex.end());
+        ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
+        std::vector<gpry_cand> v;
+        v.reserve((size_t)M);
+        size_t xi = 0;
+        for (int64_t i = 0; i < M; i++) {
+            if (xi < ex.size() && ex[xi] == i) { xi++; continue; }
+            v.push_back(hrec[i]);
+        }
+        auto before = [](const gpry_cand& a, const gpry_cand& b) {
+            unsigned long long ka, kb; double x = a.acq, y = b.acq;
+            memcpy(&ka, &x, 8); memcpy(&kb, &y, 8);
+            ka = (ka >> 63) ? ~ka : (ka | 0x8000000000000000ull);
+            kb = (kb >> 63) ? ~kb : (kb | 0x8000000000000000ull);
+            if (ka != kb) return ka > kb;
+            return a.idx > b.idx;
+        };
+        // the device path counts the exclusions as given (n_valid = M - n_exclude)
+        int64_t n_valid = M - (n_exclude > 0 ? n_exclude : 0);
+        if (n_valid < 0) n_valid = 0;
+        if (n_valid > (int64_t)v.size()) n_valid = (int64_t)v.size();
+        const int64_t K = Kp < n_valid ? Kp : n_valid;
+        *n_out = 0; *bound = -INFINITY;
+        if (K <= 0) return 0;
+        const int64_t take = std::min<int64_t>(K + 1, (int64_t)v.size());
+        std::partial_sort(v.begin(), v.begin() + take, v.end(), before);
+        for (int64_t k = 0; k < K; k++) top[k] = v[(size_t)k];
+        *n_out = K;
+        if ((int64_t)v.size() > K) *bound = v[(size_t)K].acq;
+        return 0;
+    }
     if (M > ctx->keys_cap) {
         if (ctx->dkeys) GPRY_TRY(dev_free(ctx, ctx->dkeys));
         GPRY_TRY(dev_alloc(ctx, &ctx->dkeys, round_up(M, 1024)));

@@ -137,6 +137,7 @@ struct gpry_ctx {
     int opt_factor_pipeline_spine = 0;    // > 0: checkpoints down the right spine of the tree while a node has >= this many blocks (0: half of all)
     int64_t opt_gemm_streamk = 5632;   // up to this Np the V = L^-1 levels >= 512 and K^-1 = V^T V are stream-K launches
                                        // (gemm_dma.hip; a gain up to 5120, neutral at 6144, a loss at 8192); 0 = off
+    int64_t opt_topk_host = 16384;    // pools up to this size are selected on the host (gpry_sweep_topk)
     int opt_factor_pipeline = 1;  // 1: V = L^-1 phases run on stream2 underneath potrf
     int opt_factor_pipeline_min = 4096;   // from this Np on (neutral at 3072, a loss at 2048: tools/ab_factor_pipeline.py)
     void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)   // cached batch descriptors of the V = L^-1 recursion (chol.hip)

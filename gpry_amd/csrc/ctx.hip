@@ -251,6 +251,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "lauum_split")) { ctx->opt_lauum_split = (int)value; return 0; }
     if (!strcmp(key, "trtri_split_cap")) { ctx->opt_trtri_split_cap = (int)value; return 0; }
     if (!strcmp(key, "trtri_diag_v1")) { ctx->opt_trtri_diag_v1 = (int)value; return 0; }
+    if (!strcmp(key, "topk_host")) { ctx->opt_topk_host = value; return 0; }
     if (!strcmp(key, "gemm_streamk")) { ctx->opt_gemm_streamk = value; return 0; }
     if (!strcmp(key, "factor_pipeline")) { ctx->opt_factor_pipeline = (int)value; return 0; }
     if (!strcmp(key, "factor_pipeline_spine")) {
