@@ -80,10 +80,14 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *              "chol_overlap" = 0/1 trailing-update tiles ride in the Cholesky panel launches (default 1, Np <= 7168)
  *              "factor_pipeline" = 0/1 V = L^-1 is queued phase by phase on a second stream underneath the
  *                                  Cholesky panel chain (default 1, from "factor_pipeline_min" = 4096 on; bit-identical)
+ *              "gemm_streamk" = largest Np at which the top levels of V = L^-1 and K^-1 = V^T V run as stream-K
+ *                               launches (default 5632; 0 = off)
+ *              "topk_host" = largest pool that gpry_sweep_topk selects on the host from one kernel's records
+ *                            (default 16384; 0 = always the device radix select)
  * Everything else is an A/B switch of the measurements quoted in DESIGN.md (defaults are the
  * measured best): "sweep_dma" 0..3, "sweep_persist", "sweep_overlap", "sweep_tilemap", "sweep_colouter", "chol_outer",
  * "chol_lookahead", "chol_overlap_max", "chol_caps", "split_k", "gemm_dma", "syrk_lds", "lauum_lds", "lauum_split",
- * "trtri_split_cap", "kb_tile", "predict_small", "lml_cache".  Unknown keys return -1.
+ * "trtri_split_cap", "kb_tile", "predict_small", "lml_cache", "factor_pipeline_spine".  Unknown keys return -1.
  * The environment variable GPRY_HIP_OPTIONS="key=value,key=value" applies options to every context the process
  * creates (gpry_ctx_create fails on an unknown key or a malformed entry). */
 int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value);
