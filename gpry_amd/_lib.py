@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpry_hip.so")
 
-GPRY_MAX_DIM = 64
+GPRY_MAX_DIM = 32      # include/gpry_hip.h: ABI array size and the enforced limit on d
 MASK_CLASSIFIED_INF = 1
 MASK_OUTSIDE_TRUST = 2
 

@@ -53,11 +53,16 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
         // V = L^-1 phase by phase on stream2 while the panel chain is still running (chol.hip); "trtri" then
         // times what is left of it after potrf
         bool piped = false;
+        struct PipeGuard {      // an error between begin and finish must not leave side-stream work in flight
+            gpry_ctx* c; bool armed = false;
+            ~PipeGuard() { if (armed) trtri_pipeline_abort(c); }
+        } guard{ctx};
         if (ctx->opt_factor_pipeline && ctx->opt_chol == 0 && !ctx->opt_chol_lookahead &&
             ctx->Np >= ctx->opt_factor_pipeline_min) {
             const int rc = trtri_pipeline_begin(ctx, A, V, T, ctx->Np);
             if (rc < 0) return rc;
             piped = rc == 0;
+            guard.armed = piped;
         }
         {
             StageScope s(ctx, "potrf");
@@ -67,7 +72,7 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
         }
         {
             StageScope s(ctx, "trtri");
-            if (piped) GPRY_TRY(trtri_pipeline_finish(ctx));
+            if (piped) { GPRY_TRY(trtri_pipeline_finish(ctx)); guard.armed = false; }
             else GPRY_TRY(trtri_lower(ctx, A, V, T, ctx->Np));
         }
     }
@@ -362,7 +367,7 @@ static int ensure_sweep_buffers(gpry_ctx* ctx, int64_t M) {
         void* old[] = {ctx->dXc, ctx->dmask, ctx->dy_all, ctx->dsig_all, ctx->dacq_all};
         for (void* p : old) if (p) GPRY_TRY(dev_free(ctx, p));
         int64_t cap = round_up(M, 1024);
-        GPRY_TRY(dev_alloc(ctx, &ctx->dXc, cap * GPRY_MAX_DIM / 2));  // d <= 32
+        GPRY_TRY(dev_alloc(ctx, &ctx->dXc, cap * GPRY_MAX_DIM));
         GPRY_TRY(dev_alloc(ctx, &ctx->dmask, cap));
         GPRY_TRY(dev_alloc(ctx, &ctx->dy_all, cap));
         GPRY_TRY(dev_alloc(ctx, &ctx->dsig_all, cap));
@@ -1123,8 +1128,13 @@ int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, 
     hipStream_t st = ctx->stream;
     const int64_t Np = ctx->Np;
     int64_t need = ctx->kb_n + round_up(m, 128);
-    if (need > ctx->kb_cap) {
-        int64_t cap = std::max<int64_t>(need, std::max<int64_t>(1024, 2 * ctx->kb_cap));
+    // rows registered earlier were written with the padded size of that time as their stride: every path that
+    // changes Np (set_train, append_rows) ends the session, so a stride change can only meet an empty session
+    if (ctx->kb_n > 0 && ctx->kb_ld < Np) return gpry_fail(ctx, -4, "kb_register: session rows have stride %lld, model needs %lld", (long long)ctx->kb_ld, (long long)Np);
+    if (need > ctx->kb_cap || Np > ctx->kb_ld) {
+        // (the row buffer used to be sized kb_cap x Np_at_allocation only: after the training set grew within
+        // ctx->cap -- Np 1280 -> 1408, same buffers -- a session of ~900+ rows ran over its end)
+        int64_t cap = std::max<int64_t>(need, std::max<int64_t>(1024, need > ctx->kb_cap ? 2 * ctx->kb_cap : ctx->kb_cap));
         double *nU = nullptr, *nX = nullptr, *nO = nullptr;
         GPRY_TRY(dev_alloc(ctx, &nU, cap * Np));
         GPRY_TRY(dev_alloc(ctx, &nX, cap * ctx->dpad));
@@ -1137,7 +1147,7 @@ int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, 
         if (ctx->dU) GPRY_TRY(dev_free(ctx, ctx->dU));
         if (ctx->dXkb) GPRY_TRY(dev_free(ctx, ctx->dXkb));
         if (ctx->dkbout) GPRY_TRY(dev_free(ctx, ctx->dkbout));
-        ctx->dU = nU; ctx->dXkb = nX; ctx->dkbout = nO; ctx->kb_cap = cap;
+        ctx->dU = nU; ctx->dXkb = nX; ctx->dkbout = nO; ctx->kb_cap = cap; ctx->kb_ld = Np;
     }
     const int64_t mp = round_up(m, 128);
     // stage the candidates, build their cross-kernel panel, then U^T = K*  V^T

@@ -61,7 +61,7 @@ static int grow_keep_factor(gpry_ctx* ctx, int64_t N_new) {
         ctx->dW2 = nW2; ctx->dW3 = nW3; ctx->dalpha_ = na; ctx->dvec = nv;
         ctx->cap = cap;
         ctx->kst_cap = 0; if (ctx->dKst) { (void)hipFree(ctx->dKst); ctx->dKst = nullptr; }
-        ctx->kb_cap = 0;
+        ctx->kb_cap = 0; ctx->kb_ld = 0;
         if (ctx->dU) { (void)hipFree(ctx->dU); ctx->dU = nullptr; }
         if (ctx->dXkb) { (void)hipFree(ctx->dXkb); ctx->dXkb = nullptr; }
         ctx->bord_cap = 0; if (ctx->dbord) { (void)hipFree(ctx->dbord); ctx->dbord = nullptr; }

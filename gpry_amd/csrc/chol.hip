@@ -257,7 +257,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
         // stream-K for the levels whose launches have few, long tiles
         pl.seg_t.push_back(0); pl.seg_v.push_back(0);
         pl.sk_t.emplace_back(); pl.sk_v.emplace_back();
-        if (al && mN >= 512) {
+        if (al && mN >= 512 && Np <= ctx->opt_gemm_streamk) {     // (built only for the sizes that launch them)
             std::vector<GemmShape> st_, sv_;
             for (auto& a : bt) st_.push_back({a.M, a.N, a.K});
             for (auto& b : bv) sv_.push_back({b.M, b.N, b.K});
@@ -268,7 +268,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
             if (rc) { pl.release(); pl = TrtriPlan(); return rc; }
         }
     }
-    {   // K^-1 = V^T V: lower tiles, k >= max(i, j) * 128
+    if (Np >= 512 && Np <= ctx->opt_gemm_streamk) {   // K^-1 = V^T V: lower tiles, k >= max(i, j) * 128
         std::vector<GemmShape> sh = {{(int)Np, (int)Np, (int)Np}};
         pl.seg_lauum = gemm_parts_segment(KM_AT_LOWER_B_LOWER, 1, sh, slots);
         int rc = gemm_parts_plan_build(ctx, KM_AT_LOWER_B_LOWER, 1, sh, pl.seg_lauum, &pl.sk_lauum);
@@ -541,6 +541,15 @@ int trtri_pipeline_finish(gpry_ctx* ctx) {
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, evd, 0));
     for (; pp->next < pl->phases.size(); pp->next++) GPRY_TRY(trtri_phase_run(ctx, pp, pp->next, ctx->stream));
     return 0;
+}
+
+// error path of the chain (build_factor): whatever the side stream still has queued on V / T / the split-K scratch
+// is waited for, so that the caller's next operation on those buffers cannot race with it
+void trtri_pipeline_abort(gpry_ctx* ctx) {
+    TrtriPipe* pp = static_cast<TrtriPipe*>(ctx->trtri_pipe);
+    if (!pp || !pp->active) return;
+    pp->active = false;
+    if (pp->side) (void)hipStreamSynchronize(pp->side);
 }
 
 // K^-1 = V^T V, lower triangle only (the traces kernel reads Kinv[max(i,j)][min(i,j)]).

@@ -124,7 +124,8 @@ struct gpry_ctx {
 
     // Kriging-believer session
     int64_t kb_n = 0, kb_cap = 0;
-    double* dU = nullptr;      // kb_cap x Np : row x = u(x)^T   (x-major, contiguous u)
+    int64_t kb_ld = 0;         // row length dU was allocated for (Np may grow within ctx->cap: set_train, gpry_append_rows)
+    double* dU = nullptr;      // kb_cap x kb_ld : row x = u(x)^T, used with stride Np <= kb_ld (x-major, contiguous u)
     double* dXkb = nullptr;    // kb_cap x dpad scaled candidate rows
     double* dkbout = nullptr;  // 2 * kb_cap
 
@@ -279,6 +280,7 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
 int trtri_pipeline_begin(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
 int trtri_pipeline_step(gpry_ctx* ctx, int blocks_done);
 int trtri_pipeline_finish(gpry_ctx* ctx);
+void trtri_pipeline_abort(gpry_ctx* ctx);   // error path: wait for the side stream, mark the chain inactive
 void trtri_pipe_free(gpry_ctx* ctx);
 int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np);
 int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha,

@@ -109,7 +109,7 @@ int ensure_capacity(gpry_ctx* ctx, int64_t N, int d) {
         ctx->cap = cap;
         ctx->dp_cap = dp;
         ctx->kst_cap = 0; if (ctx->dKst) { GPRY_TRY(dev_free(ctx, ctx->dKst)); ctx->dKst = nullptr; }
-        ctx->kb_cap = 0; ctx->kb_n = 0;
+        ctx->kb_cap = 0; ctx->kb_n = 0; ctx->kb_ld = 0;
         if (ctx->dU) { GPRY_TRY(dev_free(ctx, ctx->dU)); ctx->dU = nullptr; }
         if (ctx->dXkb) { GPRY_TRY(dev_free(ctx, ctx->dXkb)); ctx->dXkb = nullptr; }
     }
@@ -252,7 +252,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "trtri_split_cap")) { ctx->opt_trtri_split_cap = (int)value; return 0; }
     if (!strcmp(key, "trtri_diag_v1")) { ctx->opt_trtri_diag_v1 = (int)value; return 0; }
     if (!strcmp(key, "topk_host")) { ctx->opt_topk_host = value; return 0; }
-    if (!strcmp(key, "gemm_streamk")) { ctx->opt_gemm_streamk = value; return 0; }
+    if (!strcmp(key, "gemm_streamk")) { ctx->opt_gemm_streamk = value; trtri_plan_free(ctx); return 0; }   // the plan holds the stream-K parts
     if (!strcmp(key, "factor_pipeline")) { ctx->opt_factor_pipeline = (int)value; return 0; }
     if (!strcmp(key, "factor_pipeline_spine")) {
         if (value < 0) return gpry_fail(ctx, -1, "factor_pipeline_spine must be >= 0");
@@ -279,7 +279,7 @@ int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const doub
                    int64_t N, int d) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_set_train: ctx is NULL");
     if (N <= 0 || d <= 0) return gpry_fail(ctx, -1, "set_train: need N > 0 and d > 0 (got %lld, %d)", (long long)N, d);
-    if (d > 32) return gpry_fail(ctx, -1, "set_train: d=%d > 32 is not supported by this build", d);
+    if (d > GPRY_MAX_DIM) return gpry_fail(ctx, -1, "set_train: d=%d > GPRY_MAX_DIM=%d is not supported by this build", d, GPRY_MAX_DIM);
     if (!X_ || !y_ || !alpha) return gpry_fail(ctx, -1, "set_train: X_, y_ and alpha must not be NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(ensure_capacity(ctx, N, d));

@@ -31,9 +31,10 @@ typedef struct gpry_group gpry_group;
 /* kernel ids: Product(ConstantKernel, RBF | Matern(nu)) -- gpry/kernels.py:213,281,601,681 */
 enum { GPRY_RBF = 0, GPRY_MATERN12 = 1, GPRY_MATERN32 = 2, GPRY_MATERN52 = 3 };
 
-/* ABI size of the per-dimension arrays in gpry_affine.  The kernels of this build are instantiated for
- * d <= 32 (GPry's design envelope is d < 20, README.rst:64); gpry_set_train refuses more. */
-#define GPRY_MAX_DIM 64
+/* Largest dimension of the parameter space: ABI size of the per-dimension arrays in gpry_affine AND the
+ * limit gpry_set_train enforces (the kernels of this build are instantiated for d <= 32; GPry's design
+ * envelope is d < 20, README.rst:64). */
+#define GPRY_MAX_DIM 32
 
 /* Affine pre-/post-processing fused into the device path.
  * x_ = (x - x_lo) / x_span       gpry/preprocessing.py:380 (Normalize_bounds.transform)

@@ -159,7 +159,13 @@ def test_config3_at_full_size_sharded_eight_ways_equals_one_context():
     """BASELINE configs[3] logic at full size on one GPU: N=4096, d=16, M=1e6 candidates sharded over 8 contexts
     (125 000 candidates = 4 launches each, model replicated and factorised on every member, shortlists merged
     with the hold-back rule): proposals, lies, acquisition values, the ranked pool and the y / sigma arrays of
-    all 1e6 candidates must equal the one-context run bit for bit."""
+    all 1e6 candidates must equal the one-context run bit for bit.
+
+    This is a SELF-comparison (8 contexts against 1): it pins the sharding, not the arithmetic.  The one-context run
+    at this very size is anchored to the oracle by
+    ``tests/test_hip_parity.py::test_full_size_config2_sweep_topk_and_multi_add_vs_oracle`` (same N, d, M, theta,
+    pool: shortlist = head of np.lexsort over all 1e6 acquisition values, 2048 rows and the 16 proposals against
+    the oracle), so the sharded result reaches the oracle through that test."""
     import bench
     from gpry_amd.gp_acquisition import NORA
     N, d, M, npts = 4096, 16, 1_000_000, 16

@@ -883,3 +883,37 @@ def test_stream_k_gemm_matches_numpy(dev, seg):
     B = rng.standard_normal((384, 512))
     assert relmax(dev.debug_gemm(A, np.ascontiguousarray(B.T), None, 256, 512, 384, b_trans=1, tile_map=hook), A @ B) < 1e-14
 
+
+
+def test_kb_session_after_the_padded_size_grew_within_the_allocation():
+    """ADVICE r02 (append.hip / ctx.hip): the Kriging-believer row buffer was sized kb_cap x Np at its
+    allocation; when the training set then grew to a wider padded size WITHOUT new buffers (Np 1280 ->
+    1408 inside cap = 1408), a session of ~1000 rows wrote beyond its end.  The conditioned variances of
+    all registered points are compared with predict() here, after exactly that sequence."""
+    from gpry_amd import _lib
+    rng = np.random.default_rng(77)
+    d = 4
+    X = rng.uniform(size=(1400, d))
+    y = np.sin(X.sum(axis=1))
+    theta = np.log(np.array([2.0] + [0.4] * d))
+    dv = _lib.Device(0)
+    dv_round = 0
+    try:
+        for n in (1400, 1200, 1400):            # cap = 1408; Np = 1408 -> 1280 -> 1408 in the same buffers
+            dv.set_train(X[:n], y[:n], 1e-4)
+            dv.set_theta(3, theta)
+            assert dv.factorize() == 0
+            dv.set_affine()
+            if dv_round == 0:                   # only sizes the N x N buffers (cap = 1408)
+                dv_round += 1
+                continue
+            m = 1000 if n == 1400 else 64       # the small session sizes the row buffer for Np = 1280
+            Xc = rng.uniform(size=(m, d))
+            first, var0 = dv.kb_register(Xc)
+            assert first == 0
+            _, sd = dv.predict(Xc, return_std=True)
+            assert np.max(np.abs(var0 - sd ** 2)) <= 1e-9 * np.exp(theta[0])
+            G, kv = dv.kb_gram(m - 1, m)        # reads the last row: beyond the old allocation before the fix
+            assert np.isfinite(G).all() and abs(G[m - 1] - (np.exp(theta[0]) - var0[m - 1])) <= 1e-9 * np.exp(theta[0])
+    finally:
+        dv.close()

@@ -49,6 +49,7 @@ def test_reference_runner_drives_the_mirror_classes(monkeypatch):
     saved = {k: getattr(gpry.run, k) for k in ("GaussianProcessRegressor", "GenericGPAcquisition",
                                                 "Normalize_bounds", "Normalize_y")}
     saved_nora, saved_gpr = gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor
+    saved_bo = gpry.gp_acquisition.BatchOptimizer
     monkeypatch.setattr(_lib, "Device", lambda index=0: OracleDevice())
     try:
         from gpry_amd.integration import patch_gpry
@@ -58,6 +59,7 @@ def test_reference_runner_drives_the_mirror_classes(monkeypatch):
         for k, v in saved.items():
             setattr(gpry.run, k, v)
         gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor = saved_nora, saved_gpr
+        gpry.gp_acquisition.BatchOptimizer = saved_bo
     assert isinstance(ours.gpr, mirror_gpr.GaussianProcessRegressor)
     assert isinstance(ours.acquisition, mirror_acq.NORA)
     assert isinstance(ours.gpr.device, OracleDevice)
@@ -95,6 +97,7 @@ def test_reference_runner_with_an_infinite_region_uses_the_device_gates(monkeypa
     saved = {k: getattr(gpry.run, k) for k in ("GaussianProcessRegressor", "GenericGPAcquisition",
                                                 "Normalize_bounds", "Normalize_y")}
     saved_nora, saved_gpr = gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor
+    saved_bo = gpry.gp_acquisition.BatchOptimizer
     monkeypatch.setattr(_lib, "Device", lambda index=0: OracleDevice())
     try:
         from gpry_amd.integration import patch_gpry
@@ -104,6 +107,7 @@ def test_reference_runner_with_an_infinite_region_uses_the_device_gates(monkeypa
         for k, v in saved.items():
             setattr(gpry.run, k, v)
         gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor = saved_nora, saved_gpr
+        gpry.gp_acquisition.BatchOptimizer = saved_bo
     assert ref.has_converged and ours.has_converged
     assert ours.gpr.n_total > ours.gpr.n                      # some evaluations hit the -inf region
     assert ours.gpr.device.gates is not None                  # ... and the sweep used the device gates
@@ -115,10 +119,13 @@ def test_reference_runner_with_an_infinite_region_uses_the_device_gates(monkeypa
     assert np.max(np.abs(ref.gpr.predict(Xt) - truth)) < 0.1
 
 
-def test_reference_batch_optimizer_runs_on_the_mirror_gpr(monkeypatch):
+@pytest.mark.parametrize("which", ["reference", "mirror"])
+def test_reference_batch_optimizer_runs_on_the_mirror_gpr(monkeypatch, which):
     """The reference's own gradient-based acquisition (``BatchOptimizer``, gp_acquisition.py:270-389)
     needs nothing but ``predict(..., return_mean_grad, return_std_grad)``, lies appended with
-    ``fit_gpr=False`` and deep copies: on top of the mirror GPR it drives the run to convergence."""
+    ``fit_gpr=False`` and deep copies: on top of the mirror GPR it drives the run to convergence
+    (``which="reference"``).  ``patch_gpry()`` also rebinds the name ``BatchOptimizer`` that
+    ``Runner`` looks up (run.py:392): ``which="mirror"`` is the same run on the mirror class."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from make_goldens import import_reference
     import_reference()
@@ -136,10 +143,15 @@ def test_reference_batch_optimizer_runs_on_the_mirror_gpr(monkeypatch):
     saved = {k: getattr(gpry.run, k) for k in ("GaussianProcessRegressor", "GenericGPAcquisition",
                                                 "Normalize_bounds", "Normalize_y")}
     saved_nora, saved_gpr = gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor
+    saved_bo = gpry.gp_acquisition.BatchOptimizer
     monkeypatch.setattr(_lib, "Device", lambda index=0: OracleDevice())
     try:
         from gpry_amd.integration import patch_gpry
         patch_gpry()
+        import gpry_amd.gp_acquisition as mirror_acq
+        assert gpry.gp_acquisition.BatchOptimizer is mirror_acq.BatchOptimizer
+        if which == "reference":
+            gpry.gp_acquisition.BatchOptimizer = saved_bo
         r = gpry.run.Runner(loglike, [[-5, 5], [-5, 5]], gpr={"kernel": {"Matern": {"nu": 2.5}}},
                             gp_acquisition="BatchOptimizer", options={"max_total": 120, "max_finite": 120},
                             checkpoint=None, verbose=0, seed=1)
@@ -150,8 +162,10 @@ def test_reference_batch_optimizer_runs_on_the_mirror_gpr(monkeypatch):
         for k, v in saved.items():
             setattr(gpry.run, k, v)
         gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor = saved_nora, saved_gpr
+        gpry.gp_acquisition.BatchOptimizer = saved_bo
     assert isinstance(r.gpr, mirror_gpr.GaussianProcessRegressor)
     assert type(r.acquisition).__name__ == "BatchOptimizer" and r.has_converged
+    assert (type(r.acquisition) is mirror_acq.BatchOptimizer) == (which == "mirror")
     Xt = rv.rvs(30, random_state=3)
     truth = np.array([loglike(*x) for x in Xt]) - np.log(100.0)
     assert np.max(np.abs(r.gpr.predict(Xt) - truth)) < 0.1
@@ -180,6 +194,7 @@ def test_reference_checkpoint_is_light_and_resumes_on_the_mirror_classes(monkeyp
     saved = {k: getattr(gpry.run, k) for k in ("GaussianProcessRegressor", "GenericGPAcquisition",
                                                 "Normalize_bounds", "Normalize_y")}
     saved_nora, saved_gpr = gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor
+    saved_bo = gpry.gp_acquisition.BatchOptimizer
     monkeypatch.setattr(_lib, "Device", lambda index=0: OracleDevice())
 
     def make(load, max_total):
@@ -217,6 +232,7 @@ def test_reference_checkpoint_is_light_and_resumes_on_the_mirror_classes(monkeyp
         for k, v in saved.items():
             setattr(gpry.run, k, v)
         gpry.gp_acquisition.NORA, gpry.gpr.GaussianProcessRegressor = saved_nora, saved_gpr
+        gpry.gp_acquisition.BatchOptimizer = saved_bo
     assert resumed.has_converged and resumed.gpr.n_total > 12
     truth = np.array([loglike(*x) for x in Xt]) - np.log(100.0)
     assert np.max(np.abs(resumed.gpr.predict(Xt) - truth)) < 0.1
