@@ -25,11 +25,22 @@ hyper-parameter fit, 32 L-BFGS-B restarts split over the ranks (gpry/run.py:1238
 
 Rank 0 prints ONE JSON line; ``value`` = candidates swept by all ranks per second of whole cycle
 (farm: restarts per second).
+
+Launching.  ``python bench.py --gpus N`` with N > 1 and no ``WORLD_SIZE`` in the environment is its own
+launcher: the parent (which imports neither the library nor HIP) starts N child processes of this script
+with ``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE`` / ``MASTER_ADDR=127.0.0.1`` / ``MASTER_PORT`` set -- the
+environment ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` gives them --
+relays rank 0's JSON line and exits with the worst child code; a watchdog ends the group when a rank dies
+or the run exceeds ``GPRY_BENCH_LAUNCH_TIMEOUT`` seconds.  ``--gpus N`` beyond the visible GPUs is refused
+(exit 2) unless ``GPRY_HIP_DEVICE_WRAP=1`` lets ranks share devices (development boxes; no RCCL then:
+``--allow-gloo``).  ``--workload farm --mode group`` keeps ONE process and spreads the restarts of the fit
+over N GPUs from host threads (what an unmodified single-process ``gpry.Runner`` does).
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -290,7 +301,16 @@ def run_farm(args, rank, world, local_rank):
     gpr = make_gpr(bounds, n_restarts_optimizer=n_restarts)
     dev = gpr.device
     comm, dist, comm_kind, n_rccl = None, None, "none", 0
-    if world > 1 or "RANK" in os.environ:
+    group = args.mode == "group"
+    n_gpus = args.gpus if group else world
+    if group:
+        # ONE process: the contexts of the fit are dealt out over the GPUs (gpry_amd.gpr.fit_context_devices;
+        # an explicit list here so that a development box can repeat its only device)
+        from gpry_amd.gpr import fit_contexts
+        devs = [int(v) for v in os.environ.get("GPRY_BENCH_GROUP_DEVICES", "0").split(",")][:args.gpus]
+        gpr.fit_devices = [devs[i % len(devs)] for i in range(fit_contexts() * len(devs))]
+        comm_kind = "one process, host threads"
+    elif world > 1 or "RANK" in os.environ:
         comm, dist, comm_kind, n_rccl = connect(args, rank, world, dev)
     # setup (untimed): first fit on the base set
     gpr.append_to_data(X[:n_base], y[:n_base], fit_gpr="simple")
@@ -326,19 +346,24 @@ def run_farm(args, rank, world, local_rank):
     names = ("kernel_build", "potrf", "trtri", "lauum", "lml_traces")
     T = {k: dev.timing(k) for k in names}
     Np = (N + 127) // 128 * 128
+    evals_gpu = evals_rank / (n_gpus if group else 1)      # group: the process' evaluations are spread over its GPUs
     one_eval_ms = sum(T[k][0] / max(T[k][1], 1) for k in names)
     po_ms, po_n = T["potrf"]
     chain_ms = sum(T[k][0] / max(T[k][1], 1) for k in ("potrf", "trtri", "lauum"))
     result = {
         "metric": "gp_hyperparameter_restart_farm_throughput",
         "value": n_restarts / (elapsed / K), "unit": "restarts/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "n_gpus": n_gpus, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[4]: 20-d synthetic posterior, N_train=8192, Matern-5/2, "
-                               f"{n_restarts} L-BFGS-B restarts of the log-marginal-likelihood split over the GPUs",
-                   "N_train": N, "d": d, "n_restarts": n_restarts,
+                               f"{n_restarts} L-BFGS-B restarts of the log-marginal-likelihood " +
+                               ("spread over the GPUs by ONE process (host threads, one context each)" if group
+                                else "split over the GPUs (one process per GPU)"),
+                   "N_train": N, "d": d, "n_restarts": n_restarts, "mode": args.mode,
                    "restarts_per_rank": [int(v) for v in split_number_for_parallel_processes(n_restarts, world)],
+                   "fit_context_devices": getattr(gpr, "fit_stats", {}).get("devices"),
+                   "evals_per_context_last_fit": getattr(gpr, "fit_stats", {}).get("evals_per_context"),
                    "comm": comm_kind, "rccl_ranks": n_rccl},
         "farm": {"lml_grad_evals_per_step_per_rank": [float(v) for v in evals_all],
                  "one_lml_grad_call_ms_device": one_eval_ms,
@@ -347,10 +372,10 @@ def run_farm(args, rank, world, local_rank):
         # section 5), so the per-stage event times above overlap; the rate of the GPU as a whole is
         # evaluations x Np^3 flop (potrf + V = L^-1 + K^-1 = V^T V) over the wall time of the step
         "roofline": {"kernel": "factor chain of the LML+gradient evaluations (potrf + V = L^-1 + K^-1 = V^T V), "
-                               "all concurrent contexts of rank 0",
-                     "bound": "mfma", "achieved": evals_rank * float(Np) ** 3 / (elapsed / K) / 1e12,
+                               "all concurrent contexts of rank 0" + (" (average per GPU of the process)" if group else ""),
+                     "bound": "mfma", "achieved": evals_gpu * float(Np) ** 3 / (elapsed / K) / 1e12,
                      "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": evals_rank * float(Np) ** 3 / (elapsed / K) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                     "frac": evals_gpu * float(Np) ** 3 / (elapsed / K) / 1e12 / F64_MFMA_PEAK_TFLOPS,
                      "traffic": None, "flops_per_call": float(Np) ** 3,
                      "evals_per_step_rank0": evals_rank, "ms_per_eval_wall": elapsed / K * 1e3 / max(evals_rank, 1),
                      "single_stage_chain_ms_under_contention": chain_ms,
@@ -365,12 +390,128 @@ def run_farm(args, rank, world, local_rank):
         dist.destroy_process_group()
 
 
-def main():
+def visible_gpus():
+    """GPUs this process tree can use, counted in a short-lived child: the launcher itself never
+    initialises HIP (a process that has must not be the parent of a rank's exec on this pool)."""
+    code = ("import sys; sys.path.insert(0, %r); from gpry_amd import _lib; print('GPUS', _lib.device_count())" % ROOT)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        for line in reversed(out.stdout.splitlines()):
+            if line.startswith("GPUS "):
+                return int(line.split()[1])
+        print(f"bench.py: device probe failed: {out.stderr.strip()[-400:]}", file=sys.stderr)
+    except Exception as e:
+        print(f"bench.py: device probe failed: {e!r}", file=sys.stderr)
+    return 0
+
+
+def check_gpu_count(n):
+    """Refuse ``--gpus n`` beyond the visible devices (round 2 ran 1 GPU and printed ``n_gpus: 1``)."""
+    have = visible_gpus()
+    if n <= have:
+        return have
+    if os.environ.get("GPRY_HIP_DEVICE_WRAP", "") == "1" and have >= 1:
+        print(f"bench.py: --gpus {n} on {have} visible GPU(s): ranks share devices (GPRY_HIP_DEVICE_WRAP=1; "
+              "no RCCL communicator can hold a device twice)", file=sys.stderr)
+        return have
+    print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing (GPRY_HIP_DEVICE_WRAP=1 lets "
+          "ranks share a device on development boxes)", file=sys.stderr)
+    raise SystemExit(2)
+
+
+def launch_ranks(n, argv, script=None, timeout=None, env_extra=None):
+    """Parent of an N-GPU run: start one child process per GPU with the environment
+    ``torch.distributed.run`` would give it, relay rank 0's stdout, return the worst exit code.
+
+    The parent has not imported ``gpry_amd`` or touched HIP, and never ``exec``s: the ranks are ordinary
+    children in their own sessions, so the watchdog can end a whole rank (its process group) when a peer
+    died, when the time limit passed, or when the parent itself is told to stop."""
+    import signal
+    import socket
+    import threading
+    script = script or os.path.abspath(__file__)
+    timeout = float(timeout if timeout is not None else os.environ.get("GPRY_BENCH_LAUNCH_TIMEOUT", "3600"))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "GPRY_BENCH_LAUNCHER": "self",
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, start_new_session=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+
+    def end_all(sig=signal.SIGTERM):
+        for pr in procs:
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, sig)        # the rank's own session: exactly the processes it started
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, frame):
+        end_all(signal.SIGTERM)
+        raise SystemExit(128 + signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    t0, first_fail, why, t_end = time.time(), None, None, None
+    try:
+        while any(pr.poll() is None for pr in procs):
+            time.sleep(0.2)
+            now = time.time()
+            if first_fail is None and any(pr.poll() not in (None, 0) for pr in procs):
+                first_fail = now
+            if why is None and first_fail is not None and now - first_fail > float(os.environ.get("GPRY_BENCH_FAIL_GRACE", "30")):
+                why = "a rank failed"            # its peers are waiting at a barrier that will never complete
+            if why is None and now - t0 > timeout:
+                why = f"time limit of {timeout:.0f} s"
+            if why is not None and t_end is None:
+                t_end = now
+                end_all()
+            if t_end is not None and now - t_end > 20.0:
+                end_all(signal.SIGKILL)
+    finally:
+        end_all(signal.SIGKILL)
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    reader.join(timeout=10)
+    codes = [pr.returncode for pr in procs]
+    # the worst code a rank returned itself; ranks the launcher had to end (negative = signal) only count if no
+    # rank failed on its own
+    own = [c for c in codes if c is not None and c > 0]
+    worst = max(own) if own else max([128 - c for c in codes if c is not None and c < 0] or [0])
+    if why is not None:
+        print(f"bench.py: launcher ended the run ({why}); rank exit codes {codes}", file=sys.stderr)
+        worst = worst or 124
+    out = [ln.rstrip("\n") for ln in lines if ln.strip()]
+    json_lines = [ln for ln in out if ln.lstrip().startswith("{")]
+    for ln in out:
+        if not ln.lstrip().startswith("{"):
+            print(ln, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1], flush=True)
+    elif worst == 0:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        worst = 1
+    return worst
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["cycle", "farm"], default="cycle")
+    ap.add_argument("--mode", choices=["ranks", "group"], default="ranks",
+                    help="farm: 'ranks' = one process per GPU (gpry/run.py:1238-1293 over RCCL), 'group' = ONE process "
+                         "whose fit contexts are spread over --gpus devices (a single-process Runner)")
     ap.add_argument("--N", type=int, default=None)
     ap.add_argument("--d", type=int, default=None)
     ap.add_argument("--M", type=int, default=1_000_000)
@@ -380,16 +521,31 @@ def main():
     ap.add_argument("--allow-gloo", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
     ap.add_argument("--extras", choices=["auto", "off"], default="auto")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
 
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    group_mode = args.workload == "farm" and args.mode == "group"
+    if args.mode == "group" and args.workload != "farm":
+        raise SystemExit("bench.py: --mode group applies to --workload farm (the cycle shards in one process through "
+                         "NORA(devices=...), tools/bench_group.py)")
+    if group_mode and launched and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("bench.py: --mode group is ONE process; do not start it under torch.distributed.run")
+    if not launched and args.gpus > 1:
+        have = check_gpu_count(args.gpus)              # exits 2 beyond the visible devices
+        if group_mode:
+            os.environ["GPRY_BENCH_GROUP_DEVICES"] = ",".join(str(i % max(have, 1)) for i in range(args.gpus))
+        else:
+            # this process becomes the launcher: it has not imported the library or touched HIP
+            raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node "
-                  f"{args.gpus} bench.py ...`; running 1 GPU", file=sys.stderr)
-        args.gpus = world
+    if world != args.gpus and not group_mode:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (self-"
+              f"launching) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`", file=sys.stderr)
+        raise SystemExit(2)
     os.environ["GPRY_HIP_DEVICE"] = str(local_rank)
     if args.workload == "farm":
         return run_farm(args, rank, world, local_rank)

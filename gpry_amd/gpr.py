@@ -67,6 +67,34 @@ def fit_contexts():
         return 3
 
 
+def fit_context_devices(own, n_restarts, spec=None):
+    """Device index of every context that shares the optimiser restarts of one fit in THIS process; entry 0
+    is the model's own context.
+
+    ``spec`` (``GaussianProcessRegressor.fit_devices``): explicit list, one entry per context, repeats
+    allowed.  ``None``: ``GPRY_HIP_DEVICES`` (a list of GPUs, or ``all`` / ``none``), else every visible GPU
+    unless this process is one rank of a multi-process launch (``WORLD_SIZE`` > 1: one process per GPU, the
+    ranks farm the restarts among themselves, ``gpry_amd.parallel``); ``fit_contexts()`` contexts per GPU,
+    dealt out round-robin so that the first restarts land on distinct GPUs.  An unmodified single-process
+    ``gpry.Runner`` on an 8-GPU node (``gpry/run.py:315-325``: without mpi4py there is one rank) thereby
+    spreads its 10+2d restarts over all GPUs instead of running them on GPU 0."""
+    per = fit_contexts()
+    if spec is None:
+        env = os.environ.get("GPRY_HIP_DEVICES", "").strip().lower()
+        if env not in ("", "none", "1", "all"):
+            devs = [int(v) for v in env.split(",")]
+        elif env in ("none", "1") or (env == "" and int(os.environ.get("WORLD_SIZE", "1")) > 1):
+            devs = [own]
+        else:
+            n = _lib.device_count()
+            devs = list(range(n)) if n > 1 else [own]
+        devs = [own] + [v for v in dict.fromkeys(devs) if v != own]
+        spec = [devs[i % len(devs)] for i in range(per * len(devs))]
+    else:
+        spec = [own] + [int(v) for v in list(spec)[1:]]
+    return spec[:max(1, min(len(spec), int(n_restarts)))]
+
+
 _SCRATCH = None
 
 
@@ -176,7 +204,7 @@ class GaussianProcessRegressor(_RM, _BE):
         self._dev_factor_ok = False    # device factor matches kernel_.theta + training set
         self._host_factor = {}         # lazily fetched copies of L_, V_, alpha_
         self._kb = None                # Kriging-believer session on the current factor
-        self._fit_devs = []            # extra contexts for concurrent optimiser restarts
+        self._fit_devs = []            # extra contexts for concurrent optimiser restarts: (device index, context)
 
     @property
     def device(self):
@@ -614,14 +642,15 @@ class GaussianProcessRegressor(_RM, _BE):
                     "bounds are finite. You can pass some finite bounds manually using "
                     "``hyperparameter_bounds``.")
         self._rng = check_random_state(self.random_state)
-        n_ctx = min(fit_contexts(), n_restarts) if self.optimizer == "fmin_l_bfgs_b" else 1
-        if n_ctx > 1:
+        ctx_devs = (fit_context_devices(getattr(self.device, "device", 0), n_restarts, getattr(self, "fit_devices", None))
+                    if self.optimizer == "fmin_l_bfgs_b" else [0])
+        if len(ctx_devs) > 1:
             # the optimiser never touches the RNG: drawing the start points up front gives the reference's
             # sequence (gpry/gpr.py:969-978)
             starts = [np.array(self.kernel_.theta) if (it == 0 and start_from_current) else
                       self._rng.uniform(hyperparameter_bounds[:, 0], hyperparameter_bounds[:, 1])
                       for it in range(n_restarts)]
-            optima = self._concurrent_restarts(starts, hyperparameter_bounds, n_ctx)
+            optima = self._concurrent_restarts(starts, hyperparameter_bounds, ctx_devs)
         else:
             optima = []
             for iteration in range(n_restarts):
@@ -638,26 +667,50 @@ class GaussianProcessRegressor(_RM, _BE):
         self._fitted = True
         return self
 
-    def _concurrent_restarts(self, starts, bounds, n_ctx):
-        """The optimiser runs of a multi-restart fit are independent: they are worked off by ``n_ctx``
-        host threads, each with its own device context holding the same training set (a context is not
-        re-entrant, distinct contexts may be driven from distinct threads; ctypes releases the GIL while
-        an evaluation runs).  One LML evaluation leaves most of the GPU idle in its latency-bound panel
-        steps: 2 / 3 contexts give 1.6x / 1.9x the evaluations per second at N=4096 and 1.3x / 1.4x at
-        N=8192 (``tools/ab_concurrent_lml.py``).  Every run is deterministic and evaluated exactly as in
-        the sequential loop, so the optima -- and the selected one -- do not depend on the schedule."""
+    def _concurrent_restarts(self, starts, bounds, ctx_devs):
+        """The optimiser runs of a multi-restart fit are independent: they are worked off by one host
+        thread per entry of ``ctx_devs`` (device indices, entry 0 = the model's own context), each with its
+        own device context holding the same training set (a context is not re-entrant, distinct contexts
+        may be driven from distinct threads; ctypes releases the GIL while an evaluation runs).  On one
+        GPU, one LML evaluation leaves most of it idle in its latency-bound panel steps: 2 / 3 contexts
+        give 1.6x / 1.9x the evaluations per second at N=4096 and 1.3x / 1.4x at N=8192
+        (``tools/ab_concurrent_lml.py``); with several GPUs in the process the contexts are spread over
+        them (``fit_context_devices``: the restart farm of BASELINE configs[4] in ONE process).  Every
+        run is deterministic and evaluated exactly as in the sequential loop, so the optima -- and the
+        selected one -- do not depend on the schedule or on which GPU ran them."""
         import queue
         import threading
         self._upload_train()
         kern0 = self.kernel_
         kid, theta_full0 = kern0.device_spec(self.d)
+        n_ctx = len(ctx_devs)
         devs = [self.device]
-        while len(self._fit_devs) < n_ctx - 1:
-            self._fit_devs.append(type(self.device)(default_device_index()))   # same kind as the main one
-        for dv in self._fit_devs[:n_ctx - 1]:
+        spare = list(self._fit_devs)
+        used = []
+        for idx in ctx_devs[1:]:
+            hit = next((pr for pr in spare if pr[0] == idx), None)
+            if hit is None:
+                hit = (idx, type(self.device)(idx))         # same kind as the main one
+                self._fit_devs.append(hit)
+            else:
+                spare.remove(hit)
+            used.append(hit)
+
+        def _replicate(dv):
             dv.set_train(self.X_train_, self.y_train_, self.alpha)
             dv.set_theta(kid, theta_full0)
-            devs.append(dv)
+
+        if len({idx for idx, _ in used}) > 1:       # several GPUs: their uploads run side by side
+            ths = [threading.Thread(target=_replicate, args=(dv,)) for _, dv in used]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        else:
+            for _, dv in used:
+                _replicate(dv)
+        devs += [dv for _, dv in used]
+        self.fit_stats = {"contexts": n_ctx, "devices": list(ctx_devs), "evals_per_context": None}
         todo = queue.Queue()
         for it, th in enumerate(starts):
             todo.put((it, th))
@@ -693,6 +746,7 @@ class GaussianProcessRegressor(_RM, _BE):
         for t in threads:
             t.join()
         self.n_eval_loglike += sum(counts)
+        self.fit_stats["evals_per_context"] = list(counts)
         if errors:
             raise errors[0]
         return optima

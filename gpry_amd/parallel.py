@@ -60,6 +60,11 @@ def fit_gpr_parallel(gpr, new_X, new_y, comm=None, fit="full", n_restarts=None,
         # an int seed (or None) would give every rank the same start points: each rank gets its own
         # child stream of the seed, as Runner does (gpry/run.py:321,756 -> mpi.get_random_generator)
         gpr.set_random_state(get_random_generator(gpr.random_state, comm))
+    if world > 1 and getattr(gpr, "fit_devices", None) is None:
+        # one process per GPU: this rank's share of the restarts stays on this rank's GPU (a single process
+        # spreads its contexts over every visible GPU, gpry_amd.gpr.fit_context_devices)
+        from gpry_amd.gpr import fit_contexts
+        gpr.fit_devices = [getattr(gpr.device, "device", 0)] * fit_contexts()
     if fit == "full":
         total = gpr.n_restarts_optimizer if n_restarts is None else n_restarts
         n_mine = int(split_number_for_parallel_processes(total, world)[rank])

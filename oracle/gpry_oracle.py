@@ -151,6 +151,57 @@ def log_marginal_likelihood(X_, y_, alpha, theta, kernel_id, eval_gradient=False
     return lml, grad.sum(axis=-1)
 
 
+def log_marginal_likelihood_blocked(X_, y_, alpha, theta, kernel_id, block=256):
+    """Same value and gradient as ``log_marginal_likelihood(..., eval_gradient=True)`` without the
+    ``(N, N, 1+d)`` tensors of sklearn:_gpr.py:625-649 / sklearn:kernels.py:960-964,1574-1580,1740-1768
+    (10 GB at N=4096, d=16; 56 GB at N=8192, d=20): the trace
+    ``grad_k = 1/2 sum_ij (a a^T - K^-1)_ij dK_ij/dtheta_k`` (:643-645) is accumulated over blocks of
+    ``block`` rows, each block's ``dK`` rows built with the formulas of ``kernel_matrix``.  Same BLAS/LAPACK
+    factorisation calls; only the summation order of the trace differs (row blocks).  Used by the
+    full-size parity tests of the device objective (N=8192) and checked against the einsum form on the
+    F3 goldens (tests/test_oracle_golden.py)."""
+    theta = np.asarray(theta, dtype=float)
+    X = np.atleast_2d(X_)
+    N = X.shape[0]
+    const = math.exp(theta[0])
+    ls = np.exp(theta[1:])
+    K = kernel_matrix(X, theta, kernel_id)
+    k = K / const                       # correlation with unit diagonal (sklearn:kernels.py:1560,1738)
+    np.fill_diagonal(k, 1)
+    K[np.diag_indices_from(K)] += alpha
+    try:
+        L = cholesky(K, lower=True, check_finite=False)
+    except np.linalg.LinAlgError:
+        return -np.inf, np.zeros_like(theta)
+    a = cho_solve((L, True), y_, check_finite=False)
+    lml = -0.5 * float(y_ @ a) - np.log(np.diag(L)).sum() - N / 2 * np.log(2 * np.pi)
+    W = cho_solve((L, True), np.eye(N), check_finite=False)       # K^-1
+    W *= -1.0
+    W += np.outer(a, a)                                           # inner = a a^T - K^-1 (:641-642)
+    del K, L
+    grad = np.zeros(len(theta))
+    Xs = X / ls
+    for i0 in range(0, N, block):
+        i1 = min(N, i0 + block)
+        Wb, kb = W[i0:i1], k[i0:i1]
+        grad[0] += 0.5 * np.sum(Wb * (const * kb))                # d K / d log C = K (:1278-1289)
+        D = (Xs[i0:i1, None, :] - Xs[None, :, :]) ** 2            # (b, N, d) = (x_i - x_j)^2 / l^2
+        if kernel_id == RBF:
+            g = D * kb[..., None]
+        elif kernel_id == MATERN12:
+            denom = np.sqrt(D.sum(axis=2))[:, :, None]
+            q = np.zeros_like(D)
+            np.divide(D, denom, out=q, where=denom != 0)
+            g = kb[..., None] * q
+        elif kernel_id == MATERN32:
+            g = 3 * D * np.exp(-np.sqrt(3 * D.sum(-1)))[..., None]
+        else:
+            t = np.sqrt(5 * D.sum(-1))[..., None]
+            g = 5.0 / 3.0 * D * (t + 1) * np.exp(-t)
+        grad[1:] += 0.5 * const * np.einsum("ij,ijk->k", Wb, g)
+    return lml, grad
+
+
 # ----------------------------------------------------------------------------
 # f3: x-gradients (SURVEY.md section 8f item 3)
 # ----------------------------------------------------------------------------

@@ -12,6 +12,7 @@ from gpry_amd._lib import CAND_DTYPE, MASK_CLASSIFIED_INF, MASK_OUTSIDE_TRUST
 
 class OracleDevice:
     def __init__(self, device=0):
+        self.device = int(device)
         self.N = self.d = 0
         self.kid, self.theta = orc.RBF, None
         self.lo = self.span = None

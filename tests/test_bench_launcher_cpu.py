@@ -1,0 +1,85 @@
+"""``python bench.py --gpus N`` launches itself: the parent starts N one-GPU child processes with
+the environment ``torch.distributed.run`` would give them, relays rank 0's single JSON line and returns the worst
+exit code; ``--gpus N`` beyond the visible devices is refused instead of silently measuring one GPU.  The ranks here
+run ``tests/tools/bench_double.py`` = bench.py on the oracle-backed device double, shortlists over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DOUBLE = os.path.join(ROOT, "tests", "tools", "bench_double.py")
+SMALL = ["--N", "96", "--d", "3", "--M", "3000", "--steps", "1", "--warmup", "1", "--extras", "off",
+         "--cpu-baseline", "off"]
+
+
+def _launch(n, extra_args=(), env_extra=None, timeout=240):
+    """Run ``bench.launch_ranks`` in a fresh interpreter (it installs signal handlers and prints the relayed line)."""
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch_ranks(%d, %r, script=%r, timeout=%r))"
+            % (ROOT, n, ["--gpus", str(n)] + SMALL + list(extra_args), DOUBLE, timeout))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=timeout + 120)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_self_launched_ranks_print_one_line_for_n_gpus(n):
+    out = _launch(n, ["--allow-gloo"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == n and res["config"]["comm"] == "gloo-fallback" and res["config"]["rccl_ranks"] == 0
+    assert res["config"]["sharding"] == f"candidates x{n}" and res["config"]["M_total"] == 3000
+    assert res["config"]["M_per_gpu"] == -(-3000 // n) and res["config"]["N_train_per_step"] == [96]
+    assert res["value"] > 0 and res["scaling"] == "strong"
+
+
+def test_without_rccl_the_ranks_exit_3_unless_gloo_is_allowed():
+    out = _launch(2)
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    assert not [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert "no RCCL communicator" in out.stderr
+
+
+def test_a_failing_rank_ends_the_group_with_its_code():
+    out = _launch(2, ["--allow-gloo"], {"GPRY_BENCH_DOUBLE_FAIL_RANK": "1", "GPRY_BENCH_FAIL_GRACE": "3"})
+    assert out.returncode == 7, (out.returncode, out.stderr[-2000:])
+    assert not out.stdout.strip()
+
+
+def test_the_watchdog_ends_a_hanging_run():
+    out = _launch(2, ["--allow-gloo"], {"GPRY_BENCH_DOUBLE_HANG_RANK": "1"}, timeout=40)
+    assert out.returncode != 0 and "time limit" in out.stderr
+    assert not out.stdout.strip()
+
+
+def test_more_gpus_than_visible_is_refused(monkeypatch, capsys):
+    import bench
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GPRY_HIP_DEVICE_WRAP"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 1)
+    called = []
+    monkeypatch.setattr(bench, "launch_ranks", lambda n, argv, **kw: called.append((n, argv)) or 0)
+    for wl in (["--workload", "cycle"], ["--workload", "farm"], ["--workload", "farm", "--mode", "group"]):
+        with pytest.raises(SystemExit) as e:
+            bench.main(["--gpus", "8"] + wl)
+        assert e.value.code == 2 and "only 1 GPU(s) are visible" in capsys.readouterr().err
+    assert not called
+    # development boxes: ranks may share a device when asked to
+    monkeypatch.setenv("GPRY_HIP_DEVICE_WRAP", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2", "--steps", "3"])
+    assert e.value.code == 0 and called == [(2, ["--gpus", "2", "--steps", "3"])]
+    # a launcher that disagrees with --gpus is an error, not a silent 1-GPU line
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4"])
+    assert e.value.code == 2

@@ -69,6 +69,64 @@ def test_concurrent_restarts_select_the_sequential_optimum(monkeypatch):
         np.testing.assert_array_equal(out[n_ctx][3], out["1"][3])
 
 
+def test_fit_contexts_are_dealt_out_over_the_devices_of_the_process(monkeypatch):
+    """``fit_context_devices``: own device first, GPUs round-robin (the first restarts land on distinct
+    GPUs), ``GPRY_HIP_FIT_CONTEXTS`` contexts per GPU, never more contexts than restarts; one rank of a
+    multi-process launch stays on its own GPU; an explicit list (repeats allowed) is taken as it is."""
+    from gpry_amd import gpr as G
+    from gpry_amd import _lib
+    for var in ("GPRY_HIP_DEVICES", "WORLD_SIZE", "GPRY_HIP_FIT_CONTEXTS"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(_lib, "device_count", lambda: 8)
+    assert G.fit_context_devices(0, 32) == [0, 1, 2, 3, 4, 5, 6, 7] * 3
+    assert G.fit_context_devices(2, 5) == [2, 0, 1, 3, 4]
+    assert G.fit_context_devices(0, 1) == [0]
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+    assert G.fit_context_devices(0, 32) == list(range(8))
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "2")
+    monkeypatch.setenv("GPRY_HIP_DEVICES", "4,5")
+    assert G.fit_context_devices(5, 32) == [5, 4, 5, 4]
+    monkeypatch.setenv("GPRY_HIP_DEVICES", "none")
+    assert G.fit_context_devices(3, 32) == [3, 3]
+    monkeypatch.delenv("GPRY_HIP_DEVICES")
+    monkeypatch.setenv("WORLD_SIZE", "8")                 # one process per GPU: the ranks farm among themselves
+    assert G.fit_context_devices(6, 32) == [6, 6]
+    monkeypatch.delenv("WORLD_SIZE")
+    assert G.fit_context_devices(0, 32, spec=[0, 0, 1, 1, 1]) == [0, 0, 1, 1, 1]
+    monkeypatch.setattr(_lib, "device_count", lambda: 1)
+    assert G.fit_context_devices(0, 32) == [0, 0]
+
+
+@pytest.mark.parametrize("devices", [[0, 1], [0, 1, 2, 3, 4, 5, 6, 7], [0, 0, 1, 1, 2]])
+def test_restart_farm_over_several_devices_in_one_process_equals_the_sequential_fit(monkeypatch, devices):
+    """BASELINE configs[4] in ONE process (an unmodified ``Runner`` without mpi4py, gpry/run.py:315-325,
+    1238-1293): the restarts of a fit spread over the contexts of ``fit_devices`` give the start points,
+    optima, selected theta, LML and evaluation count of the reference's sequential loop, and every context
+    is created on the device it was dealt."""
+    g = load_golden("fit")
+    p = "f6_k3_"
+    X, y = g[p + "X"], g[p + "y"]
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+    seq = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=9, random_state=11)
+    seq.append_to_data(X[:60], y[:60], fit_gpr=True)
+    assert not seq._fit_devs
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "3")
+    par = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=9, random_state=11)
+    par.fit_devices = devices
+    par.append_to_data(X[:60], y[:60], fit_gpr=True)
+    assert [par.device.device] + [idx for idx, _ in par._fit_devs] == devices
+    assert all(dv.device == idx for idx, dv in par._fit_devs)
+    assert par.fit_stats["devices"] == devices and sum(par.fit_stats["evals_per_context"]) > 0
+    np.testing.assert_array_equal(par.kernel_.theta, seq.kernel_.theta)
+    assert par.log_marginal_likelihood_value_ == seq.log_marginal_likelihood_value_
+    assert par.n_eval_loglike == seq.n_eval_loglike
+    np.testing.assert_array_equal(par.predict(g[p + "Xc"]), seq.predict(g[p + "Xc"]))
+    # a second fit re-uses the contexts
+    ids = [id(dv) for _, dv in par._fit_devs]
+    par.append_to_data(X[60:], y[60:], fit_gpr=True)
+    assert [id(dv) for _, dv in par._fit_devs] == ids
+
+
 def test_host_append_fixed_theta_reproduces_reference_factor():
     """F8 through the host mirror: frozen theta, re-fitted pre-processors, lazy factor."""
     from gpry_amd.kernels import clone

@@ -71,6 +71,42 @@ def test_concurrent_restarts_select_the_sequential_optimum_on_the_device(monkeyp
     np.testing.assert_array_equal(out["3"][3], out["1"][3])
 
 
+@pytest.mark.parametrize("k", [2, 8])
+def test_restart_farm_over_the_devices_of_one_process_equals_the_sequential_fit(monkeypatch, k):
+    """VERDICT r02 #3 / BASELINE configs[4] in ONE process: the restarts of a fit spread over ``fit_devices``
+    (here k contexts on device 0 -- on an 8-GPU node ``fit_context_devices`` deals them out over all GPUs, 3 per
+    GPU) select the theta, LML and evaluation count of the reference's sequential loop bit for bit, and the F6
+    golden optimum of the reference itself within the tolerances of ``test_f6_fit_full_and_simple_vs_reference``."""
+    g = load_golden("fit")
+    p = "f6_k3_"
+    X, y, Xc = g[p + "X"], g[p + "y"], g[p + "Xc"]
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+    seq = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=4, random_state=3)
+    seq.append_to_data(X[:60], y[:60], fit_gpr=True)
+    assert not seq._fit_devs
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "3")
+    par = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=4, random_state=3)
+    par.fit_devices = [0] * k
+    par.append_to_data(X[:60], y[:60], fit_gpr=True)
+    assert par.fit_stats["contexts"] == min(k, 4) and len(par._fit_devs) == min(k, 4) - 1
+    np.testing.assert_array_equal(par.kernel_.theta, seq.kernel_.theta)
+    assert par.log_marginal_likelihood_value_ == seq.log_marginal_likelihood_value_
+    assert par.n_eval_loglike == seq.n_eval_loglike
+    np.testing.assert_array_equal(par.predict(Xc), seq.predict(Xc))
+    assert abs(par.log_marginal_likelihood_value_ - g[p + "lml_full"]) < 1e-5
+    np.testing.assert_allclose(par.kernel_.theta, g[p + "theta_full"], rtol=1e-3, atol=1e-3)
+    # more restarts than contexts, and a larger set: 12 restarts over 8 contexts
+    seq = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=12, random_state=5)
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+    seq.append_to_data(X, y, fit_gpr=True)
+    par = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=12, random_state=5)
+    par.fit_devices = [0] * k
+    par.append_to_data(X, y, fit_gpr=True)
+    np.testing.assert_array_equal(par.kernel_.theta, seq.kernel_.theta)
+    assert par.log_marginal_likelihood_value_ == seq.log_marginal_likelihood_value_
+    assert par.n_eval_loglike == seq.n_eval_loglike and sum(par.fit_stats["evals_per_context"]) == par.n_eval_loglike
+
+
 def test_concurrent_fit_is_reproducible_over_many_runs(monkeypatch):
     """The same comparison thirty times over (tests/tools/stress_concurrent_fit.py runs hundreds): a race in the
     hand-over of LML results shows up as a different evaluation count in a few percent of the fits -- host-side

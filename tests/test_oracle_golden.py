@@ -53,6 +53,34 @@ def test_f3_lml_and_gradient(kid):
         float(g[f"f3_k{kid}_lml_nograd"]), rel=1e-13)
 
 
+@pytest.mark.parametrize("kid", [0, 1, 2, 3])
+@pytest.mark.parametrize("block", [7, 256])
+def test_f3_blocked_gradient_restatement_vs_reference(kid, block):
+    """The memory-light form used for the full-size objective tests (N = 8192 needs 56 GB as (N, N, 1+d)
+    tensors): same value and gradient as the reference's einsum (F3 goldens) and as the einsum restatement,
+    on ragged row blocks and on a duplicated training row (the r = 0 branch of Matern-1/2)."""
+    g = load_golden("factor_lml")
+    X_, y_, alpha = g[f"f2_k{kid}_X_"], g[f"f2_k{kid}_y_"], g[f"f2_k{kid}_alpha"]
+    th = g[f"f3_k{kid}_theta"]
+    lml, grad = orc.log_marginal_likelihood_blocked(X_, y_, alpha, th, kid, block=block)
+    assert abs(lml - g[f"f3_k{kid}_lml"]) <= 1e-12 * abs(g[f"f3_k{kid}_lml"])
+    np.testing.assert_allclose(grad, g[f"f3_k{kid}_grad"], rtol=1e-9, atol=1e-10)
+    rng = np.random.default_rng(kid)
+    X2 = rng.uniform(size=(150, 5))
+    X2[17] = X2[3]
+    y2 = rng.standard_normal(150)
+    th2 = np.log(np.array([3.0, 0.3, 0.5, 0.2, 0.9, 0.4]))
+    a = orc.log_marginal_likelihood(X2, y2, np.full(150, 1e-3), th2, kid, eval_gradient=True)
+    b = orc.log_marginal_likelihood_blocked(X2, y2, np.full(150, 1e-3), th2, kid, block=block)
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0])
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-10, atol=1e-10)
+    # non-PD convention
+    g3 = load_golden("factor_lml")
+    lm, gr = orc.log_marginal_likelihood_blocked(g3["f3_nonpd_X_"], g3["f3_nonpd_y_"], np.zeros(len(g3["f3_nonpd_y_"])),
+                                                 g3["f3_nonpd_theta"], 0)
+    assert lm == -np.inf and not gr.any()
+
+
 def test_f3_non_pd_convention():
     g = load_golden("factor_lml")
     X_, y_, th = g["f3_nonpd_X_"], g["f3_nonpd_y_"], g["f3_nonpd_theta"]
