@@ -58,6 +58,7 @@ SIGNATURES = {
     "gpry_append_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _P(C.c_int)]),
     "gpry_lml": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_double), _vp, _P(C.c_int)]),
     "gpry_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "gpry_debug_serve_stats": (C.c_int, [_vp, _P(C.c_int64), _P(C.c_int64)]),
     "gpry_predict_grad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     "gpry_predict_grad_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
     "gpry_set_gates": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_int, _vp]),
@@ -304,6 +305,12 @@ class Device:
             self._check(self._lib.gpry_predict(self._h, _ptr(X), M, _ptr(mask), _ptr(mean),
                                                _ptr(std)), "gpry_predict")
         return (mean, std) if return_std else mean
+
+    def serve_stats(self):
+        """(launches, requests) of the resident predict kernel that answers small mean-only ``predict`` calls."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.gpry_debug_serve_stats(self._h, C.byref(a), C.byref(b)), "gpry_debug_serve_stats")
+        return a.value, b.value
 
     def set_gates(self, sv=None, coef=None, gamma=0.0, intercept=0.0, positive_is_finite=True,
                   trust_bounds=None):

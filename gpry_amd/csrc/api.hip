@@ -95,6 +95,7 @@ extern "C" {
 
 int gpry_kernel_train(gpry_ctx* ctx, int add_alpha, double* K_out) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_kernel_train: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     GPRY_TRY(require_model(ctx, false));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(launch_scale_train(ctx));
@@ -110,6 +111,7 @@ int gpry_kernel_train(gpry_ctx* ctx, int add_alpha, double* K_out) {
 
 int gpry_kernel_cross(gpry_ctx* ctx, const double* Xc_, int64_t M, double* K_out) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_kernel_cross: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     GPRY_TRY(require_model(ctx, false));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return 0;
@@ -134,6 +136,7 @@ int gpry_kernel_cross(gpry_ctx* ctx, const double* Xc_, int64_t M, double* K_out
 
 int gpry_factorize(gpry_ctx* ctx, int* info) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_factorize: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     GPRY_TRY(require_model(ctx, false));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->factor_valid = false;
@@ -163,6 +166,7 @@ int gpry_factorize(gpry_ctx* ctx, int* info) {
 
 int gpry_get_factor(gpry_ctx* ctx, double* L, double* V, double* alpha_) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_get_factor: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int64_t N = ctx->N;
@@ -185,6 +189,7 @@ int gpry_get_factor(gpry_ctx* ctx, double* L, double* V, double* alpha_) {
 
 int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, double* grad, int* info) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_lml: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     if (ctx->N <= 0) return gpry_fail(ctx, -1, "no training set (call gpry_set_train)");
     if (!theta || !lml || (want_grad && !grad)) return gpry_fail(ctx, -1, "lml: theta, lml and (with want_grad) grad must not be NULL");
     for (int k = 0; k <= ctx->d; k++)
@@ -529,6 +534,23 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return 0;
     if (!X) return gpry_fail(ctx, -1, "predict: X is NULL");
+    if (!std && M <= GPRY_SERVE_MAXM && ctx->opt_predict_serve && ctx->opt_predict_small > 0) {
+        // Latency path of the point-by-point callers (gpry/gp_acquisition.py:766-771, gpry/mc.py:387-391): no kernel
+        // launch, the request goes to the resident kernel (server.hip) -- same slices, same sums, same bits as the
+        // one-launch path below.
+        double part[GPRY_SERVE_MAXM * 8];
+        int nsplit = 1;
+        GPRY_TRY(serve_predict_mean(ctx, X, M, part, &nsplit));
+        for (int64_t m = 0; m < M; m++) {
+            double mu_ = 0.0;
+            for (int sidx = 0; sidx < nsplit; sidx++) mu_ += part[m * nsplit + sidx];
+            double y = fmin(mu_ * ctx->tf.y_std + ctx->tf.y_mean, ctx->tf.clip_hi);
+            if (mask && mask[m]) y = -INFINITY;
+            mean[m] = y;
+        }
+        return 0;
+    }
+    GPRY_TRY(serve_stop(ctx));
     if (!std && M <= ctx->opt_predict_small) {   // (predict_small = 0 switches both small-batch paths off)
         // Latency path (samplers call this per point, gpry/gp_acquisition.py:769-793): the points,
         // the mask and the result live in one pinned host buffer that the kernel reads and
@@ -630,6 +652,7 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
 int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgrad, double* mean_grad,
                       double* kinvk_grad) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_predict_grad: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     GPRY_TRY(require_model(ctx, want_kinv || mean_grad != nullptr));   // kgrad alone needs no factor
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!x) return gpry_fail(ctx, -1, "predict_grad: x is NULL");
@@ -680,6 +703,7 @@ __global__ __launch_bounds__(256) void colsumsq_kernel(const double* __restrict_
 int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_kinv, double* mean, double* std,
                             double* mean_grad, double* kinvk_grad) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_predict_grad_batch: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (m <= 0) return 0;
@@ -772,6 +796,7 @@ int gpry_sweep_fetch(gpry_ctx* ctx, int64_t M, double* y_all, double* sigma_all,
 int gpry_set_gates(gpry_ctx* ctx, const double* sv, const double* coef, int64_t n_sv, double gamma,
                    double intercept, int positive_is_finite, const double* trust_bounds) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_set_gates: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->d <= 0) return gpry_fail(ctx, -1, "set_gates before set_train");
     if (n_sv < 0 || (n_sv > 0 && (!sv || !coef))) return gpry_fail(ctx, -1, "set_gates: bad support vectors");
@@ -802,6 +827,7 @@ int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* 
                       double baseline, double sigma_n, double* y_all, double* sigma_all, double* acq_all,
                       int64_t* n_nan) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_sweep_logexp: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return gpry_fail(ctx, -1, "sweep: M must be > 0");
@@ -1122,6 +1148,7 @@ int gpry_kb_reset(gpry_ctx* ctx) {
 
 int gpry_kb_register(gpry_ctx* ctx, const double* X, int64_t m, int64_t* first, double* var0) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_kb_register: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (m <= 0) { if (first) *first = ctx->kb_n; return 0; }
@@ -1235,6 +1262,7 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
                                int K, int a_trans, int b_trans, int epi, int kmode, int lower_only,
                                int tile_map) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_debug_gemm: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     if (!A || !B || !C) return gpry_fail(ctx, -1, "debug_gemm: A, B and C must not be NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M % 64 || N % 64 || K % 64) return gpry_fail(ctx, -1, "debug_gemm: dims must be multiples of 64");

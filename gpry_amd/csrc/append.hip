@@ -210,6 +210,7 @@ extern "C" int gpry_append_rows(gpry_ctx* ctx, const double* Xnew_, const double
                                 int64_t k, int* info) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_append_rows: ctx is NULL");
     if (info) *info = 0;
+    GPRY_TRY(serve_stop(ctx));
     if (ctx->N <= 0 || !ctx->have_theta || !ctx->factor_valid)
         return gpry_fail(ctx, -1, "append_rows: no factorised model to extend (call gpry_factorize)");
     if (k <= 0) return 0;

@@ -143,6 +143,11 @@ struct gpry_ctx {
     int opt_factor_pipeline_min = 4096;   // from this Np on (neutral at 3072, a loss at 2048: tools/ab_factor_pipeline.py)
     void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
 
+    // resident predict kernel (server.hip)
+    void* srv = nullptr;
+    int opt_predict_serve = 1;         // mean-only gpry_predict of <= 8 points goes through the resident kernel
+    int64_t opt_serve_idle_us = 2000;  // the kernel leaves after this long without a request
+
     // host pinned staging
     void* hpin = nullptr; void* hpin_dev = nullptr; int64_t hpin_cap = 0;   // host / device view of the same buffer
 
@@ -288,6 +293,13 @@ int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, doub
 int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np,
                     double* out2_dev, double* host_res, int info_at);   // host_res: as above, value-only evaluation
 int rocsolver_potrf_trtri(gpry_ctx* ctx, double* A, double* V, int64_t Np, int want_v);
+
+// ---- server.hip: resident predict kernel --------------------------------------------
+int serve_stop(gpry_ctx* ctx);          // no-op when nothing is running; every model-changing entry point calls it first
+void serve_free(gpry_ctx* ctx);
+void serve_stats(gpry_ctx* ctx, int64_t* launches, int64_t* requests);
+int serve_predict_mean(gpry_ctx* ctx, const double* X, int64_t M, double* part, int* nsplit_out);
+#define GPRY_SERVE_MAXM 8
 
 int ensure_capacity(gpry_ctx* ctx, int64_t N, int d);
 int ensure_pinned(gpry_ctx* ctx, int64_t bytes);

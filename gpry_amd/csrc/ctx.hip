@@ -191,6 +191,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     timers_collect(ctx);
+    serve_free(ctx);
     trtri_plan_free(ctx);
     trtri_pipe_free(ctx);
     overlap_plan_free(ctx);
@@ -221,6 +222,12 @@ int gpry_ctx_sync(gpry_ctx* ctx) {
 
 int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_ctx_set_option: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
+    if (!strcmp(key, "predict_serve")) { ctx->opt_predict_serve = (int)value; return 0; }
+    if (!strcmp(key, "serve_idle_us")) {
+        if (value < 10 || value > 1000000) return gpry_fail(ctx, -1, "serve_idle_us must be in 10..1000000");
+        ctx->opt_serve_idle_us = value; return 0;
+    }
     if (!strcmp(key, "chol")) { ctx->opt_chol = (int)value; return 0; }
     if (!strcmp(key, "sweep_chunk")) {
         if (value < 128) return gpry_fail(ctx, -1, "sweep_chunk must be >= 128");
@@ -278,6 +285,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
 int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const double* alpha,
                    int64_t N, int d) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_set_train: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     if (N <= 0 || d <= 0) return gpry_fail(ctx, -1, "set_train: need N > 0 and d > 0 (got %lld, %d)", (long long)N, d);
     if (d > GPRY_MAX_DIM) return gpry_fail(ctx, -1, "set_train: d=%d > GPRY_MAX_DIM=%d is not supported by this build", d, GPRY_MAX_DIM);
     if (!X_ || !y_ || !alpha) return gpry_fail(ctx, -1, "set_train: X_, y_ and alpha must not be NULL");
@@ -298,6 +306,7 @@ int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const doub
 
 int gpry_set_theta(gpry_ctx* ctx, int kernel_id, const double* theta) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_set_theta: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     if (kernel_id < 0 || kernel_id > 3) return gpry_fail(ctx, -1, "unknown kernel id %d", kernel_id);
     if (ctx->d <= 0) return gpry_fail(ctx, -1, "set_theta before set_train");
     if (!theta) return gpry_fail(ctx, -1, "set_theta: theta is NULL");
@@ -314,6 +323,7 @@ int gpry_set_theta(gpry_ctx* ctx, int kernel_id, const double* theta) {
 
 int gpry_set_affine(gpry_ctx* ctx, const gpry_affine* tf) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_set_affine: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
     if (!tf) return gpry_fail(ctx, -1, "set_affine: null");
     ctx->tf = *tf;
     return 0;

@@ -1,0 +1,191 @@
+// Kernel algebra shared by the covariance kernels (kernel_build.hip) and the resident predict kernel (server.hip):
+// parameter blocks, correlation functions restated from sklearn:kernels.py:1553-1580 (RBF), :1708-1768 (Matern),
+// :1239-1291 (Constant), and the per-slice posterior mean of one point.
+#pragma once
+#include "common.h"
+
+struct KernParams {
+    double C;
+    int d, dpad, has_aff;
+    int64_t N;
+};
+struct AffParams {
+    double ls[GPRY_MAX_DIM];     // length scales (unused slots = 1)
+    double lo[GPRY_MAX_DIM];
+    double span[GPRY_MAX_DIM];
+};
+
+#define SQRT3 1.7320508075688772
+#define SQRT5 2.23606797749979
+
+template <int KID>
+__device__ __forceinline__ double corr_r2(double r2) {
+    if (KID == GPRY_RBF) return exp(-0.5 * r2);
+    if (KID == GPRY_MATERN12) return exp(-sqrt(r2));
+    if (KID == GPRY_MATERN32) { double t = sqrt(r2) * SQRT3; return (1.0 + t) * exp(-t); }
+    double t = sqrt(r2) * SQRT5;
+    return (1.0 + t + t * t * (1.0 / 3.0)) * exp(-t);
+}
+// Straight-line sqrt / exp for the cross-kernel panel (4.1e9 evaluations per 1e6 candidates at
+// N = 4096: the panel build is VALU-bound, and libm's versions carry range checks, denormal
+// scaling and ~10 register moves each).  Valid for the arguments that occur here: x >= 0 not
+// denormal; t >= 0.  Accuracy ~1 ulp.
+__device__ __forceinline__ double fast_sqrt_pos(double x) {
+    const double s = __builtin_amdgcn_rsq(x);
+    double g = x * s, h = 0.5 * s;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    double e = fma(-g, g, x);
+    g = fma(e, h, g);
+    e = fma(-g, g, x);
+    g = fma(e, h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+__device__ __forceinline__ double fast_exp_neg(double t) {      // exp(-t)
+    const double y = -t;
+    const double n = __builtin_rint(y * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, y);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    // exp(r), |r| <= ln2/2: Taylor to degree 13 (truncation 4e-18 relative)
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double nn = fmax(n, -1100.0);      // exp(-t) underflows to 0 through ldexp
+    return __builtin_ldexp(p, (int)nn);
+}
+template <int KID>
+__device__ __forceinline__ double corr_r2_fast(double r2) {
+    if (KID == GPRY_RBF) return fast_exp_neg(0.5 * r2);
+    if (KID == GPRY_MATERN12) return fast_exp_neg(fast_sqrt_pos(r2));
+    if (KID == GPRY_MATERN32) { double t = fast_sqrt_pos(r2) * SQRT3; return (1.0 + t) * fast_exp_neg(t); }
+    double t = fast_sqrt_pos(r2) * SQRT5;
+    return (1.0 + t + t * t * (1.0 / 3.0)) * fast_exp_neg(t);
+}
+// returns k(r) in *kval and h with d k / d log l_k = h * D_k   (both without the factor C)
+template <int KID>
+__device__ __forceinline__ double corr_and_h(double r2, double* kval) {
+    if (KID == GPRY_RBF) { double e = fast_exp_neg(0.5 * r2); *kval = e; return e; }
+    if (KID == GPRY_MATERN12) {
+        double r = fast_sqrt_pos(r2); double e = fast_exp_neg(r); *kval = e;
+        return r != 0.0 ? e / r : 0.0;
+    }
+    if (KID == GPRY_MATERN32) {
+        double t = fast_sqrt_pos(r2) * SQRT3; double e = fast_exp_neg(t);
+        *kval = (1.0 + t) * e;
+        return 3.0 * e;
+    }
+    double t = fast_sqrt_pos(r2) * SQRT5; double e = fast_exp_neg(t);
+    *kval = (1.0 + t + t * t * (1.0 / 3.0)) * e;
+    return (5.0 / 3.0) * (t + 1.0) * e;
+}
+
+static KernParams make_kp(gpry_ctx* ctx) {
+    KernParams kp;
+    kp.C = exp(ctx->theta[0]);
+    kp.d = ctx->d; kp.dpad = ctx->dpad;
+    kp.has_aff = ctx->tf.has_x_affine; kp.N = ctx->N;
+    return kp;
+}
+static AffParams make_ap(gpry_ctx* ctx, bool use_affine) {
+    AffParams ap;
+    for (int k = 0; k < GPRY_MAX_DIM; k++) {
+        // sklearn divides by the length scale (x / l); we keep the division, not a reciprocal
+        // multiply, so that scaled coordinates round identically.
+        ap.ls[k] = k < ctx->d ? exp(ctx->theta[1 + k]) : 1.0;
+        ap.lo[k] = (use_affine && k < ctx->d) ? ctx->tf.x_lo[k] : 0.0;
+        ap.span[k] = (use_affine && k < ctx->d) ? ctx->tf.x_span[k] : 1.0;
+    }
+    return ap;
+}
+
+#define DISPATCH_KID(kid, CALL)                         \
+    switch (kid) {                                      \
+        case GPRY_RBF: { CALL(GPRY_RBF); break; }       \
+        case GPRY_MATERN12: { CALL(GPRY_MATERN12); break; } \
+        case GPRY_MATERN32: { CALL(GPRY_MATERN32); break; } \
+        default: { CALL(GPRY_MATERN52); break; }        \
+    }
+
+
+// ------------------------------------------------------------------------------------
+// One slice of the posterior mean of ONE point: sum over the training rows [row_lo, row_lo + rows_per_split) of
+// alpha_j C k(x, X_j) in transformed units, by one workgroup of 256 threads (result valid in thread 0).  `x`: the d
+// raw coordinates of the point (any address space the caller can read: mapped host memory, LDS, global).  Shared by
+// the one-launch kernel (predict_mean_small_kernel) and the resident one (server.hip): whichever of the two serves
+// a call, the bits are the same.
+#define MEAN_SLICE_CH 4096        // rows per LDS chunk
+template <int DP, int KID>
+__device__ __forceinline__ double mean_slice(const double* x, const double* __restrict__ Xs, const double* __restrict__ alpha_,
+                                             int64_t row_lo, int64_t rows_per_split, const KernParams& kp, const AffParams& ap,
+                                             double* r2s /*[MEAN_SLICE_CH]*/, double* red /*[256]*/) {
+    constexpr int P = DP / 2;             // lanes per training row: one 16-byte piece each
+    constexpr int CH = MEAN_SLICE_CH;
+    const int t = threadIdx.x, sub = t % P, rloc = t / P;
+    // this lane's two scaled coordinates of the point
+    double x0 = 0.0, x1 = 0.0;
+    {
+        const int k0 = 2 * sub, k1 = 2 * sub + 1;
+        if (k0 < kp.d) { double v = x[k0]; if (kp.has_aff) v = (v - ap.lo[k0]) / ap.span[k0]; x0 = v / ap.ls[k0]; }
+        if (k1 < kp.d) { double v = x[k1]; if (kp.has_aff) v = (v - ap.lo[k1]) / ap.span[k1]; x1 = v / ap.ls[k1]; }
+    }
+    const bool piece_ok = 2 * sub < kp.dpad;
+    double acc = 0.0;
+    const int64_t row_hi = (row_lo + rows_per_split < kp.N) ? row_lo + rows_per_split : kp.N;
+    for (int64_t c0 = row_lo; c0 < row_hi; c0 += CH) {
+        const int nrow = (int)((row_hi - c0 < CH) ? row_hi - c0 : CH);
+        // phase 1: squared distances, rows read as whole cache lines (P lanes per row); eight
+        // passes are loaded back to back so that their memory latencies overlap
+        constexpr int RP = 256 / P;       // rows per pass
+        for (int r0 = 0; r0 < nrow; r0 += 8 * RP) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int row = r0 + u * RP + rloc;
+                v[u] = make_double2(0.0, 0.0);
+                if (row < nrow && piece_ok)
+                    v[u] = *reinterpret_cast<const double2*>(Xs + (c0 + row) * kp.dpad + 2 * sub);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int row = r0 + u * RP + rloc;
+                const double d0 = x0 - v[u].x, d1 = x1 - v[u].y;
+                double part = piece_ok ? fma(d1, d1, d0 * d0) : 0.0;
+#pragma unroll
+                for (int o = 1; o < P; o <<= 1) part += __shfl_xor(part, o);
+                if (sub == 0 && row < nrow) r2s[row] = part;
+            }
+        }
+        __syncthreads();
+        // phase 2: one row per lane, four independent chains
+        for (int j0 = t; j0 < nrow; j0 += 1024) {
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int j = j0 + 256 * q;
+                v[q] = j < nrow ? alpha_[c0 + j] * (kp.C * corr_r2_fast<KID>(r2s[j])) : 0.0;
+            }
+            acc += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        __syncthreads();
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    const double out = red[0];
+    __syncthreads();          // `red` may be reused by the caller's next point
+    return out;
+}

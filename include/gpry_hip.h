@@ -85,6 +85,9 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                               launches (default 5632; 0 = off)
  *              "topk_host" = largest pool that gpry_sweep_topk selects on the host from one kernel's records
  *                            (default 16384; 0 = always the device radix select)
+ *              "predict_serve" = 0/1 mean-only gpry_predict of <= 8 points is answered by a RESIDENT kernel (no
+ *                                launch per call; default 1), "serve_idle_us" = how long that kernel waits for the
+ *                                next request before it leaves (default 2000)
  * Everything else is an A/B switch of the measurements quoted in DESIGN.md (defaults are the
  * measured best): "sweep_dma" 0..3, "sweep_persist", "sweep_overlap", "sweep_tilemap", "sweep_colouter", "chol_outer",
  * "chol_lookahead", "chol_overlap_max", "chol_caps", "split_k", "gemm_dma", "syrk_lds", "lauum_lds", "lauum_split",
@@ -143,6 +146,13 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml,
  * clipped (clip_hi) and masked exactly as predict() does.  std may be NULL. */
 int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
                  double* mean, double* std);
+/* Mean-only calls of <= 8 points -- the closures the nested samplers / MCMC call once per point
+ * (gpry/gp_acquisition.py:766-771, 784-793; gpry/mc.py:387-391) -- do not launch a kernel: a resident kernel on
+ * a stream of its own answers them through a mailbox in pinned host memory and leaves on its own when no request
+ * arrives for "serve_idle_us".  Every other entry point stops it first (it holds the model of its launch), so the
+ * caller sees nothing but the latency.  Same bits as the one-launch path ("predict_serve" = 0).
+ * gpry_debug_serve_stats: launches of that kernel / requests it answered since the context was created. */
+int gpry_debug_serve_stats(gpry_ctx* ctx, int64_t* launches, int64_t* requests);
 
 /* ---- f3: x-gradients for one point (gpry/gpr.py:1236-1266) ------------------------- */
 /* x: d doubles, raw/transformed as in gpry_predict.  With G[j][k] = d k(x, X_j) / d x_k in the
