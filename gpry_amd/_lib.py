@@ -159,6 +159,8 @@ def make_affine(x_lo=None, x_span=None, y_mean=0.0, y_std=1.0, clip_hi=np.inf):
 class Device:
     """One ``gpry_ctx``: the device-resident GP state of one GPU."""
 
+    applies_gates_in_predict = True     # option "predict_gates": gpry_predict ORs the gates of set_gates into the mask
+
     def __init__(self, device=0):
         self._lib = load_library()
         self._h = C.c_void_p()
@@ -295,8 +297,24 @@ class Device:
 
     # -- predict / sweep ------------------------------------------------------------
     def predict(self, X, return_std=False, mask=None):
+        if not return_std and mask is None and 0 < len(X) <= 8:
+            # the point-by-point callers (nested samplers, MCMC): persistent buffers and cached pointers -- building
+            # four ctypes pointers and two arrays per call cost more than the device round trip
+            fast = getattr(self, "_small", None)
+            if fast is None or fast[0].shape[1] != self.d:
+                xin, out = np.zeros((8, max(self.d, 1))), np.zeros(8)
+                fast = self._small = (xin, out, C.c_void_p(xin.ctypes.data), C.c_void_p(out.ctypes.data))
+            xin, out, pin, pout = fast
+            M = len(X)
+            xin[:M] = X            # (raises on a shape mismatch; converts dtype / strides)
+            rc = self._lib.gpry_predict(self._h, pin, M, None, pout, None)
+            if rc != 0:
+                self._check(rc, "gpry_predict")
+            return out[:M].copy()
         X = _f64(X)
         M = X.shape[0]
+        if X.ndim != 2 or X.shape[1] != self.d:
+            raise ValueError(f"expected an array of shape (M, {self.d}), got {X.shape}")
         mean = np.empty(M)
         std = np.empty(M) if return_std else None
         if mask is not None:

@@ -539,18 +539,35 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         // launch, the request goes to the resident kernel (server.hip) -- same slices, same sums, same bits as the
         // one-launch path below.
         double part[GPRY_SERVE_MAXM * 8];
+        unsigned gbits[GPRY_SERVE_MAXM];
         int nsplit = 1;
-        GPRY_TRY(serve_predict_mean(ctx, X, M, part, &nsplit));
+        GPRY_TRY(serve_predict_mean(ctx, X, M, part, &nsplit, gbits));
         for (int64_t m = 0; m < M; m++) {
             double mu_ = 0.0;
             for (int sidx = 0; sidx < nsplit; sidx++) mu_ += part[m * nsplit + sidx];
             double y = fmin(mu_ * ctx->tf.y_std + ctx->tf.y_mean, ctx->tf.clip_hi);
-            if (mask && mask[m]) y = -INFINITY;
+            if ((mask && mask[m]) || gbits[m]) y = -INFINITY;
             mean[m] = y;
         }
         return 0;
     }
     GPRY_TRY(serve_stop(ctx));
+    // "predict_gates" = 1: the verdicts of gpry_set_gates are ORed into the caller's mask here as gpry_sweep_logexp
+    // does (the small paths below post-process on the host: they get a merged host mask; the panel paths run the
+    // gates kernel on their resident candidate buffers)
+    const bool dev_gates = ctx->gates_on && ctx->opt_predict_gates;
+    std::vector<uint8_t> merged;
+    if (dev_gates && M <= 4096) {
+        const int64_t xb = round_up(sizeof(double) * M * ctx->d, 256);
+        GPRY_TRY(ensure_pinned(ctx, xb + round_up(M, 256)));
+        char* h = (char*)ctx->hpin; char* hd = (char*)ctx->hpin_dev;
+        memcpy(h, X, sizeof(double) * M * ctx->d);
+        if (mask) memcpy(h + xb, mask, (size_t)M); else memset(h + xb, 0, (size_t)M);
+        GPRY_TRY(launch_gates(ctx, (const double*)hd, M, (uint8_t*)(hd + xb)));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        merged.assign((uint8_t*)(h + xb), (uint8_t*)(h + xb) + M);
+        mask = merged.data();
+    }
     if (!std && M <= ctx->opt_predict_small) {   // (predict_small = 0 switches both small-batch paths off)
         // Latency path (samplers call this per point, gpry/gp_acquisition.py:769-793): the points,
         // the mask and the result live in one pinned host buffer that the kernel reads and
@@ -642,7 +659,13 @@ int gpry_predict(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask,
         return 0;
     }
     GPRY_TRY(upload_candidates(ctx, X, M, mask));
-    GPRY_TRY(run_sweep(ctx, M, mask != nullptr, std != nullptr, false, 0.0, 0.0, 0.0, true));
+    bool have_mask = mask != nullptr;
+    if (dev_gates) {
+        if (!have_mask) HIP_TRY(ctx, hipMemsetAsync(ctx->dmask, 0, (size_t)M, ctx->stream));
+        GPRY_TRY(launch_gates(ctx, ctx->dXc, M, ctx->dmask));
+        have_mask = true;
+    }
+    GPRY_TRY(run_sweep(ctx, M, have_mask, std != nullptr, false, 0.0, 0.0, 0.0, true));
     HIP_TRY(ctx, hipMemcpyAsync(mean, ctx->dy_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
     if (std) HIP_TRY(ctx, hipMemcpyAsync(std, ctx->dsig_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

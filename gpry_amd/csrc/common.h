@@ -147,6 +147,7 @@ struct gpry_ctx {
     void* srv = nullptr;
     int opt_predict_serve = 1;         // mean-only gpry_predict of <= 8 points goes through the resident kernel
     int64_t opt_serve_idle_us = 2000;  // the kernel leaves after this long without a request
+    int opt_predict_gates = 0;         // 1: gpry_predict ORs the device gates (gpry_set_gates) into the caller's mask, as the sweep does
 
     // host pinned staging
     void* hpin = nullptr; void* hpin_dev = nullptr; int64_t hpin_cap = 0;   // host / device view of the same buffer
@@ -298,7 +299,7 @@ int rocsolver_potrf_trtri(gpry_ctx* ctx, double* A, double* V, int64_t Np, int w
 int serve_stop(gpry_ctx* ctx);          // no-op when nothing is running; every model-changing entry point calls it first
 void serve_free(gpry_ctx* ctx);
 void serve_stats(gpry_ctx* ctx, int64_t* launches, int64_t* requests);
-int serve_predict_mean(gpry_ctx* ctx, const double* X, int64_t M, double* part, int* nsplit_out);
+int serve_predict_mean(gpry_ctx* ctx, const double* X, int64_t M, double* part, int* nsplit_out, unsigned* gate_bits);
 #define GPRY_SERVE_MAXM 8
 
 int ensure_capacity(gpry_ctx* ctx, int64_t N, int d);

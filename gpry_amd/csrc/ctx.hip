@@ -224,6 +224,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_ctx_set_option: ctx is NULL");
     GPRY_TRY(serve_stop(ctx));
     if (!strcmp(key, "predict_serve")) { ctx->opt_predict_serve = (int)value; return 0; }
+    if (!strcmp(key, "predict_gates")) { ctx->opt_predict_gates = (int)value; return 0; }
     if (!strcmp(key, "serve_idle_us")) {
         if (value < 10 || value > 1000000) return gpry_fail(ctx, -1, "serve_idle_us must be in 10..1000000");
         ctx->opt_serve_idle_us = value; return 0;

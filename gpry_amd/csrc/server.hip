@@ -56,7 +56,51 @@ struct SrvArgs {
     unsigned long long gen;
     long long idle_ticks;      // wall_clock64 ticks (100 MHz) without a request before the kernel leaves
     int64_t rows_per_split;
+    // gates (gpry_set_gates) evaluated per point by the leader when the context applies them to gpry_predict
+    const double* gate_sv; const double* gate_coef; const double* gate_trust;
+    int64_t gate_nsv; double gate_gamma, gate_intercept;
+    int gate_positive_finite, gate_has_trust, gates;
 };
+
+// GPRY_MASK_* bits of one point (raw coordinates x in LDS): the trust box on the raw coordinates, the SVM decision
+// function sum_r coef_r exp(-gamma |x_ - sv_r|^2) + intercept on the transformed ones -- the per-pair arithmetic of
+// gates_kernel (kernel_build.hip), the support vectors dealt out over the 256 threads and their terms added by the
+// fixed LDS tree.  Valid in every thread.
+__device__ __forceinline__ unsigned srv_gate_bits(const double* x, const SrvArgs& a, const KernParams& kp, const AffParams& ap,
+                                                  double* red) {
+    const int t = threadIdx.x;
+    unsigned bits = 0;
+    if (a.gate_has_trust) {
+        for (int k = 0; k < kp.d; k++) {
+            const double v = x[k];
+            if (!(v >= a.gate_trust[2 * k] && v <= a.gate_trust[2 * k + 1])) bits |= GPRY_MASK_OUTSIDE_TRUST;
+        }
+    }
+    if (a.gate_nsv > 0) {
+        double part = 0.0;
+        for (int64_t r = t; r < a.gate_nsv; r += 256) {
+            double r2 = 0.0;
+            for (int k = 0; k < kp.d; k++) {
+                double v = x[k];
+                if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
+                const double df = v - a.gate_sv[r * kp.d + k];
+                r2 = fma(df, df, r2);
+            }
+            part = fma(a.gate_coef[r], fast_exp_neg(a.gate_gamma * r2), part);
+        }
+        red[t] = part;
+        __syncthreads();
+        for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+            if (t < s2) red[t] += red[t + s2];
+            __syncthreads();
+        }
+        const double dec = red[0] + a.gate_intercept;
+        __syncthreads();
+        const bool finite = a.gate_positive_finite ? dec > 0.0 : !(dec > 0.0);
+        if (!finite) bits |= GPRY_MASK_CLASSIFIED_INF;
+    }
+    return bits;
+}
 
 typedef unsigned int srv_u4 __attribute__((ext_vector_type(4)));
 
@@ -157,6 +201,10 @@ __global__ __launch_bounds__(256) void predict_server_kernel(SrvArgs a, KernPara
             const double v = mean_slice<DP, KID>(s_x + m * kp.d, a.Xs, a.alpha_, (int64_t)g * a.rows_per_split, a.rows_per_split,
                                                  kp, ap, r2s, red);
             if (t == 0) srv_store_sys(a.res + g * SRV_MAXM + m, (unsigned long long)__double_as_longlong(v), seq);
+            if (a.gates && g == 0) {
+                const unsigned bits = srv_gate_bits(s_x + m * kp.d, a, kp, ap, red);
+                if (t == 0) srv_store_sys(a.res + SRV_MAX_SLICES * SRV_MAXM + m, (unsigned long long)bits, seq);
+            }
         }
         last = seq;
         t_last = wall_clock64();
@@ -174,6 +222,7 @@ struct SrvHost {
     bool running = false;
     unsigned long long seq = 0, gen = 0;           // last sequence number posted / last generation launched
     int nsplit = 1;
+    int gates = 0;                                 // the running generation evaluates the gates of its launch
     int64_t launches = 0, requests = 0;
     // layout of the host buffer
     static constexpr size_t REQ = 0, RES = 8192, STATE = 8192 + 2048, BYTES = 16384;
@@ -195,7 +244,7 @@ static int srv_get(gpry_ctx* ctx, SrvHost** out) {
         ctx->srv = s;
         static_assert(sizeof(SrvUnit) == 16, "unit size");
         static_assert(sizeof(SrvUnit) * SRV_REQ_UNITS <= SrvHost::RES, "mailbox");
-        static_assert(sizeof(SrvUnit) * SRV_MAX_SLICES * SRV_MAXM <= 2048, "results");
+        static_assert(sizeof(SrvUnit) * (SRV_MAX_SLICES + 1) * SRV_MAXM <= 2048, "results (+ one row of gate bits)");
         if (hipHostMalloc((void**)&s->h, SrvHost::BYTES, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) {
             s->h = nullptr;
             return gpry_fail(ctx, -2, "serve: hipHostMalloc failed");
@@ -247,6 +296,11 @@ static int srv_launch(gpry_ctx* ctx, SrvHost* s) {
     a.seq0 = s->seq - 1;
     a.idle_ticks = (long long)ctx->opt_serve_idle_us * 100;       // wall_clock64: 100 MHz
     a.rows_per_split = round_up((ctx->N + nsplit - 1) / nsplit, 32);
+    a.gates = ctx->gates_on && ctx->opt_predict_gates;
+    s->gates = a.gates;
+    a.gate_sv = ctx->gate_sv; a.gate_coef = ctx->gate_coef; a.gate_trust = ctx->gate_trust;
+    a.gate_nsv = ctx->gate_nsv; a.gate_gamma = ctx->gate_gamma; a.gate_intercept = ctx->gate_intercept;
+    a.gate_positive_finite = ctx->gate_positive_finite; a.gate_has_trust = ctx->gate_has_trust;
 #define SV2(DP, KID) hipLaunchKernelGGL((predict_server_kernel<DP, KID>), dim3((unsigned)nsplit), dim3(256), 0, s->stream, a, kp, ap)
 #define SV4(KID) { if (ctx->d <= 4) SV2(4, KID); else if (ctx->d <= 8) SV2(8, KID); \
                    else if (ctx->d <= 16) SV2(16, KID); else SV2(32, KID); }
@@ -289,8 +343,9 @@ void serve_stats(gpry_ctx* ctx, int64_t* launches, int64_t* requests) {
 }
 
 // Mean of M <= SRV_MAXM points through the resident kernel; `part` receives M x nsplit partial sums in the layout of
-// the one-launch path (part[m * nsplit + slice]).  Returns 0 and *nsplit_out, or an error code.
-int serve_predict_mean(gpry_ctx* ctx, const double* X, int64_t M, double* part, int* nsplit_out) {
+// the one-launch path (part[m * nsplit + slice]).  gate_bits[m]: GPRY_MASK_* bits of the device gates (0 unless the
+// context applies them to gpry_predict).  Returns 0 and *nsplit_out, or an error code.
+int serve_predict_mean(gpry_ctx* ctx, const double* X, int64_t M, double* part, int* nsplit_out, unsigned* gate_bits) {
     if (M < 1 || M > SRV_MAXM) return gpry_fail(ctx, -1, "serve: 1..%d points per request", SRV_MAXM);
     SrvHost* s = nullptr;
     GPRY_TRY(srv_get(ctx, &s));
@@ -308,6 +363,9 @@ int serve_predict_mean(gpry_ctx* ctx, const double* X, int64_t M, double* part, 
         for (int g = 0; g < nsplit && done; g++)
             for (int m = 0; m < (int)M; m++)
                 if (rs[g * SRV_MAXM + m].stamp != seq) { done = false; break; }
+        if (done && s->gates)
+            for (int m = 0; m < (int)M; m++)
+                if (rs[SRV_MAX_SLICES * SRV_MAXM + m].stamp != seq) { done = false; break; }
         if (done) break;
         if (s->exited()) {
             // the generation left without this request (it was posted while the leader was leaving): the next one
@@ -331,6 +389,7 @@ int serve_predict_mean(gpry_ctx* ctx, const double* X, int64_t M, double* part, 
             const unsigned long long b = rs[g * SRV_MAXM + m].payload;
             memcpy(&part[m * nsplit + g], &b, 8);
         }
+    for (int m = 0; m < (int)M; m++) gate_bits[m] = s->gates ? (unsigned)rs[SRV_MAX_SLICES * SRV_MAXM + m].payload : 0u;
     *nsplit_out = nsplit;
     return 0;
 }

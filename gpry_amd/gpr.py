@@ -205,12 +205,15 @@ class GaussianProcessRegressor(_RM, _BE):
         self._host_factor = {}         # lazily fetched copies of L_, V_, alpha_
         self._kb = None                # Kriging-believer session on the current factor
         self._fit_devs = []            # extra contexts for concurrent optimiser restarts: (device index, context)
+        self._dev_gates = None         # (key, on_device) of the gates the model's context holds (_sync_gates)
 
     @property
     def device(self):
         if self._dev is None:
             kind = getattr(self, "_device_kind", None) or _lib.Device
             self._dev = kind(default_device_index())
+            if getattr(self._dev, "applies_gates_in_predict", False):
+                self._dev.set_option("predict_gates", 1)     # predict() leaves classifier / trust box to the device
         return self._dev
 
     def _invalidate(self, train=False):
@@ -799,20 +802,36 @@ class GaussianProcessRegressor(_RM, _BE):
         sinks = [self.device] if sinks is None else list(sinks)
         trust = None if (self.trust_bounds is None or ignore_trust_region) else self.trust_bounds
         params = None
+        ok = True
         if clf is not None:
             always_finite = getattr(clf, "all_finite", False) and getattr(clf, "y_train", None) is not None
             params = clf.device_params() if hasattr(clf, "device_params") else None
             if params is None and not always_finite:
                 for snk in sinks:
                     snk.set_gates()
-                return False
-        for snk in sinks:
+                ok = False
+        for snk in (sinks if ok else ()):
             if params is None:
                 snk.set_gates(trust_bounds=trust)
             else:
                 sv, coef, gamma, intercept, pos = params
                 snk.set_gates(sv, coef, gamma, intercept, pos, trust_bounds=trust)
-        return True
+        if any(snk is self._dev for snk in sinks):
+            self._dev_gates = (self._gates_key(ignore_trust_region), ok)
+        return ok
+
+    def _gates_key(self, ignore_trust_region):
+        clf = self.infinities_classifier
+        trust = None if (self.trust_bounds is None or ignore_trust_region) else np.asarray(self.trust_bounds).tobytes()
+        return (id(clf), getattr(clf, "_fit_count", 0), trust, id(self._dev))
+
+    def _sync_gates(self, ignore_trust_region=False):
+        """``_push_gates`` for the point-by-point callers: the gates travel to the device only when classifier,
+        trust box or context changed since the last push (an upload per call would cost more than the call)."""
+        held = self._dev_gates
+        if held is not None and held[0] == self._gates_key(ignore_trust_region):
+            return held[1]
+        return self._push_gates(ignore_trust_region)
 
     def _validate_X(self, X, validate):
         if validate:
@@ -851,7 +870,17 @@ class GaussianProcessRegressor(_RM, _BE):
             return tuple(out) if len(out) > 1 else out[0]
         self._ensure_factor()
         self._push_affine()
-        mask = self._masks(X, validate, ignore_trust_region)
+        # classifier and trust box: on the device with the points (``gpry_predict`` with "predict_gates") when they have
+        # a device form; the x-gradient branch below needs the verdict on the host
+        if (not return_mean_grad and getattr(self.device, "applies_gates_in_predict", False)
+                and (self.infinities_classifier is not None or self.trust_bounds is not None)
+                and self._sync_gates(ignore_trust_region)):
+            mask = None
+        else:
+            if self._dev_gates is not None and self._dev_gates[1] and getattr(self.device, "applies_gates_in_predict", False):
+                self.device.set_gates()          # host verdicts for this call: nothing may be ORed in on the device
+                self._dev_gates = None
+            mask = self._masks(X, validate, ignore_trust_region)
         res = self.device.predict(X, return_std=return_std, mask=mask)
         y_mean = res[0] if return_std else res
         y_std = res[1] if return_std else None
@@ -968,7 +997,7 @@ class GaussianProcessRegressor(_RM, _BE):
 
     def __getstate__(self):
         state = dict(self.__dict__)
-        for k in ("_dev", "_kb", "_host_factor", "_fit_devs", "_affine_cache", "_dev_affine", "_dev_affine_on"):
+        for k in ("_dev", "_kb", "_host_factor", "_fit_devs", "_affine_cache", "_dev_affine", "_dev_affine_on", "_dev_gates"):
             state.pop(k, None)
         state["_dev_train_ok"] = False
         state["_dev_factor_ok"] = False

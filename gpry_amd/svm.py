@@ -5,7 +5,8 @@ Same role and interface as ``gpry/svm.py`` (``fit`` :227, ``_is_finite_raw`` :27
 "y above (max - threshold)" labels.  Training stays on the host (libsvm through scikit-learn);
 its decision function -- an RBF expansion over the support vectors -- is exported with
 ``device_params`` so that the NORA sweep evaluates it on the GPU for its 1e5-1e6 candidates
-(``gpry_set_gates``); small ``predict`` calls keep using libsvm.
+(``gpry_set_gates``), and ``GaussianProcessRegressor.predict`` lets the device apply it to its points as well
+(option ``predict_gates``: the one-point calls of the samplers would otherwise spend 50-100 us in libsvm per call).
 """
 import warnings
 
@@ -26,6 +27,7 @@ class SVM:
         self.all_finite = False
         self.diff_threshold = None
         self._max_y = None
+        self._fit_count = 0        # bumped by every fit: what the device-side copy of the decision function is keyed by
 
     @property
     def d(self):
@@ -54,6 +56,7 @@ class SVM:
 
     def fit(self, X, y, diff_threshold):
         from sklearn.svm import SVC
+        self._fit_count = getattr(self, "_fit_count", 0) + 1
         self.X_train, self.y_train = np.copy(X), np.copy(y)
         if np.all(self.y_train == -np.inf):
             self.at_least_one_finite = False

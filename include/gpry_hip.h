@@ -85,6 +85,7 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                               launches (default 5632; 0 = off)
  *              "topk_host" = largest pool that gpry_sweep_topk selects on the host from one kernel's records
  *                            (default 16384; 0 = always the device radix select)
+ *              "predict_gates" = 0/1 gpry_predict applies the gates of gpry_set_gates itself (default 0)
  *              "predict_serve" = 0/1 mean-only gpry_predict of <= 8 points is answered by a RESIDENT kernel (no
  *                                launch per call; default 1), "serve_idle_us" = how long that kernel waits for the
  *                                next request before it leaves (default 2000)
@@ -182,7 +183,9 @@ int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_
  *   finite  <=>  (sum_i coef[i] exp(-gamma |x_ - sv[i]|^2) + intercept > 0) == positive_is_finite
  * sv: n_sv x d support vectors, coef: dual_coef_[0], intercept: intercept_[0] of the fitted SVC;
  * trust_bounds: d x 2 (lo, hi) or NULL.  n_sv = 0 and trust_bounds = NULL switch the gates off.
- * gpry_predict is not affected (its callers pass their own mask). */
+ * gpry_predict keeps to the caller's mask unless the option "predict_gates" = 1 asks it to OR the same verdicts in
+ * (what the host mirror does: the one-point calls of the samplers then cost no libsvm call each; the resident
+ * kernel evaluates decision function and trust box next to the mean). */
 int gpry_set_gates(gpry_ctx* ctx, const double* sv, const double* coef, int64_t n_sv, double gamma,
                    double intercept, int positive_is_finite, const double* trust_bounds);
 

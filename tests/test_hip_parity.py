@@ -546,8 +546,10 @@ def test_capacity_does_not_grow_when_only_the_dimension_changes(dev):
         dev.set_train(X, rng.standard_normal(200), np.full(200, 1e-3))
         dev.set_theta(3, np.log(np.array([2.0] + [0.5] * d)))
     assert dev.factorize() == 0
-    m = dev.predict(rng.uniform(0, 1, (5, 3)))
+    m = dev.predict(rng.uniform(0, 1, (5, d)))
     assert np.all(np.isfinite(m))
+    with pytest.raises(ValueError):
+        dev.predict(rng.uniform(0, 1, (5, 3)))          # the model holds d = 32 columns
 
 
 def test_f5_logexp_edge_vectors_through_the_device_epilogue(dev):

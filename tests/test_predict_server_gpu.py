@@ -199,3 +199,70 @@ def test_point_by_point_predict_of_the_mirror_class_uses_the_resident_kernel():
     v2 = np.array([logp(x) for x in Xc[5:40]])
     r2 = ref.predict(Xc[5:40])
     assert np.max(np.abs(v2 - r2)) <= 1e-7 * np.max(np.abs(r2))
+
+
+def test_classifier_and_trust_box_on_the_device_for_every_predict_path():
+    """GPry's defaults (account_for_inf="SVM", a trust region): ``predict`` leaves the verdicts to the device (option
+    ``predict_gates``: resident kernel for 1..8 points, gates kernel for the batches) instead of calling libsvm per
+    call on the host.  Every path must give what the host-side masks give (gpry/gpr.py:1107-1112, 1145-1150 ->
+    gpry/svm.py:308-347): one point at a time, small batches, with std, a few thousand points, ignore_trust_region."""
+    from test_host_mirror_gpu import make_gpr
+    bounds, X, y, Xc = orc.synthetic_like_goldens(150, 3, 6000, seed=9)
+    y = y.copy()
+    bad = X[:, 0] > 1.0
+    y[bad] = -np.inf
+    theta = np.log(np.array([4.0, 0.3, 0.3, 0.3]))
+
+    def build(on_device):
+        gpr = make_gpr(bounds, 3, theta=theta, account_for_inf="SVM", inf_threshold="20s", trust_region_factor=1.5,
+                       random_state=1)
+        gpr.append_to_data(X, y, fit_gpr=False)
+        if not on_device:
+            gpr.device.applies_gates_in_predict = False          # host verdicts (libsvm + numpy) as before
+            gpr.device.set_option("predict_gates", 0)
+        return gpr
+
+    dev_g, host_g = build(True), build(False)
+    # one point at a time: the resident kernel computes decision function and trust box itself
+    for g in (dev_g, host_g):                 # (first launches load their code objects: not part of the per-call time)
+        g.predict(Xc[:1], validate=False)
+    t0 = time.perf_counter()
+    a = np.array([dev_g.predict(x[None, :], validate=False)[0] for x in Xc[:1500]])
+    t_dev = (time.perf_counter() - t0) / 1500
+    t0 = time.perf_counter()
+    b = np.array([host_g.predict(x[None, :], validate=False)[0] for x in Xc[:1500]])
+    t_host = (time.perf_counter() - t0) / 1500
+    np.testing.assert_array_equal(a, b)
+    assert 50 < np.isneginf(a).sum() < 1450
+    print(f"one-point predict with SVM + trust box: {t_dev * 1e6:.1f} us (device gates) vs {t_host * 1e6:.1f} us (host gates)")
+    launches, requests = dev_g.device.serve_stats()
+    assert requests == 1501 and launches <= 3
+    # batches through the other paths
+    for sl, std in ((slice(0, 5), False), (slice(0, 3), True), (slice(0, 300), True), (slice(0, 6000), True),
+                    (slice(0, 6000), False), (slice(10, 17), False)):
+        ra, rb = dev_g.predict(Xc[sl], return_std=std), host_g.predict(Xc[sl], return_std=std)
+        if std:
+            np.testing.assert_array_equal(ra[0], rb[0])
+            np.testing.assert_array_equal(ra[1], rb[1])
+        else:
+            np.testing.assert_array_equal(ra, rb)
+    # without the trust region: another set of gates on the device, same verdicts as the host's
+    ra, rb = dev_g.predict(Xc[:400], ignore_trust_region=True), host_g.predict(Xc[:400], ignore_trust_region=True)
+    np.testing.assert_array_equal(ra, rb)
+    assert np.isneginf(ra).sum() < np.isneginf(dev_g.predict(Xc[:400])).sum()
+    va = np.array([dev_g.predict(x[None, :], ignore_trust_region=True)[0] for x in Xc[:50]])
+    np.testing.assert_array_equal(va, rb[:50])
+    # the x-gradient branch keeps its host verdict and is not disturbed by gates held on the device
+    x1 = Xc[np.flatnonzero(np.isfinite(a))[0]][None, :]
+    ga, gb = dev_g.predict(x1, return_std=True, return_mean_grad=True), host_g.predict(x1, return_std=True, return_mean_grad=True)
+    for u, v in zip(ga, gb):
+        np.testing.assert_array_equal(u, v)
+    # a refit of the classifier (new data) reaches the device
+    Xn = Xc[:20]
+    yn = np.where(Xn[:, 0] > 0.5, -np.inf, -1.0)
+    for g in (dev_g, host_g):
+        g.append_to_data(Xn, yn, fit_gpr=False)
+    a2 = np.array([dev_g.predict(x[None, :], validate=False)[0] for x in Xc[100:400]])
+    b2 = np.array([host_g.predict(x[None, :], validate=False)[0] for x in Xc[100:400]])
+    np.testing.assert_array_equal(a2, b2)
+    assert not np.array_equal(np.isneginf(a2), np.isneginf(a[100:400]))
