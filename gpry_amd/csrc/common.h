@@ -41,6 +41,8 @@ struct gpry_ctx {
     int opt_sweep_diag = 0;
     int opt_sweep_dma = 3;       // 3: LDS-DMA + explicit software pipeline (default); 1: LDS-DMA; 2: 128x256 ring; 0: register-staged
     int opt_kb_tile = 64;        // kernel-build tile size (32 or 64; 64 measured faster)
+    int opt_kb_variant = 1;      // 1 (default): register-mirrored 64 x 64 tiles; 0: round-2 kernel (LDS transpose); 2: 32 x 32 single-wave
+                                 // tiles; 3: distances per row pair (measured at N = 4096: 37.2 / 41.5 / 49.2 / 41.0 us back to back, tools/ab_kernel_build.py)
     int opt_sweep_kskew = 0;
     int opt_sweep_overlap = 0;   // 1: build the panel of chunk c+1 on a second stream while chunk c is contracted (measured: slower, the co-running cross_build costs the contraction +10 %)
     int opt_sweep_persist = 0;   // 1: persistent workgroups + per-XCD tile tickets (sweep_dma=3 only)

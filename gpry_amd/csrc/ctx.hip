@@ -272,6 +272,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "predict_small")) { ctx->opt_predict_small = (int64_t)value; return 0; }
     if (!strcmp(key, "lml_cache")) { ctx->opt_lml_cache = (int)value; ctx->lml_cache = false; return 0; }
     if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }
+    if (!strcmp(key, "kb_variant")) { ctx->opt_kb_variant = (int)value; ctx->lml_cache = false; return 0; }
     if (!strcmp(key, "sweep_kskew")) { ctx->opt_sweep_kskew = (int)value; return 0; }
     if (!strcmp(key, "sweep_diag")) { ctx->opt_sweep_diag = (int)value; return 0; }
     if (!strcmp(key, "sweep_extra_lds")) { ctx->opt_sweep_extra_lds = (int)value; return 0; }

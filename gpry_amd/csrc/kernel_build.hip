@@ -133,8 +133,116 @@ __global__ __launch_bounds__((TS / 4) * (TS / 4), 5) void kernel_train_kernel(
     }
 }
 
+// Round 3 mapping ("kb_variant" = 1: 64 x 64 tile per workgroup, = 2: 32 x 32 tile per single-wave workgroup).
+// Every wave owns a 32 x 32 quadrant; lane = (ly, lx) in an 8 x 8 grid; the thread's 4 x 4 patch has rows
+// {16 a' + 2 ly + a''} and columns {16 b' + 2 lx + b''} of the quadrant.  With that shape BOTH images of an entry
+// are stored straight from registers in whole 128-byte lines: the direct one as double2 over b'' (8 lx lanes = 16
+// contiguous doubles of a row), the mirrored one as double2 over a'' (8 ly lanes = 16 contiguous doubles of the
+// mirrored row).  No LDS transpose, no barrier behind the staging of the coordinates, and the stores of the first
+// two patch rows leave while the last two are still being evaluated -- the round-2 kernel computed all 16 values,
+// then stored, then transposed through LDS behind two barriers, so that VALU time (~20 us of FP64 issue at N = 4096)
+// and store time (~29 us at the fill rate of the GPU) overlapped only between workgroups.
+// corr_r2_fast: the straight-line sqrt / exp of the cross-kernel panel (~1 ulp; the F1 goldens hold to 1e-13).
+template <int KID, int TS, bool CHUNKED>
+__global__ __launch_bounds__((TS / 32) * (TS / 32) * 64, 6) void kernel_train_q_kernel(
+    const double* __restrict__ Xs, const double* __restrict__ noise, double* __restrict__ K,
+    int64_t ld, KernParams kp, int add_noise) {
+    constexpr int WPR = TS / 32, NT = WPR * WPR * 64;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int dp = kp.dpad;
+    double* Xi = sm;             // [dp][TS]
+    double* Xj = sm + dp * TS;   // [dp][TS]
+    int bi, bj; tri_decode(blockIdx.x, &bi, &bj);
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63, lx = lane & 7, ly = lane >> 3;
+    for (int e = t; e < TS * dp; e += NT) {
+        int row = e / dp, k = e - row * dp;
+        Xi[k * TS + row] = Xs[((int64_t)bi * TS + row) * dp + k];
+        Xj[k * TS + row] = Xs[((int64_t)bj * TS + row) * dp + k];
+    }
+    __syncthreads();
+    const int r0 = 32 * (w / WPR) + 2 * ly, c0 = 32 * (w % WPR) + 2 * lx;
+    double r2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) r2[a][b] = 0.0;
+    if (!CHUNKED) {
+        for (int k = 0; k < dp; k++) {
+            const double2 i0 = *reinterpret_cast<const double2*>(Xi + k * TS + r0);
+            const double2 i1 = *reinterpret_cast<const double2*>(Xi + k * TS + r0 + 16);
+            const double2 j0 = *reinterpret_cast<const double2*>(Xj + k * TS + c0);
+            const double2 j1 = *reinterpret_cast<const double2*>(Xj + k * TS + c0 + 16);
+            const double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) { const double df = xi[a] - xj[b]; r2[a][b] = fma(df, df, r2[a][b]); }
+        }
+    }
+#pragma unroll
+    for (int ap = 0; ap < 2; ap++) {
+        if (CHUNKED) {
+            // the distances of this row pair only: its stores leave before the other pair's arithmetic starts
+            for (int k = 0; k < dp; k++) {
+                const double2 i0 = *reinterpret_cast<const double2*>(Xi + k * TS + r0 + 16 * ap);
+                const double2 j0 = *reinterpret_cast<const double2*>(Xj + k * TS + c0);
+                const double2 j1 = *reinterpret_cast<const double2*>(Xj + k * TS + c0 + 16);
+                const double xi[2] = {i0.x, i0.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
+#pragma unroll
+                for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) { const double df = xi[a2] - xj[b]; r2[2 * ap + a2][b] = fma(df, df, r2[2 * ap + a2][b]); }
+            }
+        }
+        double v[2][4];
+#pragma unroll
+        for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int64_t i = (int64_t)bi * TS + r0 + 16 * ap + a2;
+                const int64_t j = (int64_t)bj * TS + c0 + 16 * (b >> 1) + (b & 1);
+                double x = kp.C * corr_r2_fast<KID>(r2[2 * ap + a2][b]);
+                if (i == j) x = kp.C + (add_noise ? noise[i < kp.N ? i : 0] : 0.0);
+                if (i >= kp.N || j >= kp.N) x = (i == j) ? 1.0 : 0.0;   // identity padding
+                v[a2][b] = x;
+            }
+#pragma unroll
+        for (int a2 = 0; a2 < 2; a2++) {
+            const int64_t i = (int64_t)bi * TS + r0 + 16 * ap + a2;
+            double2* p = reinterpret_cast<double2*>(K + i * ld + (int64_t)bj * TS + c0);
+            nt_store2(p, v[a2][0], v[a2][1]);
+            nt_store2(p + 8, v[a2][2], v[a2][3]);
+        }
+        if (bi != bj) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int64_t j = (int64_t)bj * TS + c0 + 16 * (b >> 1) + (b & 1);
+                double2* q = reinterpret_cast<double2*>(K + j * ld + (int64_t)bi * TS + r0 + 16 * ap);
+                nt_store2(q, v[0][b], v[1][b]);
+            }
+        }
+    }
+}
+
 int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
     KernParams kp = make_kp(ctx);
+    if (ctx->opt_kb_variant >= 1 && ctx->opt_kb_variant <= 3) {
+        const int TQ = ctx->opt_kb_variant == 2 ? 32 : 64;
+        const bool chunked = ctx->opt_kb_variant == 3;
+        const int64_t nbq = ctx->Np / TQ, ntq = nbq * (nbq + 1) / 2;
+        const size_t smq = sizeof(double) * (size_t)(2 * ctx->dpad * TQ);
+#define KQ(KID)                                                                                               \
+    if (TQ == 64 && chunked) hipLaunchKernelGGL((kernel_train_q_kernel<KID, 64, true>), dim3((unsigned)ntq), dim3(256), smq, \
+                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise);          \
+    else if (TQ == 64) hipLaunchKernelGGL((kernel_train_q_kernel<KID, 64, false>), dim3((unsigned)ntq), dim3(256), smq,     \
+                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise);          \
+    else hipLaunchKernelGGL((kernel_train_q_kernel<KID, 32, false>), dim3((unsigned)ntq), dim3(64), smq,              \
+                            ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise)
+        DISPATCH_KID(ctx->kernel_id, KQ)
+#undef KQ
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
     const int TS = ctx->opt_kb_tile == 64 ? 64 : 32;
     int64_t nb = ctx->Np / TS;
     int64_t ntile = nb * (nb + 1) / 2;
@@ -172,7 +280,7 @@ __global__ __launch_bounds__(256) void kernel_rows_kernel(const double* __restri
         const double* xj = Xs + j * kp.dpad;
         double r2 = 0.0;
         for (int c = 0; c < kp.dpad; c++) { const double df = xa[c] - xj[c]; r2 = fma(df, df, r2); }
-        v = kp.C * corr_r2<KID>(r2);
+        v = kp.C * corr_r2_fast<KID>(r2);       // the arithmetic of the training build (kernel_train_q_kernel)
         if (j == row0 + a) v = kp.C + noise[j];
         if (j >= row0) { Cb[a * 64 + (int)(j - row0)] = v; v = 0.0; }
     }
@@ -268,6 +376,11 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
     if (in_chunk && mean_part) mean_part[(int64_t)jc * mc + ml] = macc;
 }
 
+// (Round 3, measured and removed: reading the training rows of a chunk with scalar loads -- constant address space,
+// s_load_dwordx16, SGPR operands of the v_add_f64 -- instead of broadcasting them from LDS: same bits, 11.2 vs 11.2 ms per
+// 1e6 candidates at N = 4096, d = 16 with Matern-5/2, 10.4 vs 9.0 ms with RBF, 2.5 vs 1.9 ms at N = 1024: the LDS pipe
+// is not what holds this kernel at 73 % VALU issue, and the scalar loads are waited for in full at the top of every
+// two-row step.  tools/ab_cross_build.py, profiles/r03_ab_cross_build.log.)
 // The same panel for a SMALL batch (a few hundred points: gpry_predict / gpry_predict_grad_batch): with one
 // candidate per thread and 128 training rows per workgroup the launch has Np/128 workgroups whose four waves
 // walk 128 rows each at a lone wave's FP64 rate (36 us whatever the batch size).  Here a workgroup is 64
