@@ -212,10 +212,19 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     double* dres = static_cast<double*>(ctx->hpin_dev);     // the same buffer as the device sees it
     double* dout = ctx->dvec + 2 * ctx->Np;                 // device copy: [logdet/2, quad, grad...]
     if (rc == 0) { hres[RES_INFO] = -1.0; hres[RES_INFO + 1] = -1.0; }      // "not written" marker
-    if (rc == 0) rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, nullptr);
+    // N <= 128, d <= 16: the whole evaluation in one launch of one workgroup (lml_small.hip); it leaves no factor in
+    // dW / dW2 and does not touch the scaled coordinates of the prediction factor
+    bool fused = false;
+    if (rc == 0 && ctx->opt_lml_small && ctx->opt_chol == 0) {
+        StageScope s(ctx, "lml_small");
+        const int r = launch_lml_small(ctx, want_grad, dres, RES_INFO);
+        if (r < 0) rc = r;
+        fused = r == 0;
+    }
+    if (rc == 0 && !fused) rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, nullptr);
     double* dz = ctx->dvec;                 // z = V y
     double* da = ctx->dvec + ctx->Np;       // alpha
-    if (rc == 0) {
+    if (rc == 0 && !fused) {
         rc = solve_alpha(ctx, ctx->dW2, ctx->dy, dz, da, ctx->Np);
         if (rc == 0) rc = logdet_and_quad(ctx, ctx->dW, dz, ctx->Np, dout, want_grad ? nullptr : dres, RES_INFO);
         if (rc == 0 && want_grad) {
@@ -233,7 +242,7 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     ctx->have_theta = had;
     // the scaled training coordinates belong to the prediction factor: restore them (same stream, behind
     // the traces kernel that reads the ones of this evaluation)
-    if (rc == 0 && had && ctx->factor_valid) rc = launch_scale_train(ctx);
+    if (rc == 0 && had && ctx->factor_valid && !fused) rc = launch_scale_train(ctx);
     double host[2 + 1 + GPRY_MAX_DIM];
     int hinfo[2] = {0, 0};
     if (rc == 0) {
@@ -250,7 +259,7 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
         }
     }
     const int inf = hinfo[0] != 0 ? hinfo[0] : hinfo[1];
-    ctx->lml_cache = (rc == 0 && inf == 0);
+    ctx->lml_cache = (rc == 0 && inf == 0 && !fused);
     if (ctx->lml_cache) {
         memset(ctx->lml_theta, 0, sizeof(ctx->lml_theta));
         for (int k = 0; k <= ctx->d; k++) ctx->lml_theta[k] = theta[k];

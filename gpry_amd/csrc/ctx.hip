@@ -270,6 +270,7 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "lauum_lds")) { ctx->opt_lauum_lds = (int)value; return 0; }
     if (!strcmp(key, "syrk_lds")) { ctx->opt_syrk_lds = (int)value; return 0; }
     if (!strcmp(key, "predict_small")) { ctx->opt_predict_small = (int64_t)value; return 0; }
+    if (!strcmp(key, "lml_small")) { ctx->opt_lml_small = (int)value; ctx->lml_cache = false; return 0; }
     if (!strcmp(key, "lml_cache")) { ctx->opt_lml_cache = (int)value; ctx->lml_cache = false; return 0; }
     if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }
     if (!strcmp(key, "kb_variant")) { ctx->opt_kb_variant = (int)value; ctx->lml_cache = false; return 0; }

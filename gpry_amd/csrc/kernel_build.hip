@@ -142,7 +142,10 @@ __global__ __launch_bounds__((TS / 4) * (TS / 4), 5) void kernel_train_kernel(
 // two patch rows leave while the last two are still being evaluated -- the round-2 kernel computed all 16 values,
 // then stored, then transposed through LDS behind two barriers, so that VALU time (~20 us of FP64 issue at N = 4096)
 // and store time (~29 us at the fill rate of the GPU) overlapped only between workgroups.
-// corr_r2_fast: the straight-line sqrt / exp of the cross-kernel panel (~1 ulp; the F1 goldens hold to 1e-13).
+// The correlation keeps libm's exp / sqrt (corr_r2), NOT the straight-line versions of the cross-kernel panel: they
+// differ from numpy's in the last bit of a few entries, and on the cond(K) = 5e15 matrix of BASELINE config 1 one ulp
+// of K moves the posterior mean by 2e-5 of its range (tests/test_host_mirror_gpu.py::test_f9_config1_curved_degeneracy
+// failed with them; the F1 goldens, 1e-13, would not have noticed).
 template <int KID, int TS, bool CHUNKED>
 __global__ __launch_bounds__((TS / 32) * (TS / 32) * 64, 6) void kernel_train_q_kernel(
     const double* __restrict__ Xs, const double* __restrict__ noise, double* __restrict__ K,
@@ -201,7 +204,7 @@ __global__ __launch_bounds__((TS / 32) * (TS / 32) * 64, 6) void kernel_train_q_
             for (int b = 0; b < 4; b++) {
                 const int64_t i = (int64_t)bi * TS + r0 + 16 * ap + a2;
                 const int64_t j = (int64_t)bj * TS + c0 + 16 * (b >> 1) + (b & 1);
-                double x = kp.C * corr_r2_fast<KID>(r2[2 * ap + a2][b]);
+                double x = kp.C * corr_r2<KID>(r2[2 * ap + a2][b]);     // libm exp / sqrt: see below
                 if (i == j) x = kp.C + (add_noise ? noise[i < kp.N ? i : 0] : 0.0);
                 if (i >= kp.N || j >= kp.N) x = (i == j) ? 1.0 : 0.0;   // identity padding
                 v[a2][b] = x;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void kernel_rows_kernel(const double* __restri
         const double* xj = Xs + j * kp.dpad;
         double r2 = 0.0;
         for (int c = 0; c < kp.dpad; c++) { const double df = xa[c] - xj[c]; r2 = fma(df, df, r2); }
-        v = kp.C * corr_r2_fast<KID>(r2);       // the arithmetic of the training build (kernel_train_q_kernel)
+        v = kp.C * corr_r2<KID>(r2);            // the arithmetic of the training build (kernel_train_q_kernel)
         if (j == row0 + a) v = kp.C + noise[j];
         if (j >= row0) { Cb[a * 64 + (int)(j - row0)] = v; v = 0.0; }
     }

@@ -1,0 +1,341 @@
+// Log marginal likelihood + gradient of a SMALL training set (N <= 128, d <= 16) in ONE launch of ONE workgroup.
+//
+// sklearn:_gpr.py:574-652 as reached from gpry/gpr.py:876-881 (the objective of fit_gpr_hyperparameters,
+// gpry/gpr.py:883-994).  The first iterations of every GPry run -- and whole runs in low dimension -- live at a few
+// dozen to a few hundred training points.  There the chain of the general path (csrc/api.hip: gpry_lml) is 19
+// dependent kernels, nine of them at the 4-5 us floor of a dependent dispatch: 173 us per evaluation whatever N is
+// (profiles/r02_trace_small_lml.txt).  Here the whole evaluation stays in the LDS of one CU (8 waves):
+//
+//   A  x / l (true divisions, as scale_train_kernel)                    -> xs[k][row]          16 KB
+//   B  K = C k(r) + diag(noise), lower 16 x 16 tiles                    -> M[128][130]        133 KB
+//   C  M <- chol(M): dataflow between the waves, wave w owns block row w (chol16_wave / trsm16_rows / MFMA rank-16
+//      updates: the building blocks of chol_panel.hip), only the ceil(N / 16) blocks that hold training rows
+//   D  sum log L_ii
+//   E  diagonal blocks W_jj = L_jj^-1 in place (column substitution, reciprocal pivots of the factor)
+//   F  V = L^-1 IN PLACE, block columns from right to left:  V[m][j] = -(sum_{k=j+1..m} V[m][k] L[k][j]) W_jj
+//   G  z = V y, quad = z.z, alpha = V^T z
+//   H  per lower 16 x 16 tile: K^-1 tile = sum_k V[k][i] V[k][j] (MFMA, accumulators only: K^-1 is never stored),
+//      W = alpha alpha^T - K^-1 contracted at once with dK/dtheta (distances recomputed from xs, as lml_traces_kernel)
+//   I  results + factorisation status straight into the mapped host buffer of gpry_lml
+//
+// One row stride (130 doubles) serves every MFMA fragment read of the three operand layouts without bank conflicts
+// worth noting.  The factor does NOT travel back to HBM: gpry_factorize cannot adopt it (lml_cache stays false) and
+// runs the general chain once per fit -- the prediction factor keeps its operation order.
+#include "kern_math.h"
+#include "chol16.h"
+
+#define LS_NP 128
+#define LS_LD 130
+#define LS_NT 512
+#define LS_NB 8
+
+struct LmlSmallArgs {
+    const double* X;        // N x d transformed training rows (ctx->dX)
+    const double* y;        // Np (zero padded)
+    const double* noise;    // Np
+    double* host_res;       // mapped host memory: [sum log L_ii, quad, grad (1 + d) ...]; status at info_at, info_at + 1
+    double* dev_out;        // the same three groups in device memory (ctx->dvec + 2 Np)
+    int info_at, want_grad;
+    unsigned long long* dbg;   // nullable: cycles per phase (B, C, E, F, G, H) of the launch, added up (gpry_debug_read_diag)
+};
+
+template <int DP, int KID>
+__global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernParams kp, AffParams ap) {
+    __shared__ __attribute__((aligned(16))) double M[LS_NP * LS_LD];
+    __shared__ __attribute__((aligned(16))) double xs[DP * LS_NP];      // k-major: xs[k * 128 + row]
+    __shared__ double sy[LS_NP], sz[LS_NP], sal[LS_NP], srd[LS_NP], slog[LS_NP];
+    __shared__ double red[LS_NB][DP + 2];
+    __shared__ double red2[4][LS_NP];
+    __shared__ int s_flag[16];
+    __shared__ int s_bad;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int N = (int)kp.N;
+    const int nb = (N + 15) >> 4;            // 16-row blocks that hold training rows (the others are identity padding)
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
+    const bool stamp = a.dbg != nullptr && t == 0;
+#define LS_STAMP(I) if (stamp) ts[I] = __builtin_readcyclecounter()
+
+    // ---- A: scaled coordinates, targets
+#pragma unroll
+    for (int k = 0; k < DP; k++) {
+        if (t < LS_NP) {
+            double v = 0.0;
+            if (t < N && k < kp.d) v = a.X[(int64_t)t * kp.d + k] / ap.ls[k];
+            xs[k * LS_NP + t] = v;
+        }
+    }
+    if (t < LS_NP) { sy[t] = a.y[t]; srd[t] = 1.0; slog[t] = 0.0; }
+    if (t < 16) s_flag[t] = 0;
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+    LS_STAMP(0);
+
+    // ---- B: covariance matrix, lower tiles (tile list: (bi, bj), bj <= bi), MFMA C-layout per wave:
+    // lane (g, r) owns rows 16 bi + g + 4q (q = 0..3), column 16 bj + r
+    for (int tl = w; tl < LS_NB * (LS_NB + 1) / 2; tl += LS_NB) {
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= tl) bi++;
+        const int bj = tl - bi * (bi + 1) / 2;
+        const int j = 16 * bj + r;
+        double r2[4] = {0.0, 0.0, 0.0, 0.0};
+        if (bi < nb) {
+#pragma unroll
+            for (int k = 0; k < DP; k++) {
+                const double xj = xs[k * LS_NP + j];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const double df = xs[k * LS_NP + 16 * bi + g + 4 * q] - xj; r2[q] = fma(df, df, r2[q]); }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = 16 * bi + g + 4 * q;
+            double v = kp.C * corr_r2<KID>(r2[q]);               // libm exp / sqrt, as the training build of the general path
+            if (i == j) v = kp.C + (i < N ? a.noise[i] : 0.0);
+            if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;      // identity padding
+            M[i * LS_LD + j] = v;
+        }
+    }
+    __syncthreads();
+    LS_STAMP(1);
+
+    // ---- C: Cholesky, blocked by 16, as a dataflow between the waves (wave w owns block row w).  A wave that has
+    // factored its diagonal block is done with the chain: it inverts that block (E) into registers while the chain
+    // goes on -- the tile itself is still read by the rows below and is replaced after the barrier.
+    double winv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) winv[i] = 0.0;
+    if (w < nb) {
+        for (int cb = 0; cb < w; cb++) {
+            while (__hip_atomic_load(&s_flag[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(1);
+            c16::trsm16_rows<LS_LD>(M + (w * 16) * LS_LD + cb * 16, M + (cb * 16) * LS_LD + cb * 16, srd + cb * 16, lane);
+            c16::wave_fence();
+            if (lane == 0) __hip_atomic_store(&s_flag[1 + w], cb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int cc = cb + 1; cc <= w; cc++) {
+                if (cc < w)
+                    while (__hip_atomic_load(&s_flag[1 + cc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(1);
+                double* T = M + (w * 16) * LS_LD + cc * 16;
+                v4d acc = c16::tile_load<LS_LD>(T, lane);
+                acc = c16::mfma_nt<LS_LD, true>(acc, M + (w * 16) * LS_LD + cb * 16, M + (cc * 16) * LS_LD + cb * 16, 16, lane);
+                c16::tile_store<LS_LD>(T, acc, lane);
+            }
+            c16::wave_fence();
+        }
+        // a failed pivot (not positive definite) still publishes: nobody may wait forever
+        const int bad = c16::chol16_wave<LS_LD>(M + (w * 16) * LS_LD + w * 16, srd + w * 16, lane);
+        if (bad && lane == 0) atomicMin(&s_bad, 0 - (1 << 20) + w * 16 + bad);      // first failing column wins
+        c16::wave_fence();
+        if (lane == 0) __hip_atomic_store(&s_flag[0], w + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // ---- D: log-determinant terms;  E: W_ww = L_ww^-1, column `lane` by forward substitution (reciprocal pivots)
+        if (lane < 16) {
+            const double* Lw = M + (w * 16) * LS_LD + w * 16;
+            const int idx = w * 16 + lane;
+            slog[idx] = idx < N ? log(Lw[lane * LS_LD + lane]) : 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) sacc = fma(-Lw[i * LS_LD + k], winv[k], sacc);
+                winv[i] = (i >= lane) ? sacc * srd[w * 16 + i] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_bad != 0) {      // sklearn:_gpr.py:586-589: the caller turns info > 0 into (-inf, 0)
+        if (t == 0) {
+            int col = s_bad + (1 << 20);                        // 1-based failing column
+            if (col > N) col = N;
+            a.host_res[0] = 0.0; a.host_res[1] = 0.0;
+            a.host_res[a.info_at] = (double)col; a.host_res[a.info_at + 1] = 0.0;
+        }
+        return;
+    }
+    LS_STAMP(2);
+    if (w < nb && lane < 16) {
+        double* Lw = M + (w * 16) * LS_LD + w * 16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) Lw[i * LS_LD + lane] = winv[i];
+    }
+    __syncthreads();
+    LS_STAMP(3);
+
+    // ---- F: V = L^-1 in place by recursive doubling over the 16 x 16 tiles: [[L11, 0], [L21, L22]]^-1 =
+    // [[V11, 0], [-V22 (L21 V11), V22]].  Per level (block size h = 1, 2, 4 tiles) and node (lo, mid, hi): first
+    // T(m, n) = sum_{k=n}^{mid-1} L(m, k) V11(k, n) replaces L21, then V21(m, n) = -sum_{k=mid}^{m} V22(m, k) T(k, n)
+    // replaces T.  Every output tile is a task; the tasks of a product are dealt to the eight waves (two per wave on the
+    // top level, long and short k-ranges paired), accumulated in registers, and written only when everybody has read.
+    for (int lg = 0; lg < 3; lg++) {
+        const int h = 1 << lg, ntask = (LS_NB >> (lg + 1)) << (2 * lg);      // (shifts: h is a run-time value)
+#pragma unroll
+        for (int prod = 0; prod < 2; prod++) {
+            v4d acc[2];
+            double* dst[2] = {nullptr, nullptr};
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+                const int id = w + LS_NB * q;
+                if (id < ntask) {
+                    const int p = id >> (2 * lg), e = id & ((1 << (2 * lg)) - 1);
+                    int mi = e >> lg, ni = e & (h - 1);
+                    if (q == 1) { ni = h - 1 - ni; mi = (h + h / 2 - 1) - mi; }      // top level: pair long with short
+                    const int lo = 2 * h * p, mid = lo + h, m = mid + mi, n = lo + ni;
+                    if (m < nb) {
+                        dst[q] = M + (m * 16) * LS_LD + n * 16;
+                        if (prod == 0)
+                            acc[q] = c16::mfma_nn<LS_LD, false>(acc[q], M + (m * 16) * LS_LD + n * 16, M + (n * 16) * LS_LD + n * 16,
+                                                                16 * (mid - n), lane);
+                        else
+                            acc[q] = c16::mfma_nn<LS_LD, true>(acc[q], M + (m * 16) * LS_LD + mid * 16, M + (mid * 16) * LS_LD + n * 16,
+                                                               16 * (m - mid + 1), lane);
+                    }
+                }
+            }
+            __syncthreads();                       // all reads of this product are done
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                if (dst[q]) c16::tile_store<LS_LD>(dst[q], acc[q], lane);
+            __syncthreads();
+        }
+    }
+    LS_STAMP(4);
+
+    // ---- G: z = V y, alpha = V^T z, quad = z.z, log-determinant
+    {   // z: four threads per row, 32 terms each (walking a row with the 64 lanes and a butterfly sum per row was
+        // twice as slow: 16 x 6 dependent cross-lane steps per wave)
+        const int row = t >> 2, seg = t & 3;
+        double s0 = 0.0, s1 = 0.0;
+        const double* mr = M + row * LS_LD + seg * 32;
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {          // (above the diagonal M holds no data)
+            const int kk = seg * 32 + k;
+            s0 = fma(kk <= row ? mr[k] : 0.0, sy[kk], s0);
+            s1 = fma(kk + 1 <= row ? mr[k + 1] : 0.0, sy[kk + 1], s1);
+        }
+        double sacc = s0 + s1;
+        sacc += __shfl_xor(sacc, 1);
+        sacc += __shfl_xor(sacc, 2);
+        if (seg == 0) sz[row] = sacc;
+    }
+    __syncthreads();
+    {
+        const int col = t & 127, seg = t >> 7;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; i += 2) {
+            const int ii = seg * 32 + i;
+            s0 = fma(ii >= col ? M[ii * LS_LD + col] : 0.0, sz[ii], s0);
+            s1 = fma(ii + 1 >= col ? M[(ii + 1) * LS_LD + col] : 0.0, sz[ii + 1], s1);
+        }
+        red2[seg][col] = s0 + s1;
+    }
+    __syncthreads();
+    if (t < LS_NP) sal[t] = (red2[0][t] + red2[1][t]) + (red2[2][t] + red2[3][t]);
+    if (w == 7) {          // a wave that has nothing to do in the alpha pass: fixed-order sums of 128 terms
+        double sl = slog[lane] + slog[lane + 64];
+        double sq = fma(sz[lane], sz[lane], sz[lane + 64] * sz[lane + 64]);
+        for (int off = 32; off >= 1; off >>= 1) { sl += __shfl_xor(sl, off); sq += __shfl_xor(sq, off); }
+        if (lane == 0) { red[0][DP + 1] = sl; red[1][DP + 1] = sq; }
+    }
+    __syncthreads();
+    if (!a.want_grad) {
+        if (t == 0) {
+            const double sl = red[0][DP + 1], sq = red[1][DP + 1];
+            a.dev_out[0] = sl; a.dev_out[1] = sq;
+            a.host_res[0] = sl; a.host_res[1] = sq;
+            a.host_res[a.info_at] = 0.0; a.host_res[a.info_at + 1] = 0.0;
+        }
+        return;
+    }
+
+    LS_STAMP(5);
+    // ---- H: traces 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_k) over the lower tiles, off-diagonal tiles twice
+    double gacc[DP + 1];
+#pragma unroll
+    for (int k = 0; k <= DP; k++) gacc[k] = 0.0;
+    const int ntile = nb * (nb + 1) / 2;
+    for (int q8 = 0; q8 * LS_NB < ntile; q8++) {
+        const int tl = q8 * LS_NB + ((q8 & 1) ? LS_NB - 1 - w : w);      // snake over the waves: long tiles come first
+        if (tl >= ntile) continue;
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= tl) bi++;
+        const int bj = tl - bi * (bi + 1) / 2;
+        v4d kin = {0.0, 0.0, 0.0, 0.0};
+        kin = c16::mfma_tn<LS_LD>(kin, M + (bi * 16) * LS_LD + bi * 16, M + (bi * 16) * LS_LD + bj * 16, (nb - bi) * 16, lane);
+        const int j = 16 * bj + r;
+        const double aj = sal[j];
+        const double wt = bi == bj ? 1.0 : 2.0;
+        double r2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < DP; k++) {
+            const double xj = xs[k * LS_NP + j];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const double df = xs[k * LS_NP + 16 * bi + g + 4 * q] - xj; r2[q] = fma(df, df, r2[q]); }
+        }
+        double wh[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = 16 * bi + g + 4 * q;
+            double wv = (sal[i] * aj - kin[q]) * wt;
+            double kv;
+            const double h = corr_and_h<KID>(r2[q], &kv);
+            if (i == j) kv = 1.0;
+            if (i >= N || j >= N) wv = 0.0;
+            gacc[0] = fma(wv, kp.C * kv, gacc[0]);
+            wh[q] = wv * kp.C * h;
+        }
+#pragma unroll
+        for (int k = 0; k < DP; k++) {
+            const double xj = xs[k * LS_NP + j];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double df = xs[k * LS_NP + 16 * bi + g + 4 * q] - xj;
+                gacc[1 + k] = fma(wh[q], df * df, gacc[1 + k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k <= DP; k++) {
+        double v = gacc[k];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[w][k] = v;
+    }
+    __syncthreads();
+    LS_STAMP(6);
+    if (stamp) for (int q = 0; q < 6; q++) atomicAdd(&a.dbg[q], ts[q + 1] - ts[q]);
+    // ---- I: results
+    if (t <= kp.d) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < LS_NB; q++) s += red[q][t];
+        a.dev_out[2 + t] = 0.5 * s;
+        a.host_res[2 + t] = 0.5 * s;
+    }
+    if (t == 0) {
+        const double sl = red[0][DP + 1], sq = red[1][DP + 1];
+        a.dev_out[0] = sl; a.dev_out[1] = sq;
+        a.host_res[0] = sl; a.host_res[1] = sq;
+        a.host_res[a.info_at] = 0.0; a.host_res[a.info_at + 1] = 0.0;
+    }
+}
+
+// N <= 128, d <= 16: the single-launch evaluation.  host_res / dev_out as launch_lml_traces; the status is part of
+// the results (info_at).  Returns 1 if the model does not fit this kernel (the caller takes the general chain).
+int launch_lml_small(gpry_ctx* ctx, int want_grad, double* host_res, int info_at) {
+    if (ctx->Np != LS_NP || ctx->d > 16) return 1;
+    KernParams kp;
+    kp.C = exp(ctx->theta[0]); kp.d = ctx->d; kp.dpad = ctx->dpad; kp.has_aff = 0; kp.N = ctx->N;
+    AffParams ap = make_ap(ctx, false);
+    LmlSmallArgs a;
+    a.X = ctx->dX; a.y = ctx->dy; a.noise = ctx->dnoise;
+    a.host_res = host_res; a.dev_out = ctx->dvec + 2 * ctx->Np;
+    a.info_at = info_at; a.want_grad = want_grad;
+    a.dbg = nullptr;
+    if (ctx->opt_chol_dbg) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); a.dbg = ctx->dsel + 16; }
+#define LS2(DP, KID) hipLaunchKernelGGL((lml_small_kernel<DP, KID>), dim3(1), dim3(LS_NT), 0, ctx->stream, a, kp, ap)
+#define LS4(KID) { if (ctx->d <= 4) LS2(4, KID); else if (ctx->d <= 8) LS2(8, KID); else LS2(16, KID); }
+    DISPATCH_KID(ctx->kernel_id, LS4)
+#undef LS4
+#undef LS2
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

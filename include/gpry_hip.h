@@ -85,6 +85,8 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                               launches (default 5632; 0 = off)
  *              "topk_host" = largest pool that gpry_sweep_topk selects on the host from one kernel's records
  *                            (default 16384; 0 = always the device radix select)
+ *              "lml_small" = 0/1 gpry_lml of N <= 128, d <= 16 in ONE launch of one workgroup (default 1; the factor of
+ *                            such an evaluation is not kept for gpry_factorize)
  *              "predict_gates" = 0/1 gpry_predict applies the gates of gpry_set_gates itself (default 0)
  *              "predict_serve" = 0/1 mean-only gpry_predict of <= 8 points is answered by a RESIDENT kernel (no
  *                                launch per call; default 1), "serve_idle_us" = how long that kernel waits for the
