@@ -286,13 +286,21 @@ class Device:
         return L, V, a
 
     def lml(self, theta, eval_gradient=False):
-        theta = _f64(theta, (self.d + 1,))
-        val, info = C.c_double(0.0), C.c_int(0)
-        grad = np.zeros(self.d + 1)
-        self._check(self._lib.gpry_lml(self._h, _ptr(theta), int(bool(eval_gradient)),
-                                       C.byref(val), _ptr(grad), C.byref(info)), "gpry_lml")
+        # persistent argument buffers: at small N an evaluation takes 30-60 us, of which building two arrays and four
+        # ctypes pointers per call used to be 3-4
+        buf = getattr(self, "_lml_buf", None)
+        if buf is None or len(buf[0]) != self.d + 1:
+            th, gr = np.zeros(self.d + 1), np.zeros(self.d + 1)
+            val, info = C.c_double(0.0), C.c_int(0)
+            buf = self._lml_buf = (th, gr, C.c_void_p(th.ctypes.data), C.c_void_p(gr.ctypes.data), val, info,
+                                   C.byref(val), C.byref(info))
+        th, gr, pth, pgr, val, info, rval, rinfo = buf
+        th[:] = theta                          # (raises on a shape mismatch)
+        rc = self._lib.gpry_lml(self._h, pth, 1 if eval_gradient else 0, rval, pgr, rinfo)
+        if rc != 0:
+            self._check(rc, "gpry_lml")
         if eval_gradient:
-            return val.value, grad, info.value
+            return val.value, gr.copy(), info.value
         return val.value, info.value
 
     # -- predict / sweep ------------------------------------------------------------

@@ -215,9 +215,11 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     // N <= 128, d <= 16: the whole evaluation in one launch of one workgroup (lml_small.hip); it leaves no factor in
     // dW / dW2 and does not touch the scaled coordinates of the prediction factor
     bool fused = false;
+    double fhost[2 + 1 + GPRY_MAX_DIM];
+    int finfo = 0;
     if (rc == 0 && ctx->opt_lml_small && ctx->opt_chol == 0) {
         StageScope s(ctx, "lml_small");
-        const int r = launch_lml_small(ctx, want_grad, dres, RES_INFO);
+        const int r = launch_lml_small(ctx, want_grad, fhost, &finfo);     // returns with the results in hand
         if (r < 0) rc = r;
         fused = r == 0;
     }
@@ -245,7 +247,10 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     if (rc == 0 && had && ctx->factor_valid && !fused) rc = launch_scale_train(ctx);
     double host[2 + 1 + GPRY_MAX_DIM];
     int hinfo[2] = {0, 0};
-    if (rc == 0) {
+    if (rc == 0 && fused) {
+        memcpy(host, fhost, sizeof(double) * (2 + (want_grad ? ctx->d + 1 : 0)));
+        hinfo[0] = finfo;
+    } else if (rc == 0) {
         // (Polling the status word in the mapped buffer instead of waiting for the stream returns 15 us earlier and is
         // WRONG: inbound PCIe writes to different cache lines are not ordered here -- the host saw the status before
         // the last gradient entries in 2 % of the evaluations, tests/tools/stress_concurrent_fit.py; a loop over

@@ -69,6 +69,7 @@ struct gpry_ctx {
     int lml_kernel_id = -1;
     double lml_theta[1 + GPRY_MAX_DIM] = {0};
     int opt_lml_cache = 1;
+    unsigned long long lml_seq = 0;     // stamp of the last single-launch evaluation
     int opt_lml_small = 1;       // N <= 128, d <= 16: LML + gradient in one launch of one workgroup (lml_small.hip)
 
     double* dX = nullptr;      // N x d raw transformed training rows (row-major, ld = d)
@@ -276,7 +277,7 @@ int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, 
                  double* u, double* w, double* part, double* out);
 int launch_gradx_batch(gpry_ctx* ctx, const double* Xb, int64_t m, int raw_affine, const double* Wm, int64_t ldw,
                        double* out);
-int launch_lml_small(gpry_ctx* ctx, int want_grad, double* host_res, int info_at);   // lml_small.hip: N <= 128, d <= 16 in one launch; 1 = not applicable
+int launch_lml_small(gpry_ctx* ctx, int want_grad, double* out, int* info);   // lml_small.hip: N <= 128, d <= 16 in one launch, results picked up as they land; 1 = not applicable
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
                       double* grad_out_dev, const double* lq_dev, double* host_res, int info_at);
 // host_res (nullable, mapped host memory): [logdet/2, quad, grad...] and dinfo[0..1] as doubles at info_at, status last
