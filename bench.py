@@ -151,7 +151,20 @@ def cpu_baseline(N, d, M, lml_evals, cache_models):
         g["candidates_per_s"] = M / cycle
         out[name] = g
     a = out["all_cores"]
+    # the small-N regime on the host: one-point mean predict and one LML + gradient of the CPU port (all BLAS threads)
+    small = {}
+    for Ns, ds in SMALL_N_CASES:
+        bounds_s, Xs_, ys_, Xq_, theta_s = _small_problem(Ns, ds)
+        m = orc.OracleGPR(bounds_s, kernel_id=orc.MATERN52)
+        m.theta = theta_s
+        m.fitted = True
+        m.append_to_data(Xs_, ys_, fit_gpr=False, fit_preprocessors=True)
+        small[f"N{Ns}_d{ds}"] = {
+            "predict_1pt_us": _per_call_us(lambda: m.predict(Xq_[:1]), 300),
+            "lml_grad_us": _per_call_us(lambda: orc.log_marginal_likelihood(m.X_train_, m.y_train_, m.alpha, theta_s, orc.MATERN52,
+                                                                          eval_gradient=True), 20 if Ns <= 256 else 3)}
     return {
+        "small_n": small,
         "value": a["candidates_per_s"], "unit": "candidates/s", "cores": min(threads, affinity),
         "kind": "port",
         "sample": (f"oracle/gpry_oracle.py on host, {threads} BLAS threads: 1 LML+grad at N="
@@ -287,6 +300,67 @@ def refit_extras(bounds, X, y):
         ev = g.n_eval_loglike - e0
         out[name] = {"ms": dt * 1e3, "lml_grad_evals": ev, "ms_per_eval": dt * 1e3 / max(ev, 1),
                      "lml": float(g.log_marginal_likelihood_value_), "N_train": g.n}
+        del g
+    return out
+
+
+SMALL_N_CASES = ((64, 2), (128, 4), (256, 4), (1024, 8))
+
+
+def _small_problem(N, d):
+    rng = np.random.default_rng(100 + N)
+    bounds = np.array([[-5.0, 5.0]] * d)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = -0.5 * (X ** 2).sum(axis=1) / d
+    return bounds, X, y, rng.uniform(-5, 5, size=(512, d)), np.log(np.array([4.0] + [0.3] * d))
+
+
+def _per_call_us(fn, reps):
+    for _ in range(max(3, reps // 10)):
+        fn()
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        best = min(best, (time.perf_counter() - t0) / reps * 1e6)
+    return best
+
+
+def small_n_extras():
+    """Not the headline: the regime most GPry iterations live in: one-point
+    mean ``predict`` -- what PolyChord / UltraNest / MCMC call 1e4..1e6 times per acquisition step,
+    gpry/gp_acquisition.py:766-771 -- and one LML + gradient evaluation at small N, through the mirror class, wall clock per
+    call; the resident predict kernel (csrc/server.hip) and the single-launch objective (csrc/lml_small.hip) against the
+    one-launch-per-call / 19-kernel paths of round 2."""
+    from gpry_amd.kernels import clone
+    out = {}
+    for N, d in SMALL_N_CASES:
+        bounds, X, y, Xq, theta = _small_problem(N, d)
+        g = make_gpr(bounds)
+        k = clone(g.kernel)
+        k.theta = theta
+        g.kernel_, g._fitted = k, True
+        g.append_to_data(X, y, fit_gpr=False)
+        dev = g.device
+        it = {"i": 0}
+
+        def one_point():
+            it["i"] = (it["i"] + 1) % len(Xq)
+            return g.predict(Xq[it["i"]:it["i"] + 1], return_std=False, validate=False)
+
+        row = {}
+        for serve in (1, 0):
+            dev.set_option("predict_serve", serve)
+            row["predict_1pt_us" if serve else "predict_1pt_us_one_launch_per_call"] = _per_call_us(one_point, 2000)
+        dev.set_option("predict_serve", 1)
+        for small in (1, 0):
+            dev.set_option("lml_small", small)
+            key = "lml_grad_us" if small else "lml_grad_us_general_chain"
+            row[key] = _per_call_us(lambda: g.log_marginal_likelihood(theta, eval_gradient=True), 200 if N <= 256 else 50)
+        dev.set_option("lml_small", 1)
+        row["single_launch_objective"] = bool(N <= 128 and d <= 16)
+        out[f"N{N}_d{d}"] = row
         del g
     return out
 
@@ -780,6 +854,10 @@ def main(argv=None):
             result["refit_extras"] = refit_extras(bounds, gpr.X_train_all.copy(), gpr.y_train_all.copy())
         except Exception as e:
             result["refit_extras"] = {"error": repr(e)}
+        try:
+            result["small_n"] = small_n_extras()
+        except Exception as e:
+            result["small_n"] = {"error": repr(e)}
     if rank == 0 and world == 1 and args.cpu_baseline == "auto":
         try:
             result["cpu_baseline"] = cpu_baseline(N, d, args.M, lml_evals, cache_models / K)

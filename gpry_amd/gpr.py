@@ -580,25 +580,32 @@ class GaussianProcessRegressor(_RM, _BE):
             return self.log_marginal_likelihood_value_
         theta = np.asarray(theta, dtype=float)
         kernel = self.kernel_ if self.kernel_ is not None else clone(self.kernel)
+        fast = hasattr(kernel, "set_theta_and_full")
         if clone_kernel:
             kernel = kernel.clone_with_theta(theta)
+            kid, theta_full = kernel.device_spec(self.d)
         else:
             if self.kernel_ is None:
                 self.kernel_ = kernel
-            kernel.theta = theta          # same side effect as the reference
+            if fast:                      # same side effect as the reference: kernel_.theta = theta
+                kid, theta_full = kernel.set_theta_and_full(theta, self.d)
+            else:
+                kernel.theta = theta
+                kid, theta_full = kernel.device_spec(self.d)
             self._dev_factor_ok = False
             self._host_factor = {}
             self._kb = None
-        self._upload_train()
-        kid, theta_full = kernel.device_spec(self.d)
-        if self.device.N != len(self.y_train_):
+        if not self._dev_train_ok:
+            self._upload_train()
+        dev = self._dev if self._dev is not None else self.device
+        if dev.N != len(self.y_train_):
             raise RuntimeError("device training set out of sync")
         if eval_gradient:
-            lml, grad_full, _ = self.device.lml(theta_full, True)
+            lml, grad_full, _ = dev.lml(theta_full, True)
             if not np.isfinite(lml):
                 return -np.inf, np.zeros_like(theta)
-            return lml, kernel.grad_from_full(grad_full, self.d)
-        lml, _ = self.device.lml(theta_full, False)
+            return lml, (kernel.grad_from_full_fast(grad_full, self.d) if fast else kernel.grad_from_full(grad_full, self.d))
+        lml, _ = dev.lml(theta_full, False)
         return lml if np.isfinite(lml) else -np.inf
 
     def fit_gpr_hyperparameters(self, simple=False, start_from_current=True, n_restarts=None,
@@ -724,14 +731,19 @@ class GaussianProcessRegressor(_RM, _BE):
         def worker(k):
             dev, kern = devs[k], clone(kern0)
 
+            fast = hasattr(kern, "set_theta_and_full")
+
             def obj_func(theta, eval_gradient=True):
                 counts[k] += 1
-                kern.theta = np.asarray(theta, dtype=float)
-                full = kern.device_spec(self.d)[1]
+                if fast:
+                    full = kern.set_theta_and_full(theta, self.d)[1]
+                else:
+                    kern.theta = np.asarray(theta, dtype=float)
+                    full = kern.device_spec(self.d)[1]
                 lml, grad_full, _ = dev.lml(full, True)
                 if not np.isfinite(lml):
                     return np.inf, np.zeros_like(theta)
-                return -lml, -kern.grad_from_full(grad_full, self.d)
+                return -lml, -(kern.grad_from_full_fast(grad_full, self.d) if fast else kern.grad_from_full(grad_full, self.d))
 
             try:
                 while True:
