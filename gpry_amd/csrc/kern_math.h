@@ -124,13 +124,15 @@ static AffParams make_ap(gpry_ctx* ctx, bool use_affine) {
 // raw coordinates of the point (any address space the caller can read: mapped host memory, LDS, global).  Shared by
 // the one-launch kernel (predict_mean_small_kernel) and the resident one (server.hip): whichever of the two serves
 // a call, the bits are the same.
-#define MEAN_SLICE_CH 4096        // rows per LDS chunk
-template <int DP, int KID>
+#define MEAN_SLICE_CH 4096        // rows per LDS chunk of the one-launch kernel
+// CH: rows per chunk (the size of r2s).  `base`: Xs / alpha_ hold the rows from `base` on (0: the arrays of the context
+// in global memory; row_lo: a copy of this slice that the resident kernel keeps in LDS) -- the values and the order of
+// every sum are the same either way.
+template <int DP, int KID, int CH = MEAN_SLICE_CH>
 __device__ __forceinline__ double mean_slice(const double* x, const double* __restrict__ Xs, const double* __restrict__ alpha_,
                                              int64_t row_lo, int64_t rows_per_split, const KernParams& kp, const AffParams& ap,
-                                             double* r2s /*[MEAN_SLICE_CH]*/, double* red /*[256]*/) {
+                                             double* r2s /*[CH]*/, double* red /*[256]*/, int64_t base = 0) {
     constexpr int P = DP / 2;             // lanes per training row: one 16-byte piece each
-    constexpr int CH = MEAN_SLICE_CH;
     const int t = threadIdx.x, sub = t % P, rloc = t / P;
     // this lane's two scaled coordinates of the point
     double x0 = 0.0, x1 = 0.0;
@@ -154,7 +156,7 @@ __device__ __forceinline__ double mean_slice(const double* x, const double* __re
                 const int row = r0 + u * RP + rloc;
                 v[u] = make_double2(0.0, 0.0);
                 if (row < nrow && piece_ok)
-                    v[u] = *reinterpret_cast<const double2*>(Xs + (c0 + row) * kp.dpad + 2 * sub);
+                    v[u] = *reinterpret_cast<const double2*>(Xs + (c0 - base + row) * kp.dpad + 2 * sub);
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -173,19 +175,29 @@ __device__ __forceinline__ double mean_slice(const double* x, const double* __re
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int j = j0 + 256 * q;
-                v[q] = j < nrow ? alpha_[c0 + j] * (kp.C * corr_r2_fast<KID>(r2s[j])) : 0.0;
+                v[q] = j < nrow ? alpha_[c0 - base + j] * (kp.C * corr_r2_fast<KID>(r2s[j])) : 0.0;
             }
             acc += (v[0] + v[1]) + (v[2] + v[3]);
         }
         __syncthreads();
     }
+    // The binary tree over the 256 partial sums -- red[t] += red[t + s] for s = 128, 64, ..., 1 -- with ONE barrier: the
+    // two cross-wave levels are read back by wave 0, the six levels inside it are cross-lane adds with the same pairs
+    // (t, t + s), so the result is the tree's to the last bit (the eight barriers of the loop form were 0.8 us of a
+    // request the resident kernel answers in ~3).
     red[t] = acc;
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if (t < s) red[t] += red[t + s];
-        __syncthreads();
+    double out = 0.0;
+    if (t < 64) {
+        double v = (red[t] + red[t + 128]) + (red[t + 64] + red[t + 192]);
+        v += __shfl_down(v, 32);
+        v += __shfl_down(v, 16);
+        v += __shfl_down(v, 8);
+        v += __shfl_down(v, 4);
+        v += __shfl_down(v, 2);
+        v += __shfl_down(v, 1);
+        out = v;
     }
-    const double out = red[0];
     __syncthreads();          // `red` may be reused by the caller's next point
     return out;
 }

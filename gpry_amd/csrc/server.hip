@@ -56,6 +56,7 @@ struct SrvArgs {
     unsigned long long gen;
     long long idle_ticks;      // wall_clock64 ticks (100 MHz) without a request before the kernel leaves
     int64_t rows_per_split;
+    int cached;                // this launch keeps its slices of Xs / alpha_ in LDS
     // gates (gpry_set_gates) evaluated per point by the leader when the context applies them to gpry_predict
     const double* gate_sv; const double* gate_coef; const double* gate_trust;
     int64_t gate_nsv; double gate_gamma, gate_intercept;
@@ -102,7 +103,10 @@ __device__ __forceinline__ unsigned srv_gate_bits(const double* x, const SrvArgs
     return bits;
 }
 
+#define SRV_CACHE_ROWS 1024
+#define SRV_CACHE_DOUBLES 16384           // 128 KB of the 160 KB of a CU
 typedef unsigned int srv_u4 __attribute__((ext_vector_type(4)));
+
 
 // one 16-byte unit, system scope (the mailbox is fine-grained host memory: nothing may be served from a cache)
 __device__ __forceinline__ SrvUnit srv_load_sys(const SrvUnit* p) {
@@ -120,11 +124,25 @@ __device__ __forceinline__ void srv_store_sys(SrvUnit* p, unsigned long long pay
 
 template <int DP, int KID>
 __global__ __launch_bounds__(256) void predict_server_kernel(SrvArgs a, KernParams kp, AffParams ap) {
-    __shared__ double r2s[MEAN_SLICE_CH];
+    // The slice of the model this workgroup owns stays in LDS for the life of the kernel when it fits (<= 1024 rows,
+    // rows x dpad <= 16384 doubles): a request then touches no global memory but the mailbox.
+    __shared__ __attribute__((aligned(16))) double xs_c[SRV_CACHE_DOUBLES];
+    __shared__ double al_c[SRV_CACHE_ROWS];
+    __shared__ double r2s[SRV_CACHE_ROWS];
     __shared__ double red[256];
     __shared__ double s_x[SRV_MAXM * GPRY_MAX_DIM];
     __shared__ unsigned long long s_hdr;
     const int t = threadIdx.x, g = blockIdx.x;
+    const int64_t row_lo = (int64_t)g * a.rows_per_split;
+    if (a.cached) {
+        const int64_t nrows = a.rows_per_split;
+        for (int64_t e = t; e < nrows * kp.dpad; e += 256) {
+            const int64_t row = row_lo + e / kp.dpad;
+            xs_c[e] = row < kp.N ? a.Xs[row_lo * kp.dpad + e] : 0.0;
+        }
+        for (int64_t r = t; r < nrows; r += 256) al_c[r] = row_lo + r < kp.N ? a.alpha_[row_lo + r] : 0.0;
+        __syncthreads();
+    }
     unsigned long long last = a.seq0;
     long long t_last = wall_clock64();
     int polls = 0;
@@ -198,8 +216,10 @@ __global__ __launch_bounds__(256) void predict_server_kernel(SrvArgs a, KernPara
         const int M = (int)(hdr & 0xff);
         const unsigned long long seq = last + 1;
         for (int m = 0; m < M; m++) {
-            const double v = mean_slice<DP, KID>(s_x + m * kp.d, a.Xs, a.alpha_, (int64_t)g * a.rows_per_split, a.rows_per_split,
-                                                 kp, ap, r2s, red);
+            // (the one-launch kernel walks chunks of 4096 rows; a slice of <= 1024 rows is one chunk either way: same sums)
+            const double v = a.cached
+                ? mean_slice<DP, KID, SRV_CACHE_ROWS>(s_x + m * kp.d, xs_c, al_c, row_lo, a.rows_per_split, kp, ap, r2s, red, row_lo)
+                : mean_slice<DP, KID>(s_x + m * kp.d, a.Xs, a.alpha_, row_lo, a.rows_per_split, kp, ap, xs_c, red);   // (xs_c: free, serves as the 4096-row r2 buffer)
             if (t == 0) srv_store_sys(a.res + g * SRV_MAXM + m, (unsigned long long)__double_as_longlong(v), seq);
             if (a.gates && g == 0) {
                 const unsigned bits = srv_gate_bits(s_x + m * kp.d, a, kp, ap, red);
@@ -296,6 +316,7 @@ static int srv_launch(gpry_ctx* ctx, SrvHost* s) {
     a.seq0 = s->seq - 1;
     a.idle_ticks = (long long)ctx->opt_serve_idle_us * 100;       // wall_clock64: 100 MHz
     a.rows_per_split = round_up((ctx->N + nsplit - 1) / nsplit, 32);
+    a.cached = a.rows_per_split <= SRV_CACHE_ROWS && a.rows_per_split * ctx->dpad <= SRV_CACHE_DOUBLES;
     a.gates = ctx->gates_on && ctx->opt_predict_gates;
     s->gates = a.gates;
     a.gate_sv = ctx->gate_sv; a.gate_coef = ctx->gate_coef; a.gate_trust = ctx->gate_trust;
