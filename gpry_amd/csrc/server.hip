@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void predict_server_kernel(SrvArgs a, KernPara
                     const bool fresh = t >= nfirst || u.stamp == last + 1;
                     if (__all(fresh)) {
                         hdr = __shfl(u.payload, 0);
-                        const int nd = (int)(hdr & 0xff) * kp.d;
+                        if ((hdr >> 56) == SRV_CMD_PREDICT && ((hdr & 0xff) == 0 || (hdr & 0xff) > SRV_MAXM)) hdr = SRV_CMD_QUIT << 56;   // malformed: leave
+                        const int nd = (hdr >> 56) == SRV_CMD_PREDICT ? (int)(hdr & 0xff) * kp.d : 0;
                         if (t >= 1 && t <= kp.d) s_x[t - 1] = __longlong_as_double((long long)u.payload);
                         // further points of the request: their units may still be on their way
                         bool all = true;
