@@ -10,16 +10,16 @@
 //   B  K = C k(r) + diag(noise), lower 16 x 16 tiles                    -> M[128][130]        133 KB
 //   C  M <- chol(M): dataflow between the waves, wave w owns block row w (chol16_wave / trsm16_rows / MFMA rank-16
 //      updates: the building blocks of chol_panel.hip), only the ceil(N / 16) blocks that hold training rows
-//   D  sum log L_ii
-//   E  diagonal blocks W_jj = L_jj^-1 in place (column substitution, reciprocal pivots of the factor)
-//   F  V = L^-1 IN PLACE, block columns from right to left:  V[m][j] = -(sum_{k=j+1..m} V[m][k] L[k][j]) W_jj
+//   D  log L_ii;  E  diagonal blocks W_jj = L_jj^-1 (column substitution with the factor's reciprocal pivots), by the
+//      wave that has just factored block j, into registers, while the chain goes on; stored after the barrier
+//   F  V = L^-1 IN PLACE by recursive doubling over the tiles: T = L21 V11 replaces L21, V21 = -V22 T replaces T
 //   G  z = V y, quad = z.z, alpha = V^T z
 //   H  per lower 16 x 16 tile: K^-1 tile = sum_k V[k][i] V[k][j] (MFMA, accumulators only: K^-1 is never stored),
 //      W = alpha alpha^T - K^-1 contracted at once with dK/dtheta (distances recomputed from xs, as lml_traces_kernel)
-//   I  results + factorisation status straight into the mapped host buffer of gpry_lml
+//   I  results + factorisation status as stamped 16-byte units into the mapped host buffer (LsUnit below)
 //
-// One row stride (130 doubles) serves every MFMA fragment read of the three operand layouts without bank conflicts
-// worth noting.  The factor does NOT travel back to HBM: gpry_factorize cannot adopt it (lml_cache stays false) and
+// One row stride (130 doubles) keeps the row-wise MFMA fragment reads conflict-free and the k-wise ones 2-way.  The
+// factor does NOT travel back to HBM: gpry_factorize cannot adopt it (lml_cache stays false) and
 // runs the general chain once per fit -- the prediction factor keeps its operation order.
 #include "kern_math.h"
 #include "chol16.h"
