@@ -488,3 +488,76 @@ def test_predict_with_gradients_and_border_path_of_the_mirror_on_the_cpu_double(
     np.testing.assert_allclose(s, g["f10b_std"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(mg, g["f10b_mean_grad"], rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(sg, g["f10b_std_grad"], rtol=1e-4, atol=1e-6)
+
+
+def test_predict_leaves_classifier_and_trust_box_to_a_device_that_applies_them():
+    """``GaussianProcessRegressor.predict`` with GPry's defaults (account_for_inf="SVM", a trust region): when the
+    context applies the gates itself (``applies_gates_in_predict``, the C option ``predict_gates``) the mirror sends no
+    host mask and the gates travel to the device only when classifier, trust box or the ignore flag changed
+    (``_sync_gates``); results equal the host-mask path (gpry/gpr.py:1107-1112, 1145-1150 -> gpry/svm.py:308-347)."""
+    from oracle_device import OracleDevice
+    from oracle import gpry_oracle as orc
+    from gpry_amd.kernels import clone
+
+    class GatedDouble(OracleDevice):
+        applies_gates_in_predict = True
+        n_set_gates = 0
+        n_masked_calls = 0
+
+        def set_gates(self, *a, **k):
+            type(self).n_set_gates += 1
+            super().set_gates(*a, **k)
+
+        def predict(self, X, return_std=False, mask=None):
+            if mask is not None:
+                type(self).n_masked_calls += 1
+            elif getattr(self, "gates", None) is not None:
+                mask = self._gate_bits(np.atleast_2d(X))
+            return super().predict(X, return_std=return_std, mask=mask)
+
+    bounds, X, y, Xc = orc.synthetic_like_goldens(150, 3, 400, seed=9)
+    y = y.copy()
+    y[X[:, 0] > 1.0] = -np.inf
+
+    def build(kind):
+        g = make_gpr(bounds, 3, account_for_inf="SVM", inf_threshold="20s", trust_region_factor=1.5, random_state=1)
+        g._dev = kind()
+        k = clone(g.kernel)
+        k.theta = np.log(np.array([4.0, 0.3, 0.3, 0.3]))
+        g.kernel_, g._fitted = k, True
+        g.append_to_data(X, y, fit_gpr=False)
+        return g
+
+    dev_g, host_g = build(GatedDouble), build(OracleDevice)
+    a = np.array([dev_g.predict(x[None, :], validate=False)[0] for x in Xc[:120]])
+    b = np.array([host_g.predict(x[None, :], validate=False)[0] for x in Xc[:120]])
+    np.testing.assert_array_equal(a, b)
+    assert 5 < np.isneginf(a).sum() < 115
+    assert GatedDouble.n_set_gates == 1 and GatedDouble.n_masked_calls == 0        # one upload for 120 calls, no host mask
+    ma, sa = dev_g.predict(Xc, return_std=True)
+    mb, sb = host_g.predict(Xc, return_std=True)
+    np.testing.assert_array_equal(ma, mb)
+    np.testing.assert_array_equal(sa, sb)
+    assert GatedDouble.n_set_gates == 1
+    # another gate set: the trust box switched off
+    np.testing.assert_array_equal(dev_g.predict(Xc[:50], ignore_trust_region=True), host_g.predict(Xc[:50], ignore_trust_region=True))
+    assert GatedDouble.n_set_gates == 2
+    np.testing.assert_array_equal(dev_g.predict(Xc[:50]), host_g.predict(Xc[:50]))     # (same batch size: same BLAS sums)
+    assert GatedDouble.n_set_gates == 3
+    # the x-gradient branch needs the verdict on the host: the device gates are cleared for it, and come back afterwards
+    x1 = Xc[np.flatnonzero(np.isfinite(a))[0]][None, :]
+    ga = dev_g.predict(x1, return_std=True, return_mean_grad=True)
+    gb = host_g.predict(x1, return_std=True, return_mean_grad=True)
+    for u, v in zip(ga, gb):
+        np.testing.assert_array_equal(u, v)
+    assert GatedDouble.n_masked_calls == 1 and dev_g.device.gates is None
+    np.testing.assert_array_equal(dev_g.predict(Xc[:50]), host_g.predict(Xc[:50]))
+    assert dev_g.device.gates is not None
+    # new data refits the classifier: its decision function reaches the device again
+    n0 = GatedDouble.n_set_gates
+    Xn = Xc[:20]
+    yn = np.where(Xn[:, 0] > 0.5, -np.inf, -1.0)
+    for g in (dev_g, host_g):
+        g.append_to_data(Xn, yn, fit_gpr=False)
+    np.testing.assert_array_equal(dev_g.predict(Xc[100:300]), host_g.predict(Xc[100:300]))
+    assert GatedDouble.n_set_gates == n0 + 1
