@@ -55,7 +55,7 @@ def test_a_failing_rank_ends_the_group_with_its_code():
 
 
 def test_the_watchdog_ends_a_hanging_run():
-    out = _launch(2, ["--allow-gloo"], {"GPRY_BENCH_DOUBLE_HANG_RANK": "1"}, timeout=40)
+    out = _launch(2, ["--allow-gloo"], {"GPRY_BENCH_DOUBLE_HANG_RANK": "1"}, timeout=12)
     assert out.returncode != 0 and "time limit" in out.stderr
     assert not out.stdout.strip()
 
