@@ -491,7 +491,7 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
             GemmArgs g = {};
             g.A = ctx->dV; g.lda = Np; g.B = Kst; g.ldb = mcp; g.C = ss_part; g.ldc = mcp;
             g.M = (int)Np; g.N = (int)mcp; g.K = (int)Np;
-            g.kmode = KM_A_LOWER; g.lower_only = 0; g.tile_map = TM_SWEEP | (ctx->opt_sweep_tilemap << 4) | (ctx->opt_sweep_colouter << 8); g.stagger = ctx->opt_sweep_stagger; g.extra_lds = ctx->opt_sweep_extra_lds; g.kskew = ctx->opt_sweep_kskew; g.persist = ctx->opt_sweep_persist;
+            g.kmode = KM_A_LOWER; g.lower_only = 0; g.tile_map = TM_SWEEP | (ctx->opt_sweep_tilemap << 4) | (ctx->opt_sweep_colouter << 8) | (ctx->opt_sweep_altwalk << 9); g.stagger = ctx->opt_sweep_stagger; g.extra_lds = ctx->opt_sweep_extra_lds; g.kskew = ctx->opt_sweep_kskew; g.persist = ctx->opt_sweep_persist;
             if (ctx->opt_sweep_diag) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); g.diag = ctx->dsel + 16; }
             if (ctx->opt_sweep_dma == 3) GPRY_TRY(sweep_gemm_dma_sp_launch(ctx, g));
             else if (ctx->opt_sweep_dma == 2 && !ctx->opt_sweep_diag && mcp % 256 == 0) GPRY_TRY(sweep_gemm_dma256_launch(ctx, g));

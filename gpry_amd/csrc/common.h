@@ -35,6 +35,7 @@ struct gpry_ctx {
     int64_t opt_sweep_chunk = 32768;
     int opt_timing = 0;          // per-stage HIP-event timers: off until gpry_timing_reset (or "timing" = 1) asks for them
     int opt_sweep_colouter = 0;  // 1: super-tiles ordered candidate super-column outermost
+    int opt_sweep_altwalk = 1;   // 1 (default): super-tiles of an XCD alternate the direction of their k walk (sweep_dma=3, grid launch)
     int opt_sweep_tilemap = 3;   // log2 of V row-tiles per 64-tile super-tile
     int opt_sweep_stagger = 0;
     int opt_sweep_extra_lds = 0;

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
     int q_next = 0;
     if (PERSIST && threadIdx.x == 0) q_next = atomicAdd(&g.sched[vx], 1);
     int ti, tj;
-    bool valid;
+    bool valid, desc;
     {
         const int s = (q >> 6) * 8 + vx, within = q & 63;
         // tile_map bit 8: candidate super-column outermost (the K*^T columns of a super-column stay in
@@ -412,16 +412,37 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
         // index rotates with the round so that every XCD sees every row length)
         const bool col_outer = ((g.tile_map >> 8) & 1) && nsi <= 8 && 8 % nsi == 0;
         const int rnd = s >> 3;
-        const int si = col_outer ? nsi - 1 - ((vx % nsi + rnd) % nsi) : nsi - 1 - s / nsj;
-        const int sj = col_outer ? rnd * (8 / nsi) + vx / nsi : s % nsj;
-        ti = (si << ta) + (within >> tc);
+        int si = col_outer ? nsi - 1 - ((vx % nsi + rnd) % nsi) : nsi - 1 - s / nsj;
+        int sj = col_outer ? rnd * (8 / nsi) + vx / nsi : s % nsj;
+        int rowin = within >> tc;
+        // tile_map bit 9: alternating k walk.  The 64 tiles of a super-tile fill the 64 slots of an XCD, and the
+        // eight tiles of a row tile run in lockstep (equal length), so the V panel is fetched once per XCD; the K*^T
+        // panel is shared across the eight ROW tiles only while these sit at the same k, and row tiles differ by
+        // eight slabs in length.  A super-tile whose tiles start together and walk k upwards is aligned and frees its
+        // slots row by row, shortest first, eight slab times apart; if the next super-tile of the XCD hands those
+        // slots to its rows LONGEST first and walks k DOWNWARDS, its rows meet at the same k again (start skew =
+        // length difference) and finish together, and the one after that starts aligned.  So the super-tiles of an
+        // XCD alternate between two adjacent super-rows: odd positions walk down with their rows reversed.  The
+        // direction is a function of the row tile alone, so a candidate's bits do not depend on where its
+        // column falls in a launch (sharded = unsharded).
+        const bool alt = (g.tile_map >> 9) & 1;
+        if (alt && !col_outer && !(nsi & 1) && (nsj & 7) == 0) {
+            const int n = q >> 6, per_pair = nsj >> 2;        // 2 super-rows x nsj/8 super-tiles per XCD
+            const int pair = n / per_pair, n2 = n - pair * per_pair, odd = n2 & 1;
+            si = nsi - 1 - 2 * pair - odd;
+            sj = (n2 >> 1) * 8 + vx;
+            if (odd) rowin = (1 << ta) - 1 - rowin;
+        }
+        desc = alt && ((nsi - 1 - si) & 1);
+        ti = (si << ta) + rowin;
         tj = (sj << tc) + (within & ((1 << tc) - 1));
-        valid = s < nsi * nsj && ti < tiles_m && tj < tiles_n;
+        valid = s < nsi * nsj && si >= 0 && ti < tiles_m && tj < tiles_n;
     }
     if (valid) {
     const int row0 = ti * BM, col0 = tj * BN;
-    const int kend = min(K, row0 + BM);
+    const int kend = ((g.tile_map >> 10) & 1) ? K : min(K, row0 + BM);   // bit 10 (experiments only): every row tile walks all of K
     const int nslab = kend / BK;          // multiple of 8
+    const int kfirst = desc ? (nslab - 1) * BK : 0, kstep = desc ? -BK : BK;
 
     const double* srcA[4];
     int dstA[4];
@@ -438,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
     auto issue = [&](int s, int buf) {
         double* As = smem + buf * BUF_DOUBLES;
         double* Bs = As + A_DOUBLES;
-        const int k0 = s * BK;
+        const int k0 = kfirst + s * kstep;
 #pragma unroll
         for (int j = 0; j < 4; j++) dma16(srcA[j] + k0, As + dstA[j]);
 #pragma unroll
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
     auto issue_piece = [&](int s, int buf, int j) {
         double* As = smem + buf * BUF_DOUBLES;
         double* Bs = As + A_DOUBLES;
-        const int k0 = s * BK;
+        const int k0 = kfirst + s * kstep;
         if (j < 4) dma16(srcA[j] + k0, As + dstA[j]);
         else dma16(srcB + (int64_t)(k0 + j - 4) * g.ldb, Bs + (wave * 4 + j - 4) * SMC);
     };

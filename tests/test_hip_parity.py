@@ -657,6 +657,42 @@ def test_split_k_contraction_of_small_batches_equals_the_one_pass_contraction(de
     assert np.max(np.abs(std_s[keep] ** 2 - rs[keep] ** 2)) <= 1e-9 * C
 
 
+@pytest.mark.parametrize("N", [2048, 2300, 4096])
+def test_sweep_with_alternating_k_walk_is_chunking_independent_and_matches_the_upward_walk(dev, N):
+    """The super-tiles of an XCD alternate the direction of their k walk so that the row tiles of a super-tile sit at
+    the same k and share the K*^T panel in L2.  The direction is a function of the row tile
+    alone: the bits of a candidate's sigma must not depend on the chunking (which moves its column inside a launch and
+    switches between the paired and the plain super-tile order), the mean is untouched, and against the upward walk the
+    variance moves by rounding only; both agree with the oracle."""
+    d, M = 6, 21000
+    bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M, seed=41)
+    m = orc.OracleGPR(bounds, kernel_id=3)
+    m.theta = np.log(np.array([4.0] + [0.3] * d))
+    m.fitted = True
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
+    res = {}
+    try:
+        for alt in (1, 0):
+            for chunk in (8192, 5120, 1024):
+                dev.set_option("sweep_altwalk", alt)
+                dev.set_option("sweep_chunk", chunk)
+                out = dev.sweep_logexp(Xc, 0.1, 0.0, 1e-2, want=("y", "sigma"))
+                res[alt, chunk] = (out["y"].copy(), out["sigma"].copy())
+    finally:
+        dev.set_option("sweep_altwalk", 1)
+        dev.set_option("sweep_chunk", 32768)
+    for alt in (1, 0):
+        for chunk in (5120, 1024):
+            np.testing.assert_array_equal(res[alt, chunk][1], res[alt, 8192][1])
+            np.testing.assert_array_equal(res[alt, chunk][0], res[alt, 8192][0])
+    np.testing.assert_array_equal(res[1, 8192][0], res[0, 8192][0])
+    assert np.max(np.abs(res[1, 8192][1] ** 2 - res[0, 8192][1] ** 2)) <= 1e-13 * C
+    rm, rs = m.predict(Xc[:3000], return_std=True)
+    assert np.max(np.abs(res[1, 8192][1][:3000] ** 2 - rs ** 2)) <= 1e-9 * C
+
+
 def test_f8_bordered_append_vs_reference(dev):
     """F8 through gpry_append_rows: the factor of the first 32 points is extended by border rows for the
     three appended ones (fixed theta, frozen pre-processors) and must match what the reference gets by

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 for cfg in ${1:-"3:0"}; do
   tm=${cfg%%:*}; ps=${cfg##*:}
-  out=gpurun_out/r02_traffic_${tm}_${ps}
+  out=gpurun_out/${TRAFFIC_TAG:-r02}_traffic_${tm}_${ps}_alt${GPRY_SWEEP_ALTWALK:-0}
   mkdir -p $out
   GPRY_SWEEP_PERSIST=$ps timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out -o t -- python3 tools/prof_sweep.py 4096 16 131072 32768 $tm 3 0 > $out/out.log 2>&1
   python3 - "$out" "$cfg" <<'PY'

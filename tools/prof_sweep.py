@@ -23,6 +23,7 @@ dev.set_option("sweep_tilemap", tilemap)
 dev.set_option("sweep_dma", dma)
 dev.set_option("sweep_kskew", kskew)
 dev.set_option("sweep_persist", int(os.environ.get("GPRY_SWEEP_PERSIST", "0")))
+dev.set_option("sweep_altwalk", int(os.environ.get("GPRY_SWEEP_ALTWALK", "0")))
 dev.set_option("sweep_colouter", int(os.environ.get("GPRY_SWEEP_COLOUTER", "0")))
 dev.set_train(X, y, np.full(N, 1e-4))
 dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
