@@ -27,19 +27,25 @@ class AcquisitionFunction:
         return np.atleast_2d(X)
 
 
+def _quiet_predict(gp, X, with_gradients):
+    """``gp.predict`` with std (and both x-gradients); the GP's warnings about clipped variances are not the caller's."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if with_gradients:
+            return gp.predict(X, return_std=True, return_mean_grad=True, return_std_grad=True)
+        return gp.predict(X, return_std=True) + (None, None)
+
+
 class LogExp(AcquisitionFunction):
     r"""``log A = 2 zeta (mu - baseline) + log sqrt(max(sigma^2 - sigma_n^2, 0))``."""
 
     def __init__(self, zeta=None, sigma_n=None, fixed=False, dimension=None, zeta_scaling=0.85,
                  linear=True):
-        if zeta is None:
-            if dimension is None:
-                raise ValueError("We need the dimensionality of the problem to guess an "
-                                 "appropriate zeta value.")
-            zeta = self.auto_zeta(dimension, scaling=zeta_scaling)
-        self.zeta = zeta
-        self.sigma_n = sigma_n
-        self.fixed = fixed
+        if zeta is None and dimension is None:
+            raise ValueError("We need the dimensionality of the problem to guess an "
+                             "appropriate zeta value.")
+        self.zeta = self.auto_zeta(dimension, scaling=zeta_scaling) if zeta is None else zeta
+        self.sigma_n, self.fixed = sigma_n, fixed
         self.hasgradient = True      # x-gradient branch of __call__ (gpry/acquisition_functions.py:993-1007)
 
     @staticmethod
@@ -54,42 +60,36 @@ class LogExp(AcquisitionFunction):
             return (2 * zeta * (mu - baseline) +
                     np.log(np.sqrt(np.maximum(std ** 2. - noise_level ** 2., 0.))))
 
+    def _noise(self, gp):
+        """(scalar noise of the value, noise as the gradient uses it): the reference averages a per-point
+        ``gp.noise_level`` for the value but divides by the raw one in the gradient (:993-1007)."""
+        if self.sigma_n is not None:
+            return self.sigma_n, self.sigma_n
+        raw = gp.noise_level
+        return (np.mean(raw) if isinstance(raw, Iterable) else raw), raw
+
     def __call__(self, X, gp, eval_gradient=False):
-        """Value (and x-gradient, gpry/acquisition_functions.py:937-1009) at ``X``."""
-        X = self.check_X(X)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            if eval_gradient:
-                mu, std, mu_grad, std_grad = gp.predict(X, return_std=True, return_mean_grad=True,
-                                                        return_std_grad=True)
-            else:
-                mu, std = gp.predict(X, return_std=True)
-        if self.sigma_n is None:
-            sigma_n = gp.noise_level
-            noise = np.mean(sigma_n) if isinstance(sigma_n, Iterable) else sigma_n
-        else:
-            noise = sigma_n = self.sigma_n
-        var = std ** 2 - noise ** 2.
-        mask = (var > 0) & np.isfinite(mu)
+        """Value (and x-gradient, gpry/acquisition_functions.py:937-1009) at ``X``: -inf (gradient +inf) where the
+        mean is not finite or the variance does not exceed the noise."""
+        mu, std, mu_grad, std_grad = _quiet_predict(gp, self.check_X(X), eval_gradient)
+        noise, sigma_n = self._noise(gp)
+        informative = (std ** 2 - noise ** 2. > 0) & np.isfinite(mu)
         values = np.full_like(std, -np.inf)
-        if np.any(mask):
-            values[mask] = self.f(mu[mask], std[mask], gp.y_max, noise, self.zeta)
+        if informative.any():
+            values[informative] = self.f(mu[informative], std[informative], gp.y_max, noise, self.zeta)
         if not eval_gradient:
             return values
-        # the reference's gradient: std_grad / (std - sigma_n) + 2 zeta mu_grad, +inf where
-        # std <= sigma_n (:993-1007; it uses the raw gp.noise_level here, as we do)
-        if np.array(std_grad).ndim > 1:
-            grad = np.zeros_like(std_grad)
-            if np.any(mask):
-                grad[mask] = np.array(std_grad)[mask] / (std[mask] - sigma_n) + \
-                    2 * self.zeta * np.array(mu_grad)[mask]
-            if np.any(~mask):
-                grad[~mask] = np.ones_like(std_grad[~mask]) * np.inf
-        elif std[0] > sigma_n:
-            grad = std_grad / (std[0] - sigma_n) + 2 * self.zeta * mu_grad
-        else:
-            grad = np.ones_like(std_grad) * np.inf
-        return values, grad
+        # std_grad / (std - sigma_n) + 2 zeta mu_grad
+        if np.ndim(std_grad) > 1:                       # one row per point
+            mu_grad, std_grad = np.asarray(mu_grad), np.asarray(std_grad)
+            grad = np.full_like(std_grad, np.inf)
+            if informative.any():
+                grad[informative] = (std_grad[informative] / (std[informative] - sigma_n)
+                                     + 2 * self.zeta * mu_grad[informative])
+            return values, grad
+        if std[0] > sigma_n:                            # a single point, gradients as vectors
+            return values, std_grad / (std[0] - sigma_n) + 2 * self.zeta * mu_grad
+        return values, np.full_like(std_grad, np.inf)
 
     def __repr__(self):
         return f"LogExp(zeta={self.zeta:.3f})"

@@ -1,112 +1,96 @@
 """Affine X / y maps used by the GP (host side; the device applies the same maps fused
 into its kernels through ``gpry_affine``).  Interfaces follow ``gpry/preprocessing.py``:
 ``Normalize_bounds`` (:311-411), ``Normalize_y`` (:528-630), ``DummyPreprocessor`` (:29-55).
+
+All three are ``v -> (v - origin) / width`` with a different source of (origin, width): nothing, the prior box, the
+moments of the finite training targets.  One base class carries the four directions of the map; the arithmetic
+(subtract then divide, multiply then add) is the reference's, so the transformed values have its bits.
 """
 import numpy as np
 
 
+def _unchanged(v, *unused, **unused_kw):
+    return v
+
+
 class DummyPreprocessor:
-    """Identity map; usable as a class (as the reference does) or as an instance."""
+    """The identity.  GPry passes the class itself around as well as instances, so nothing here binds ``self``."""
     is_linear = True
     fitted = True
-
-    @classmethod
-    def fit(cls, *args, **kwargs):
-        return None
-
-    @classmethod
-    def transform_bounds(cls, bounds):
-        return bounds
-
-    @classmethod
-    def transform(cls, v):
-        return v
-
-    @classmethod
-    def inverse_transform(cls, v):
-        return v
-
-    @classmethod
-    def transform_scale(cls, v):
-        return v
-
-    @classmethod
-    def inverse_transform_scale(cls, v):
-        return v
+    fit = staticmethod(lambda *args, **kwargs: None)
+    transform = inverse_transform = staticmethod(_unchanged)
+    transform_scale = inverse_transform_scale = staticmethod(_unchanged)
+    transform_bounds = staticmethod(_unchanged)
 
 
-class Normalize_bounds:
-    """Maps the prior box onto the unit cube: ``x_ = (x - lo) / (hi - lo)``."""
+class _AffineMap:
+    """``origin_width()`` -> (origin, width), per dimension or scalar."""
     is_linear = True
+
+    def origin_width(self):
+        raise NotImplementedError
+
+    def transform(self, v):
+        origin, width = self.origin_width()
+        return (v - origin) / width
+
+    def inverse_transform(self, v):
+        origin, width = self.origin_width()
+        return (v * width) + origin
+
+    def transform_scale(self, v):
+        return v / self.origin_width()[1]
+
+    def inverse_transform_scale(self, v):
+        return v * self.origin_width()[1]
+
+
+class Normalize_bounds(_AffineMap):
+    """Prior box -> unit cube."""
+    fitted = True
 
     def __init__(self, bounds):
         self.update_bounds(bounds)
-        self.fitted = True
 
     def update_bounds(self, bounds):
-        bounds = np.asarray(bounds)
-        if np.any(bounds[:, 0] > bounds[:, 1]):
-            raise ValueError(f"The bounds must be in dimension-wise order min->max, got \n{bounds}")
-        self.bounds = bounds
-        self.bounds_min = bounds[:, 0]
-        self.bounds_max = bounds[:, 1]
+        box = np.asarray(bounds)
+        lo, hi = box[:, 0], box[:, 1]
+        if (lo > hi).any():
+            raise ValueError(f"The bounds must be in dimension-wise order min->max, got \n{box}")
+        self.bounds, self.bounds_min, self.bounds_max = box, lo, hi
+
+    def origin_width(self):
+        return self.bounds_min, self.bounds_max - self.bounds_min
 
     def transform_bounds(self, bounds):
-        out = np.ones_like(bounds)
-        out[:, 0] = 0
-        return out
+        unit = np.ones_like(bounds)
+        unit[:, 0] = 0
+        return unit
 
     def fit(self, X, y):
-        """Nothing to fit: the map is fixed by the prior bounds."""
-
-    def transform(self, X):
-        return (X - self.bounds_min) / (self.bounds_max - self.bounds_min)
-
-    def inverse_transform(self, X):
-        return (X * (self.bounds_max - self.bounds_min)) + self.bounds_min
-
-    def inverse_transform_scale(self, X):
-        return X * (self.bounds_max - self.bounds_min)
+        """The map is fixed by the prior box."""
 
 
-class Normalize_y:
-    """Standardises targets with the mean / population std of the finite training values
-    (or median / inter-quartile range with ``use_median``)."""
-    is_linear = True
+class Normalize_y(_AffineMap):
+    """Centre and scale of the finite training targets: mean / population std, or median / inter-quartile range."""
 
     def __init__(self, use_median=False):
-        self.mean_ = None
-        self.std_ = None
         self.use_median = bool(use_median)
+        self.mean_ = self.std_ = None
 
     @property
     def fitted(self):
-        return self.mean_ is not None and self.std_ is not None
-
-    def _require_fit(self):
-        if not self.fitted:
-            raise TypeError("mean_ and std_ have not been fit before")
+        return not (self.mean_ is None or self.std_ is None)
 
     def fit(self, X, y):
-        y = y[np.isfinite(y)]
+        finite = y[np.isfinite(y)]
         if self.use_median:
-            q25, q50, q75 = np.percentile(y, [25, 50, 75])
-            self.mean_, self.std_ = q50, q75 - q25
+            quartiles = np.percentile(finite, [25, 50, 75])
+            self.mean_, self.std_ = quartiles[1], quartiles[2] - quartiles[0]
         else:
-            self.mean_, self.std_ = np.mean(y), np.std(y)
+            self.mean_, self.std_ = np.mean(finite), np.std(finite)
 
-    def transform(self, y):
-        self._require_fit()
-        return (y - self.mean_) / self.std_
-
-    def inverse_transform(self, y):
-        self._require_fit()
-        return (y * self.std_) + self.mean_
-
-    def transform_scale(self, scale):
-        self._require_fit()
-        return scale / self.std_
-
-    def inverse_transform_scale(self, scale):
-        self._require_fit()
-        return scale * self.std_
+    def origin_width(self):
+        if not self.fitted:
+            raise TypeError("mean_ and std_ have not been fit before")
+        return self.mean_, self.std_

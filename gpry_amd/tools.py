@@ -5,25 +5,25 @@ from scipy.stats import chi2
 
 
 def check_random_state(seed, convert_to_random_state=False):
-    """``gpry/tools.py:134-145``: numpy Generators pass through, the rest goes to sklearn's rule."""
+    """``gpry/tools.py:134-145``: a numpy ``Generator`` passes through (or is wrapped into a ``RandomState`` over the same
+    bit generator, for scikit-learn's estimators); ``None``, ints and ``RandomState`` follow scikit-learn's rule."""
+    rs_type = np.random.RandomState
     if isinstance(seed, np.random.Generator):
-        if convert_to_random_state:
-            return np.random.RandomState(seed.bit_generator)
+        return rs_type(seed.bit_generator) if convert_to_random_state else seed
+    if isinstance(seed, rs_type):
         return seed
     if seed is None or seed is np.random:
-        return np.random.mtrand._rand
+        return np.random.mtrand._rand           # numpy's global stream
     if isinstance(seed, (int, np.integer)):
-        return np.random.RandomState(seed)
-    if isinstance(seed, np.random.RandomState):
-        return seed
+        return rs_type(seed)
     raise ValueError(f"{seed!r} cannot be used to seed a numpy.random.RandomState instance")
 
 
 def get_random_generator(seed=None):
-    """Single-process form of ``gpry/mpi.py:31-50`` (first spawned child seed)."""
-    if isinstance(seed, np.random.Generator):
-        return seed
-    return np.random.default_rng(np.random.SeedSequence(seed).spawn(1)[0])
+    """Single-process form of ``gpry/mpi.py:31-50``: the first child of the seed sequence."""
+    if not isinstance(seed, np.random.Generator):
+        seed = np.random.default_rng(np.random.SeedSequence(seed).spawn(1)[0])
+    return seed
 
 
 def nstd_of_1d_nstd(n1, d):
@@ -37,84 +37,72 @@ def delta_logp_of_1d_nstd(n1, d):
 
 
 def generic_params_names(n, prefix="x_"):
-    return [prefix + str(i + 1) for i in range(int(n))]
+    return [f"{prefix}{k}" for k in range(1, int(n) + 1)]
 
 
 def get_Xnumber(value, X_letter, X_value=None, dtype=int, varname=None):
-    """Parse numbers like ``"5d"`` or ``"30d1.5"`` (``gpry/tools.py:185-234``).
-
-    With ``X_value=None`` returns ``(number, has_X, power)``.
-    """
-    if value == X_letter:
-        value = "1" + X_letter
-    has_X, power, num = False, None, value
+    """Numbers with a symbolic factor: ``"5d"`` = 5 x d, ``"30d1.5"`` = 30 x d^1.5, ``"d"`` = d, plain numbers as they
+    are (``gpry/tools.py:185-234``).  With ``X_value=None`` nothing is multiplied and the parts come back as
+    ``(number, has_X, power)``."""
+    coefficient, has_X, power = value, False, None
     if isinstance(value, str) and X_letter in value:
         has_X = True
-        num, power = value.split(X_letter)
-        num = num or 1
-        power = power or None
+        head, _, tail = value.partition(X_letter)
+        coefficient, power = head or 1, tail or None
     try:
-        num = float(num)
+        coefficient = float(coefficient)
+        exponent = None if power is None else float(power)
         if X_value is None:
-            return dtype(num), has_X, (None if power is None else float(power))
-        mult = 1
-        if has_X:
-            mult = X_value if power is None else X_value ** float(power)
-        return dtype(num * mult)
+            return dtype(coefficient), has_X, exponent
+        factor = 1 if not has_X else X_value if exponent is None else X_value ** exponent
+        return dtype(coefficient * factor)
     except (ValueError, TypeError) as excpt:
-        pre = f"Error setting variable '{varname}': " if varname else ""
-        raise ValueError(
-            pre + f"Could not convert {value} of type {type(value)} into type {dtype.__name__}. "
-            f"Pass either a string ending in '{X_letter}' or a valid {dtype.__name__} value."
-        ) from excpt
+        where = f"Error setting variable '{varname}': " if varname else ""
+        raise ValueError(f"{where}Could not convert {value} of type {type(value)} into type {dtype.__name__}. Pass "
+                         f"either a string ending in '{X_letter}' or a valid {dtype.__name__} value.") from excpt
 
 
 def check_and_return_bounds(bounds):
+    """``bounds`` as a (d, 2) array, or TypeError."""
     try:
-        b = np.atleast_2d(bounds)
-        if b.shape[1] != 2:
-            raise ValueError
-    except ValueError as excpt:
-        raise TypeError(f"bounds must be a (dim, 2) array of bounds, but is {bounds}") from excpt
-    return b
+        box = np.atleast_2d(bounds)
+        ok = box.ndim == 2 and box.shape[1] == 2
+    except ValueError:           # ragged input
+        ok = False
+    if not ok:
+        raise TypeError(f"bounds must be a (dim, 2) array of bounds, but is {bounds}")
+    return box
+
+
+def _same_dimension(box, pts, what, exc):
+    if box.shape[0] != pts.shape[1]:
+        raise exc(f"bounds and {what} appear to have different dimensionalities: "
+                  f"{box.shape[0]} for bounds and {pts.shape[1]} for {what}.")
 
 
 def is_in_bounds(points, bounds, check_shape=False):
     """``gpry/tools.py:263-290``: closed box test per row."""
-    points = np.atleast_2d(points)
+    pts = np.atleast_2d(points)
     if check_shape:
         bounds = check_and_return_bounds(bounds)
-        if bounds.shape[0] != points.shape[1]:
-            raise ValueError("bounds and point appear to have different dimensionalities: "
-                             f"{bounds.shape[0]} for bounds and {points.shape[1]} for point.")
-    return np.all((points >= bounds[:, 0]) & (points <= bounds[:, 1]), axis=1)
+        _same_dimension(bounds, pts, "point", ValueError)
+    inside = (pts >= bounds[:, 0]) & (pts <= bounds[:, 1])
+    return inside.all(axis=1)
 
 
 def shrink_bounds(bounds, samples, factor=1):
-    """Smallest box around ``samples`` scaled by ``factor``, clipped to ``bounds``
+    """Smallest box around ``samples``, widened about its centre by ``factor`` and clipped to ``bounds``
     (``gpry/tools.py:308-360``)."""
-    bounds = check_and_return_bounds(bounds)
-    samples = np.atleast_2d(samples)
-    if bounds.shape[0] != samples.shape[1]:
-        raise TypeError("bounds and samples appear to have different dimensionalities: "
-                        f"{bounds.shape[0]} for bounds and {samples.shape[1]} for samples.")
-    lo, hi = samples.min(axis=0), samples.max(axis=0)
-    delta = (factor - 1) / 2 * (hi - lo)
-    out = np.empty(bounds.shape, dtype=float)
-    out[:, 0] = np.maximum(lo - delta, bounds[:, 0])
-    out[:, 1] = np.minimum(hi + delta, bounds[:, 1])
-    return out
+    box, pts = check_and_return_bounds(bounds), np.atleast_2d(samples)
+    _same_dimension(box, pts, "samples", TypeError)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    margin = (factor - 1) / 2 * (hi - lo)
+    return np.column_stack((np.maximum(lo - margin, box[:, 0]), np.minimum(hi + margin, box[:, 1]))).astype(float)
 
 
 def remove_0_weight_samples(weights, *arrays):
-    """``gpry/tools.py:400-417``."""
-    drop = np.where(weights == 0)[0]
-    out = [np.delete(weights, drop)]
-    for a in arrays:
-        if a is None:
-            out.append(None)
-        elif a.shape[0] != len(weights):
-            raise ValueError("weights and some of the arrays have different lengths.")
-        else:
-            out.append(np.delete(a, drop, axis=0))
-    return out
+    """``weights`` and every array (``None`` passes through) without the rows of zero weight (``gpry/tools.py:400-417``)."""
+    if any(a is not None and a.shape[0] != len(weights) for a in arrays):
+        raise ValueError("weights and some of the arrays have different lengths.")
+    zero = np.flatnonzero(weights == 0)
+    return [np.delete(weights, zero)] + [None if a is None else np.delete(a, zero, axis=0) for a in arrays]

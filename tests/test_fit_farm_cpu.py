@@ -460,6 +460,15 @@ def test_proposers_draw_in_the_reference_order():
     c = CentroidsProposer(b)
     c.update(G())
     c.update_bounds(b)
+    # the centroids proposer against the reference's recipe written with scipy's frozen exponential
+    rng, ref = np.random.default_rng(7), np.random.default_rng(7)
+    sub = G.X_train[ref.choice(12, size=4, replace=False)]
+    cen = np.average(sub, axis=0)
+    partner = ref.choice(4, size=3, replace=False)
+    kick = np.array([sub[j][i] for i, j in enumerate(partner)]) - cen
+    kick *= scipy.stats.expon(scale=1.0).rvs(3, random_state=ref)
+    np.testing.assert_array_equal(c.get(rng), np.clip(cen + kick, b[:, 0], b[:, 1]))
+    assert rng.random() == ref.random()                      # and the generator was consumed alike
     p = PartialProposer(b, c)
     pts = np.array([p.get(np.random.default_rng(s)) for s in range(20)])
     assert np.all(pts >= b[:, 0]) and np.all(pts <= b[:, 1]) and len(np.unique(pts[:, 0])) > 10
