@@ -76,6 +76,7 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
             else GPRY_TRY(trtri_lower(ctx, A, V, T, ctx->Np));
         }
     }
+    ctx->info_cleared = false;
     if (!info_host) return 0;      // the caller fetches dinfo itself, together with its results
     int info[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(info, ctx->dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1318,6 +1319,7 @@ extern "C" int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, 
     g.B = dB; g.ldb = b_trans ? K : N;
     g.C = dC; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.kmode = kmode; g.lower_only = lower_only; g.tile_map = tile_map & 0xff;
+    g.small64 = (tile_map >> 28) & 1;             // test hook: bit 28 = eligible for the 64 x 64 tiles of gemm_small.hip
     const int nsplit = (tile_map >> 8) & 15;      // test hook: bits 8..11 of tile_map = split-K factor
     if (nsplit > 1) {
         GPRY_TRY(gemm_split_scratch(ctx, nsplit, (int64_t)crow * N, &g.split_buf));

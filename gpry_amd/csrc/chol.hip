@@ -92,7 +92,8 @@ __global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ A, 
 int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np) {
     const int64_t NB = 256;
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, sizeof(int), st));
+    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, sizeof(int), st));
+    ctx->info_cleared = false;
     for (int64_t K0 = 0; K0 < Np; K0 += NB) {
         int64_t nbw = (Np - K0 < NB) ? Np - K0 : NB;
         for (int64_t j0 = K0; j0 < K0 + nbw; j0 += 64) {
@@ -401,6 +402,7 @@ static int trtri_level_products(gpry_ctx* ctx, const double* L, double* V, doubl
         g.kmode = KM_B_LOWER; g.lower_only = 0; g.tile_map = TM_ROWMAJOR;
         g.batch = d_t; g.n_batch = n_t; g.info = ctx->dinfo; g.stream = st;
         g.nsplit = nsplit; g.split_buf = sbuf; g.split_stride = Np * Np; g.dma_ok = aligned;
+        g.small64 = 1;      // the tree is made of 64-row blocks
         GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_STORE));
     }
     if (n_v > 0) {
@@ -410,6 +412,7 @@ static int trtri_level_products(gpry_ctx* ctx, const double* L, double* V, doubl
         h.kmode = KM_A_LOWER; h.lower_only = 0; h.tile_map = TM_ROWMAJOR;
         h.batch = d_v; h.n_batch = n_v; h.info = ctx->dinfo; h.stream = st;
         h.nsplit = nsplit; h.split_buf = sbuf; h.split_stride = Np * Np; h.dma_ok = aligned;
+        h.small64 = 1;
         GPRY_TRY(gemm_f64_launch(ctx, h, false, false, EPI_STORE_NEG));
     }
     return 0;
@@ -419,17 +422,21 @@ static int trtri_level_products(gpry_ctx* ctx, const double* L, double* V, doubl
 // every level is two batched MFMA GEMMs.  T is an Np x Np scratch.
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np) {
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(V, 0, sizeof(double) * Np * Np, st));
     // 0 = auto: the four-wave kernel from Np = 256 on.  Up to Np = 128 the whole inverse IS this stage, and
     // the column-by-column substitution of the single-wave kernel is the operation order of the
     // reference's dtrsm: on the cond(K) = 5e15 matrix of BASELINE config 1 (N = 64) any other order moves
     // the posterior mean by 2..4e-5 of its range, beyond the one-ulp noise floor the golden test allows.
     const bool single_wave = ctx->opt_trtri_diag_v1 == 1 || (ctx->opt_trtri_diag_v1 == 0 && Np <= 128);
+    // V above its block diagonal has to be zero (the products walk whole tiles).  Up to Np = 1024 the workgroups of
+    // the diagonal stage clear the blocks to the right of their own (a memset is one more dependent dispatch, 5 us of
+    // an evaluation that takes 200 at N = 256); above, one memset of the matrix is cheaper than their 64-row strips.
+    const bool clear_in_diag = !single_wave && Np <= 1024;
+    if (!clear_in_diag) HIP_TRY(ctx, hipMemsetAsync(V, 0, sizeof(double) * Np * Np, st));
     if (single_wave) {
         hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)(Np / 64)), dim3(64), 0, st, L, V, Np, ctx->dinfo);
         HIP_TRY(ctx, hipGetLastError());
     } else {
-        GPRY_TRY(launch_trtri_diag(ctx, L, V, Np, st));
+        GPRY_TRY(launch_trtri_diag(ctx, L, V, Np, st, clear_in_diag));
     }
     TrtriPlan* pl = nullptr;
     GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
@@ -586,6 +593,7 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
         g.nsplit = nsplit; g.split_buf = sbuf; g.split_stride = Np * Np;
     }
     g.extra_lds = ctx->opt_lauum_lds;
+    g.small64 = 1;          // Np is a multiple of 128
     return gemm_f64_launch(ctx, g, true, false, EPI_STORE);
 }
 
@@ -613,9 +621,19 @@ __global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restr
     const int64_t r0 = (int64_t)blockIdx.y * 256;
     double s = 0.0;
     if (r0 + 255 >= (int64_t)blockIdx.x * 64) {
-        for (int q = 0; q < 64; q++) {
-            int64_t r = r0 + rq + 4 * q;
-            if (r >= col && r < n) s = fma(V[r * ld + col], z[r], s);
+        // eight loads in flight per step (one dependent load per multiply-add made this a 64-deep latency chain:
+        // 16 us whatever the size); terms above the diagonal enter as 0 * 0, which leaves the sum's bits alone
+        for (int q0 = 0; q0 < 64; q0 += 8) {
+            double v[8], zz[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int64_t r = r0 + rq + 4 * (q0 + u);
+                const bool in = r >= col && r < n;
+                v[u] = in ? V[r * ld + col] : 0.0;
+                zz[u] = in ? z[r] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) s = fma(v[u], zz[u], s);
         }
     }
     red[rq][c] = s;

@@ -216,7 +216,7 @@ __device__ __forceinline__ void tile_store_t(double* T, v4d v, int lane) {      
     for (int q = 0; q < 4; q++) T[r * PLD + g + 4 * q] = v[q];
 }
 __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restrict__ L, double* __restrict__ V,
-                                                           int64_t ld, const int* info) {
+                                                           int64_t ld, const int* info, int clear_right) {
     __shared__ __attribute__((aligned(16))) double sL[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sV[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sVt[64 * PLD];
@@ -224,6 +224,14 @@ __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restr
     if (*info != 0) return;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
+    if (clear_right) {      // rows of this block, columns right of it (ld = the matrix dimension): stands in for a memset of V
+        const int64_t ncol = ld - (b0 + 64);
+        const double2 zero2 = make_double2(0.0, 0.0);
+        for (int64_t e = t; e < 64 * (ncol >> 1); e += 256) {
+            const int64_t i = e / (ncol >> 1), j2 = e - i * (ncol >> 1);
+            *reinterpret_cast<double2*>(V + (b0 + i) * ld + b0 + 64 + 2 * j2) = zero2;
+        }
+    }
     for (int e = t; e < 64 * 64; e += 256) {
         const int i = e >> 6, j = e & 63;
         sL[i * PLD + j] = (j <= i) ? L[(b0 + i) * ld + b0 + j] : 0.0;
@@ -277,15 +285,15 @@ __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restr
         V[(b0 + i) * ld + b0 + j] = sV[i * PLD + j];
     }
 }
-int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st) {
-    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)(Np / 64)), dim3(256), 0, st, L, V, Np, ctx->dinfo);
+int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right) {
+    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)(Np / 64)), dim3(256), 0, st, L, V, Np, ctx->dinfo, clear_right ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 // diagonal blocks blk0 .. blk0 + nblk - 1 only (pipelined factor chain, chol.hip)
 int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st) {
     const int64_t off = (int64_t)blk0 * 64 * (Np + 1);
-    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)nblk), dim3(256), 0, st, L + off, V + off, Np, ctx->dinfo);
+    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)nblk), dim3(256), 0, st, L + off, V + off, Np, ctx->dinfo, 0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -708,7 +716,8 @@ static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int
 
 int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
+    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
+    ctx->info_cleared = false;
     int arrivals = 0;
     // Look-ahead: after panel k only the next panel's 128 columns of the trailing matrix are
     // updated on the main stream; the rest of the update runs on stream2 underneath panel k+1
@@ -1082,7 +1091,8 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
     if (prc == 1) return potrf_lower_fused(ctx, A, Np);
     if (prc) return prc;
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
+    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
+    ctx->info_cleared = false;
     int arrivals = 0;
     unsigned long long* dbg = nullptr;
     if (ctx->opt_chol_dbg) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); dbg = ctx->dsel + 16; }

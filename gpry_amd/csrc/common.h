@@ -35,6 +35,8 @@ struct gpry_ctx {
     int64_t opt_sweep_chunk = 32768;
     int opt_timing = 0;          // per-stage HIP-event timers: off until gpry_timing_reset (or "timing" = 1) asks for them
     int opt_sweep_colouter = 0;  // 1: super-tiles ordered candidate super-column outermost
+    bool info_cleared = false;   // dinfo[0..3] were zeroed by launch_scale_train and nothing has touched them since
+    int opt_gemm_small = 32;     // launches of at most this many 128 x 128 tiles run with 64 x 64 tiles (0: never)
     int opt_sweep_altwalk = 1;   // 1 (default): super-tiles of an XCD alternate the direction of their k walk (sweep_dma=3, grid launch)
     int opt_sweep_tilemap = 3;   // log2 of V row-tiles per 64-tile super-tile
     int opt_sweep_stagger = 0;
@@ -230,6 +232,7 @@ struct GemmArgs {
     double* split_buf; int64_t split_stride;
     int dma_ok;            // batched launches: 1 = every item meets gemm_dma_usable (checked by the caller)
     int skip_reduce;       // split-K: leave the slices in split_buf (the caller reduces them itself)
+    int small64;           // 1: every M, N is a multiple of 64 and every K of 32: launches with few tiles may take gemm_small.hip
 };
 // ---- stream-K launches of the DMA engine (gemm_dma.hip): the (tile, k) space of a launch is cut into segments of
 // equal length, one workgroup per segment; a segment is a list of parts (tile, share of the tile's k-range).
@@ -250,9 +253,11 @@ int gemm_dma_parts_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b
                           int64_t slice_stride);
 // a_trans: A(i,k) stored at A[k*lda + i]; b_trans: B(k,j) stored at B[j*ldb + k]
 int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
+// 64 x 64 tiles for launches with a handful of 128 x 128 tiles (gemm_small.hip); same bits
+int gemm64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
 int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
 // gemm_dma.hip: LDS-DMA staged, software-pipelined variant for 128-aligned products (NN, NT, TN)
-int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st);   // chol_panel.hip
+int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right = false);   // chol_panel.hip
 int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st);
 bool gemm_dma_usable(const GemmArgs& g, int M, int N, int K);
 int gemm_dma_launch_product(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi, dim3 grid);

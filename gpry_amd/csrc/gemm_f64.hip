@@ -335,6 +335,10 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
     } else {
         nblk = (int64_t)tiles_m * tiles_n;
     }
+    // a handful of tiles: four times as many workgroups with 64 x 64 tiles (gemm_small.hip)
+    if (g.small64 && ctx->opt_gemm_small > 0 && epi != EPI_SUMSQ && g.nsplit <= 1 && (g.tile_map & 15) == TM_ROWMAJOR &&
+        !(a_trans && b_trans) && !g.diag && nblk * (g.batch ? g.n_batch : 1) <= ctx->opt_gemm_small)
+        return gemm64_launch(ctx, g, a_trans, b_trans, epi);
     dim3 grid((unsigned)nblk, (unsigned)(g.nsplit > 1 ? g.nsplit : 1), g.batch ? (unsigned)g.n_batch : 1u);
     if (g.nsplit > 1 && !(epi == EPI_STORE || epi == EPI_STORE_NEG))
         return gpry_fail(ctx, -1, "gemm: split-K only with the store epilogues");

@@ -11,8 +11,11 @@
 
 // ------------------------------------------------------------------------------------
 __global__ void scale_train_kernel(const double* __restrict__ X, double* __restrict__ Xs,
-                                   int64_t N, int64_t Np, int d, int dpad, AffParams ap) {
+                                   int64_t N, int64_t Np, int d, int dpad, AffParams ap, int* info) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // first kernel of every factorisation: it also clears the status / arrival words the panel chain starts from
+    // (a memset in front of the first panel step is one more dependent dispatch)
+    if (idx < 4) info[idx] = 0;
     if (idx >= Np * dpad) return;
     int64_t i = idx / dpad; int k = (int)(idx - i * dpad);
     double v = 0.0;
@@ -24,8 +27,9 @@ int launch_scale_train(gpry_ctx* ctx) {
     AffParams ap = make_ap(ctx, false);
     int64_t n = ctx->Np * ctx->dpad;
     hipLaunchKernelGGL(scale_train_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       ctx->stream, ctx->dX, ctx->dXs, ctx->N, ctx->Np, ctx->d, ctx->dpad, ap);
+                       ctx->stream, ctx->dX, ctx->dXs, ctx->N, ctx->Np, ctx->d, ctx->dpad, ap, ctx->dinfo);
     HIP_TRY(ctx, hipGetLastError());
+    ctx->info_cleared = true;
     return 0;
 }
 

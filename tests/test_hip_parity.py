@@ -45,6 +45,47 @@ def test_mfma_gemm_layout_asymmetric(dev, at, bt):
     assert relmax(dev.debug_gemm(Ain, Bin, None, 192, 256, 320, at, bt), A @ B) < 1e-14
 
 
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 0)])
+def test_small_tile_gemm_gives_the_bits_of_the_128_tile_engines(dev, at, bt):
+    """Launches with a handful of tiles run with 64 x 64 tiles (gemm_small.hip: the V = L^-1 levels and K^-1 of a few
+    hundred training points): every layout, triangular k-range, epilogue and the tile-level lower_only rule against
+    numpy and, bit for bit, against the 128 x 128 engines."""
+    rng = np.random.default_rng(11)
+    SMALL = 1 << 28
+    M, N, K = 192, 320, 256
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((K, N)); C0 = rng.standard_normal((M, N))
+    Ain = np.ascontiguousarray(A.T) if at else A
+    Bin = np.ascontiguousarray(B.T) if bt else B
+    try:
+        dev.set_option("gemm_small", 1000)
+        for epi, ref in ((0, A @ B), (1, -(A @ B)), (2, C0 - A @ B)):
+            got = dev.debug_gemm(Ain, Bin, C0 if epi == 2 else None, M, N, K, at, bt, epi=epi, tile_map=SMALL)
+            big = dev.debug_gemm(Ain, Bin, C0 if epi == 2 else None, M, N, K, at, bt, epi=epi)
+            assert relmax(got, ref) < 1e-14
+            np.testing.assert_array_equal(got, big)
+        # triangular operands: square, the k-range of a tile is cut at the tile's own origin
+        n = 384
+        L = np.tril(rng.standard_normal((n, n))); G = rng.standard_normal((n, n))
+        cases = []
+        if not at and not bt:
+            cases = [(1, L, G, L @ G, 0), (2, G, L, G @ L, 0)]                # KM_A_LOWER, KM_B_LOWER
+        if at and not bt:
+            cases = [(3, L, L, np.tril(L.T @ L), 1)]                           # KM_AT_LOWER_B_LOWER, lower tiles only
+        for kmode, P, Q, ref, lower in cases:
+            got = dev.debug_gemm(P, Q, None, n, n, n, at, bt, kmode=kmode, lower_only=lower, tile_map=SMALL)
+            big = dev.debug_gemm(P, Q, None, n, n, n, at, bt, kmode=kmode, lower_only=lower)
+            if lower:
+                blk = np.kron(np.tril(np.ones((n // 64, n // 64))), np.ones((64, 64))) > 0     # tiles of the small engine
+                full = L.T @ L
+                assert relmax(got[blk], full[blk]) < 1e-13
+                got, big = np.tril(got), np.tril(big)
+            else:
+                assert relmax(got, ref) < 1e-13
+            np.testing.assert_array_equal(got, big)
+    finally:
+        dev.set_option("gemm_small", 32)
+
+
 def test_mfma_gemm_triangular_modes_and_sumsq(dev):
     rng = np.random.default_rng(2)
     n = 512

@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpry_amd import _lib
 for N, d in ((64, 2), (128, 4), (256, 4), (384, 4), (512, 4), (1024, 8)):
     rng = np.random.default_rng(0)
