@@ -320,106 +320,97 @@ class GaussianProcessRegressor(_RM, _BE):
     def alpha_(self):
         return self._fetch_factor("alpha_")
 
-    # ---- simple properties (gpry/gpr.py:391-540) ------------------------------------------
+    # ---- views of the training set (names and meaning as gpry/gpr.py:391-540) -------------------
+    # "finite" = kept by the classifier and therefore in the GP; "all" = everything ever appended
     @property
     def d(self):
         return self.X_train.shape[1] if self.bounds is None else self.bounds.shape[0]
 
+    def _finite_targets(self):
+        return getattr(self, "y_train", ())
+
+    n = property(lambda self: len(self._finite_targets()), doc="training points in the GP")
+    n_finite = n
+    fitted = property(lambda self: self._fitted)
+
     @property
     def y_max(self):
-        return np.max(getattr(self, "y_train", [self.minus_inf_value]))
-
-    @property
-    def n(self):
-        return len(getattr(self, "y_train", []))
-
-    @property
-    def n_finite(self):
-        return self.n
+        return np.max(getattr(self, "y_train", (self.minus_inf_value,)))
 
     @property
     def n_total(self):
-        if self.infinities_classifier:
-            return self.infinities_classifier.n or self.n
-        return self.n
+        clf = self.infinities_classifier
+        return (clf.n if clf else 0) or self.n
+
+    def _rejected(self, arr, empty_shape):
+        clf = self.infinities_classifier
+        return np.empty(shape=empty_shape) if clf is None else arr[~clf.y_finite]
+
+    X_train_infinite = property(lambda self: self._rejected(self.X_train_all, (0, self.d)))
+    y_train_infinite = property(lambda self: self._rejected(self.y_train_all, (0,)))
+
+    @staticmethod
+    def _tail(X, y, k):
+        return X[-k:].copy(), y[-k:].copy()
 
     @property
-    def X_train_infinite(self):
-        if self.infinities_classifier is None:
-            return np.empty(shape=(0, self.d))
-        return self.X_train_all[~self.infinities_classifier.y_finite]
-
-    @property
-    def y_train_infinite(self):
-        if self.infinities_classifier is None:
-            return np.empty(shape=(0,))
-        return self.y_train_all[~self.infinities_classifier.y_finite]
-
-    @property
-    def fitted(self):
-        return self._fitted
+    def last_appended_finite(self):
+        return self._tail(self.X_train, self.y_train, self.n_last_appended_finite)
 
     @property
     def last_appended(self):
         if self.infinities_classifier is None:
             return self.last_appended_finite
-        return (np.copy(self.X_train_all[-self.n_last_appended:]),
-                np.copy(self.y_train_all[-self.n_last_appended:]))
-
-    @property
-    def last_appended_finite(self):
-        return (np.copy(self.X_train[-self.n_last_appended_finite:]),
-                np.copy(self.y_train[-self.n_last_appended_finite:]))
+        return self._tail(self.X_train_all, self.y_train_all, self.n_last_appended)
 
     @property
     def scales(self):
-        return (self.preprocessing_y.inverse_transform_scale(np.sqrt(self.kernel_.k1.constant_value)),
-                tuple(self.preprocessing_X.inverse_transform_scale(
-                    np.atleast_1d(self.kernel_.k2.length_scale))))
+        """(output scale, length scales) in the units of the caller."""
+        amplitude, lengths = np.sqrt(self.kernel_.k1.constant_value), np.atleast_1d(self.kernel_.k2.length_scale)
+        return (self.preprocessing_y.inverse_transform_scale(amplitude),
+                tuple(self.preprocessing_X.inverse_transform_scale(lengths)))
 
     def training_set_as_df(self):
         import pandas as pd
-        data = dict(zip(generic_params_names(self.d), self.X_train_all.copy().T))
-        data["y"] = self.y_train_all.copy()
-        data["is_finite"] = self.is_finite(data["y"])
-        return pd.DataFrame(data)
+        y = self.y_train_all.copy()
+        columns = {name: col for name, col in zip(generic_params_names(self.d), self.X_train_all.copy().T)}
+        columns.update(y=y, is_finite=self.is_finite(y))
+        return pd.DataFrame(columns)
 
     @property
     def abs_finite_threshold(self):
-        thr = self.infinities_classifier.abs_threshold
-        return self.preprocessing_y.inverse_transform_scale(thr)
+        return self.preprocessing_y.inverse_transform_scale(self.infinities_classifier.abs_threshold)
 
     def is_finite(self, y):
-        if self.infinities_classifier is None:
-            return np.full(shape=len(y), fill_value=True)
-        return self.infinities_classifier.is_finite(self.preprocessing_y.transform(y))
+        """Threshold test on targets (no prediction involved)."""
+        clf = self.infinities_classifier
+        return np.ones(len(y), dtype=bool) if clf is None else clf.is_finite(self.preprocessing_y.transform(y))
 
     def predict_is_finite(self, X, validate=True):
-        if self.infinities_classifier is None:
-            return np.full(shape=(len(self.y_train_all),), fill_value=True)
-        return self.infinities_classifier.predict(
-            np.ascontiguousarray(self.preprocessing_X.transform(X)), validate=validate)
+        clf = self.infinities_classifier
+        if clf is None:
+            return np.ones(len(self.y_train_all), dtype=bool)      # (the reference's length, gpry/gpr.py:537)
+        return clf.predict(np.ascontiguousarray(self.preprocessing_X.transform(X)), validate=validate)
 
     def set_random_state(self, random_state):
         self.random_state = random_state
         if self.infinities_classifier:
-            self.infinities_classifier.random_state = check_random_state(
-                random_state, convert_to_random_state=True)
+            self.infinities_classifier.random_state = check_random_state(random_state, convert_to_random_state=True)
 
     def update_trust_region(self):
-        """gpry/gpr.py:554-575."""
+        """Box around the training points within ``trust_region_nstd`` sigma of the best one (all of them without it),
+        widened by ``trust_region_factor`` (gpry/gpr.py:554-575); the level is raised in steps of 0.1 sigma until it
+        holds min(d, n) points."""
         if self.trust_region_factor is None:
             return
-        if self.trust_region_nstd is None:
-            use_X = self.X_train
-        else:
-            nstd = self.trust_region_nstd
-            use_X = np.empty(shape=(0, self.X_train.shape[1]))
-            while len(use_X) < min(self.d, self.n):
-                use_X = self.X_train[np.where(max(self.y_train) - self.y_train <
-                                              delta_logp_of_1d_nstd(nstd, self.d))]
+        inside = self.X_train
+        if self.trust_region_nstd is not None:
+            nstd, below_top = self.trust_region_nstd, max(self.y_train) - self.y_train
+            inside = inside[:0]
+            while len(inside) < min(self.d, self.n):
+                inside = self.X_train[np.where(below_top < delta_logp_of_1d_nstd(nstd, self.d))]
                 nstd = nstd + 0.1
-        self.trust_bounds = shrink_bounds(self.bounds, use_X, factor=self.trust_region_factor)
+        self.trust_bounds = shrink_bounds(self.bounds, inside, factor=self.trust_region_factor)
 
     # ---- data ---------------------------------------------------------------------------
     def append_to_data(self, X, y, noise_level=None, fit_gpr=True, fit_classifier=True):
@@ -528,41 +519,43 @@ class GaussianProcessRegressor(_RM, _BE):
         return self.append_to_data(X, y, fit_gpr=True)
 
     def _validate_noise_level(self, noise_level, n_train):
-        """gpry/gpr.py:755-785."""
-        if n_train == 0 and noise_level is not None:
-            raise ValueError("noise_level must be None if not fitting to new points.")
-        if np.iterable(noise_level):
-            noise_level = np.atleast_1d(noise_level)
-            if noise_level.shape[0] != n_train:
-                raise ValueError("noise_level must be an array with same number of entries as y, "
-                                 f"but len(n)={noise_level.shape[0]} != len(y)={n_train})")
-        elif isinstance(noise_level, Number):
-            if np.iterable(self.noise_level):
-                noise_level = np.full(fill_value=noise_level, shape=(n_train,))
-        elif noise_level is None:
-            if np.iterable(self.noise_level):
+        """Noise of a batch of ``n_train`` new points as it will be stored: an array once any array was given
+        (now or earlier), a scalar or None otherwise (gpry/gpr.py:755-785)."""
+        per_point_so_far = np.iterable(self.noise_level)
+        if noise_level is None:
+            if per_point_so_far:
                 raise ValueError("Need to pass non-null noise_level (scalar or array) because "
                                  "concrete values were given earlier for the training points.")
-        else:
+            return None
+        if n_train == 0:
+            raise ValueError("noise_level must be None if not fitting to new points.")
+        if np.iterable(noise_level):
+            levels = np.atleast_1d(noise_level)
+            if len(levels) != n_train:
+                raise ValueError("noise_level must be an array with same number of entries as y, "
+                                 f"but len(n)={len(levels)} != len(y)={n_train})")
+            return levels
+        if not isinstance(noise_level, Number):
             raise ValueError("noise_level needs to be an iterable, number or None. "
                              f"Got type(noise_level)={type(noise_level)}")
-        return noise_level
+        return np.full(n_train, noise_level) if per_point_so_far else noise_level
 
     def _update_noise_level(self, noise_level):
-        """gpry/gpr.py:787-817."""
+        """Merge the (validated) noise of the points just appended into ``self.noise_level`` (gpry/gpr.py:787-817)."""
+        chatty = self.verbose > 1
         if np.iterable(noise_level):
-            if not np.iterable(self.noise_level):
-                if self.verbose > 1:
+            known = self.noise_level
+            if not np.iterable(known):          # a scalar so far: spell it out for the points already in
+                if chatty:
                     warnings.warn("A new noise level has been assigned to the updated training set "
                                   "while the old training set has a single scalar noise level: "
-                                  f"{self.noise_level}. Converting to individual levels!")
-                n_old = len(self.y_train_all) - len(noise_level)
-                self.noise_level = np.full(fill_value=self.noise_level, shape=(n_old,))
-            self.noise_level = np.append(self.noise_level, noise_level, axis=0)
+                                  f"{known}. Converting to individual levels!")
+                known = np.full(len(self.y_train_all) - len(noise_level), known)
+            self.noise_level = np.concatenate((known, noise_level))
         elif isinstance(noise_level, Number):
             assert not np.iterable(self.noise_level)
             if not np.isclose(noise_level, self.noise_level):
-                if self.verbose > 1:
+                if chatty:
                     warnings.warn("Overwriting the noise level with a scalar. Make sure that "
                                   "kernel's hyperparamters are refitted.")
                 self.noise_level = noise_level
