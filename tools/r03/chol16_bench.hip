@@ -9,6 +9,56 @@
 #include "chol16.h"
 
 #define LD 66
+
+// ---- experiment (measured, not adopted): the producer publishes every column as it is finished -- the column, then its
+// reciprocal pivot into rd[j] (preset to a sentinel) -- so that the wave that factors the next diagonal block can run its
+// row substitution one column behind instead of after all sixteen (trsm16_rows_follow in the kernel, removed again).
+// The two unconditional LDS writes per column cost the producer 520 cycles per block (3996 vs 3474; 4142 with a third
+// write for a counter, 4603 when the writes sit under `if (lane < 16)`), the follower pays an LDS round trip per column
+// unless it is a column behind, and every wave further down that follows too takes issue slots from the producer it
+// shares a SIMD with: chol of N = 128 in lml_small 53.5k -> 51.4-52.3k cycles at best (57k with all waves following),
+// i.e. under 1 us of a 60-us evaluation.
+namespace c16 {
+#define C16_UNPUBLISHED (-1.0)      // no reciprocal pivot is negative (a failed pivot gives NaN or +inf)
+typedef __attribute__((address_space(3))) void* c16_lptr;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(c16_lptr)p; }
+__device__ __forceinline__ void publish_column(double* col_i, double lij, double* rd_j, double rinv) {
+    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %2, %3" :: "v"(lds_addr(col_i)), "v"(lij), "v"(lds_addr(rd_j)), "v"(rinv) : "memory");
+}
+
+// chol16_wave that publishes its columns (rd[0..15] == C16_UNPUBLISHED before the call)
+__device__ __forceinline__ int chol16_wave_pub(double* S, double* rd, int lane) {
+    const int i = lane & 15;
+    double x[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = S[i * LD + c];
+    int bad = 0;
+    double my_d = 1.0, my_r = 1.0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const double djj = readlane_f64(x[j], j);
+        if (!(djj > 0.0) && bad == 0) bad = j + 1;
+        const double rinv = pivot_rsqrt(djj);
+        if (i == j) { my_d = djj; my_r = rinv; }
+        double lij = x[j] * rinv;
+        publish_column(S + i * LD + j, lij, rd + j, rinv);
+        asm volatile("s_nop 1" : "+v"(lij));
+#pragma unroll
+        for (int c = j + 1; c < 16; c++) fmsub_row_bcast(x[c], lij, lij, c);
+        x[j] = lij;
+    }
+    double piv = my_d * my_r;
+    piv = fma(fma(-piv, piv, my_d), 0.5 * my_r, piv);
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) S[i * LD + c] = x[c];      // (the published entries again, and the ones above the diagonal)
+        S[i * LD + i] = piv;
+        rd[i] = my_r;
+    }
+    return bad;
+}
+
+}  // namespace c16
 #define SB __builtin_amdgcn_sched_barrier(0)
 
 // candidate: the next pivot's entry is updated first, its reciprocal root is under way while the rest of the column's
@@ -77,6 +127,7 @@ __device__ __forceinline__ int chol16_sched(double* S, double* rd, int lane) {
 template <int VAR>
 __global__ __launch_bounds__(64) void bench(const double* A, double* out, unsigned long long* cyc, int reps) {
     __shared__ double P[16 * LD], S[16 * LD], rd[16];
+    __shared__ int cnt;
     const int lane = threadIdx.x;
     for (int e = lane; e < 256; e += 64) P[(e >> 4) * LD + (e & 15)] = A[e];
     __syncthreads();
@@ -92,7 +143,7 @@ __global__ __launch_bounds__(64) void bench(const double* A, double* out, unsign
         else if (VAR == 2) bad |= chol16_sched<1, 3, 1>(S, rd, lane);
         else if (VAR == 3) bad |= chol16_sched<2, 2, 2>(S, rd, lane);
         else if (VAR == 4) bad |= chol16_sched<0, 3, 0>(S, rd, lane);
-        else if (VAR == 5) bad |= chol16_sched<3, 4, 0>(S, rd, lane);
+        else if (VAR == 5) { if (lane < 16) rd[lane] = C16_UNPUBLISHED; bad |= c16::chol16_wave_pub(S, rd, lane); }
         c16::wave_fence();
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
