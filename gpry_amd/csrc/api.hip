@@ -7,6 +7,12 @@ static int require_model(gpry_ctx* ctx, bool need_factor) {
     if (ctx->N <= 0) return gpry_fail(ctx, -1, "no training set (call gpry_set_train)");
     if (!ctx->have_theta) return gpry_fail(ctx, -1, "no hyperparameters (call gpry_set_theta)");
     if (need_factor && !ctx->factor_valid) return gpry_fail(ctx, -1, "model not factorised (call gpry_factorize)");
+    // an X map that was set for a model of fewer dimensions has zero spans in the new ones: every prediction would be NaN
+    if (need_factor && ctx->tf.has_x_affine)
+        for (int k = 0; k < ctx->d; k++)
+            if (!(ctx->tf.x_span[k] != 0.0) || !isfinite(ctx->tf.x_span[k]) || !isfinite(ctx->tf.x_lo[k]))
+                return gpry_fail(ctx, -1, "affine map of X: span %g, offset %g in dimension %d of %d (gpry_set_affine of another model?)",
+                                 ctx->tf.x_span[k], ctx->tf.x_lo[k], k, ctx->d);
     return 0;
 }
 

@@ -180,6 +180,7 @@ struct TrtriPhase {
 };
 struct TrtriPlan {
     int64_t Np = 0;
+    int leaf = 1;                           // leaves of the recursion in 64-row blocks (2: 128 x 128 diagonal stage)
     std::vector<GemmBatchItem*> d_t, d_v;   // per level
     std::vector<int> count, maxM, maxN;
     std::vector<int> aligned;               // per level: every item is a multiple of 128 in M, N and K
@@ -218,8 +219,12 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
     pl = TrtriPlan();       // Np = 0: an incomplete plan is never taken for a finished one
     int slots = 512;        // two GEMM workgroups per CU
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) slots = 2 * prop.multiProcessorCount; }
+    // up to Np = 1024 the leaves are 128 x 128 blocks, inverted in LDS by one workgroup each (trtri_small.hip): the tree
+    // is built over 128-row blocks and its coordinates scaled back to the 64-row units everything below works in
+    pl.leaf = (ctx->opt_trtri_diag128 && Np > 128 && Np <= 1024) ? 2 : 1;
     std::vector<TriNode> nodes;
-    int nlev = build_tree(0, (int)(Np / 64), nodes);
+    int nlev = build_tree(0, (int)(Np / (64 * pl.leaf)), nodes);
+    for (auto& nd : nodes) { nd.lo *= pl.leaf; nd.mid *= pl.leaf; nd.hi *= pl.leaf; }
     for (int lev = 1; lev <= nlev; lev++) {
         std::vector<GemmBatchItem> bt, bv;
         int mM = 0, mN = 0, al = 1;
@@ -430,16 +435,18 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
     // V above its block diagonal has to be zero (the products walk whole tiles).  Up to Np = 1024 the workgroups of
     // the diagonal stage clear the blocks to the right of their own (a memset is one more dependent dispatch, 5 us of
     // an evaluation that takes 200 at N = 256); above, one memset of the matrix is cheaper than their 64-row strips.
-    const bool clear_in_diag = !single_wave && Np <= 1024;
+    const bool clear_in_diag = !single_wave && Np <= 1024 && ctx->opt_trtri_clear;
     if (!clear_in_diag) HIP_TRY(ctx, hipMemsetAsync(V, 0, sizeof(double) * Np * Np, st));
+    TrtriPlan* pl = nullptr;
+    GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
     if (single_wave) {
         hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)(Np / 64)), dim3(64), 0, st, L, V, Np, ctx->dinfo);
         HIP_TRY(ctx, hipGetLastError());
+    } else if (pl->leaf == 2 && clear_in_diag) {
+        GPRY_TRY(launch_trtri_diag128(ctx, L, V, Np, st, true));
     } else {
         GPRY_TRY(launch_trtri_diag(ctx, L, V, Np, st, clear_in_diag));
     }
-    TrtriPlan* pl = nullptr;
-    GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
     for (size_t lev = 0; lev < pl->count.size(); lev++)
         GPRY_TRY(trtri_level_products(ctx, L, V, T, Np, trtri_level_nsplit(ctx, pl, lev), pl->aligned[lev],
                                       pl->d_t[lev], pl->count[lev], pl->maxM[lev], pl->maxN[lev],
@@ -493,7 +500,7 @@ int trtri_pipeline_begin(gpry_ctx* ctx, const double* L, double* V, double* T, i
     if (!ctx->stream2) return 1;
     TrtriPlan* pl = nullptr;
     GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
-    if (pl->phases.size() < 2) return 1;
+    if (pl->phases.size() < 2 || pl->leaf != 1) return 1;      // (the phases are cut in 64-row diagonal blocks)
     while (ctx->ev_pool.size() < pl->phases.size() + 2) {
         hipEvent_t ev;
         HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));

@@ -255,6 +255,8 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "split_k")) { ctx->opt_split_k = (int)value; return 0; }
     if (!strcmp(key, "predict_split")) { ctx->opt_predict_split = (int)value; return 0; }
     if (!strcmp(key, "gemm_dma")) { ctx->opt_gemm_dma = (int)value; return 0; }
+    if (!strcmp(key, "trtri_clear")) { ctx->opt_trtri_clear = value != 0; ctx->lml_cache = false; return 0; }
+    if (!strcmp(key, "trtri_diag128")) { ctx->opt_trtri_diag128 = value != 0; trtri_plan_free(ctx); ctx->lml_cache = false; return 0; }
     if (!strcmp(key, "gemm_small")) { ctx->opt_gemm_small = (int)value; ctx->lml_cache = false; return 0; }
     if (!strcmp(key, "sweep_altwalk")) { ctx->opt_sweep_altwalk = (int)value & 3; return 0; }   // bit 1: experiment, full-K row tiles
     if (!strcmp(key, "sweep_colouter")) { ctx->opt_sweep_colouter = (int)value; return 0; }

@@ -92,7 +92,7 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                                launch per call; default 1), "serve_idle_us" = how long that kernel waits for the
  *                                next request before it leaves (default 2000)
  * Everything else is an A/B switch of the measurements quoted in DESIGN.md (defaults are the
- * measured best): "sweep_dma" 0..3, "sweep_persist", "sweep_overlap", "sweep_tilemap", "sweep_altwalk", "sweep_colouter", "gemm_small", "chol_outer",
+ * measured best): "sweep_dma" 0..3, "sweep_persist", "sweep_overlap", "sweep_tilemap", "sweep_altwalk", "sweep_colouter", "gemm_small", "trtri_diag128", "trtri_clear", "chol_outer",
  * "chol_lookahead", "chol_overlap_max", "chol_caps", "split_k", "gemm_dma", "syrk_lds", "lauum_lds", "lauum_split",
  * "trtri_split_cap", "kb_tile", "predict_small", "lml_cache", "factor_pipeline_spine".  Unknown keys return -1.
  * The environment variable GPRY_HIP_OPTIONS="key=value,key=value" applies options to every context the process

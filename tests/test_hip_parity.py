@@ -462,6 +462,29 @@ def test_cholesky_with_concurrent_trailing_update_is_bit_identical(dev):
         dev.set_option("chol_outer", 0)
 
 
+def test_an_x_map_of_another_dimension_is_refused():
+    """A gpry_set_affine made for a model of fewer dimensions has zero spans in the new ones: the prediction entry points
+    say so instead of returning NaN."""
+    from gpry_amd import _lib
+    d2 = _lib.Device(0)
+    try:
+        rng = np.random.default_rng(0)
+        d2.set_train(rng.uniform(size=(20, 2)), rng.standard_normal(20), np.full(20, 1e-6))
+        d2.set_theta(0, np.zeros(3))
+        d2.set_affine(np.zeros(2), np.ones(2), 0.0, 1.0, np.inf)
+        assert d2.factorize() == 0
+        assert np.all(np.isfinite(d2.predict(rng.uniform(size=(5, 2)), return_std=True)[1]))
+        d2.set_train(rng.uniform(size=(20, 3)), rng.standard_normal(20), np.full(20, 1e-6))
+        d2.set_theta(0, np.zeros(4))
+        assert d2.factorize() == 0
+        with pytest.raises(RuntimeError, match="affine map of X"):
+            d2.predict(rng.uniform(size=(5, 3)), return_std=True)
+        d2.set_affine(np.zeros(3), np.ones(3), 0.0, 1.0, np.inf)
+        assert np.all(np.isfinite(d2.predict(rng.uniform(size=(5, 3)), return_std=True)[1]))
+    finally:
+        d2.close()
+
+
 def test_factorize_adopts_the_factor_of_the_last_lml_evaluation(dev):
     """gpry_factorize at the theta of the preceding gpry_lml call swaps that evaluation's factor
     in instead of factorising again: same bits as a fresh factorisation, and no stale reuse once
@@ -473,6 +496,7 @@ def test_factorize_adopts_the_factor_of_the_last_lml_evaluation(dev):
     th1 = np.log(np.array([3.0, 0.3, 0.4, 0.5, 0.35, 0.45]))
     th2 = th1 + 0.1
     dev.set_train(X_, y, alpha)
+    dev.set_affine(np.zeros(5), np.ones(5), 0.0, 1.0, np.inf)     # (not the map a test of another dimension left behind)
     dev.set_option("lml_cache", 0)
     dev.set_theta(3, th1)
     assert dev.factorize() == 0
@@ -586,6 +610,7 @@ def test_capacity_does_not_grow_when_only_the_dimension_changes(dev):
         X = rng.uniform(0, 1, (200, d))
         dev.set_train(X, rng.standard_normal(200), np.full(200, 1e-3))
         dev.set_theta(3, np.log(np.array([2.0] + [0.5] * d)))
+    dev.set_affine(None, None, 0.0, 1.0, np.inf)          # (the fixture carries the map of the test before)
     assert dev.factorize() == 0
     m = dev.predict(rng.uniform(0, 1, (5, d)))
     assert np.all(np.isfinite(m))
