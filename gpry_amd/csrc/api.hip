@@ -230,7 +230,8 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
         if (r < 0) rc = r;
         fused = r == 0;
     }
-    if (rc == 0 && !fused) rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, nullptr);
+    const bool rescaled = rc == 0 && !fused;        // build_factor scales the training coordinates for THIS theta
+    if (rescaled) rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, nullptr);
     double* dz = ctx->dvec;                 // z = V y
     double* da = ctx->dvec + ctx->Np;       // alpha
     if (rc == 0 && !fused) {
@@ -249,9 +250,9 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     }
     memcpy(ctx->theta, saved, sizeof(saved));
     ctx->have_theta = had;
-    // the scaled training coordinates belong to the prediction factor: restore them (same stream, behind
-    // the traces kernel that reads the ones of this evaluation)
-    if (rc == 0 && had && ctx->factor_valid && !fused) rc = launch_scale_train(ctx);
+    // the scaled training coordinates belong to the prediction factor: whoever needs them next restores them
+    // (ensure_pred_xs; an optimiser's next evaluation does not)
+    if (rescaled && had && ctx->factor_valid) ctx->xs_foreign = true;
     double host[2 + 1 + GPRY_MAX_DIM];
     int hinfo[2] = {0, 0};
     if (rc == 0 && fused) {

@@ -35,6 +35,7 @@ struct gpry_ctx {
     int64_t opt_sweep_chunk = 32768;
     int opt_timing = 0;          // per-stage HIP-event timers: off until gpry_timing_reset (or "timing" = 1) asks for them
     int opt_sweep_colouter = 0;  // 1: super-tiles ordered candidate super-column outermost
+    bool xs_foreign = false;     // dXs holds coordinates scaled for an LML evaluation's theta, not the prediction factor's (ensure_pred_xs)
     bool info_cleared = false;   // dinfo[0..3] were zeroed by launch_scale_train and nothing has touched them since
     int opt_trtri_clear = 1;     // 1: up to Np = 1024 the diagonal stage of V = L^-1 clears V above the block diagonal itself (0: memset)
     int opt_trtri_diag128 = 1;   // 1 (default): up to Np = 1024 the diagonal stage of V = L^-1 works on 128 x 128 blocks
@@ -260,6 +261,8 @@ int gemm64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, 
 int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
 // gemm_dma.hip: LDS-DMA staged, software-pipelined variant for 128-aligned products (NN, NT, TN)
 int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right = false);   // chol_panel.hip
+// re-scales the training coordinates for the prediction factor if the last LML evaluation left its own in dXs
+int ensure_pred_xs(gpry_ctx* ctx);   // kernel_build.hip
 int launch_trtri_diag128(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right);   // trtri_small.hip
 int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st);
 bool gemm_dma_usable(const GemmArgs& g, int M, int N, int K);

@@ -30,6 +30,18 @@ int launch_scale_train(gpry_ctx* ctx) {
                        ctx->stream, ctx->dX, ctx->dXs, ctx->N, ctx->Np, ctx->d, ctx->dpad, ap, ctx->dinfo);
     HIP_TRY(ctx, hipGetLastError());
     ctx->info_cleared = true;
+    ctx->xs_foreign = false;
+    return 0;
+}
+
+// An LML evaluation scales the training coordinates for ITS theta and used to put the prediction factor's back with one
+// more launch at its end -- a dependent dispatch per evaluation of every fit, undone by the next evaluation.  It now only
+// marks dXs; whoever reads it on behalf of the prediction factor (the launchers below, the resident predict kernel)
+// restores it first.
+int ensure_pred_xs(gpry_ctx* ctx) {
+    if (!ctx->xs_foreign) return 0;
+    GPRY_TRY(launch_scale_train(ctx));
+    ctx->info_cleared = false;      // (this was not the start of a factorisation)
     return 0;
 }
 
@@ -294,6 +306,7 @@ __global__ __launch_bounds__(256) void kernel_rows_kernel(const double* __restri
     Bk[idx] = v;
 }
 int launch_kernel_rows(gpry_ctx* ctx, int64_t row0, int k, int64_t ldk, double* Bk, double* Cb) {
+    GPRY_TRY(ensure_pred_xs(ctx));
     KernParams kp = make_kp(ctx);
     const int64_t n = ctx->Np * ldk;
 #define KR(KID) hipLaunchKernelGGL((kernel_rows_kernel<KID>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, \
@@ -445,6 +458,7 @@ __global__ __launch_bounds__(256) void cross_build_small_kernel(
 // mean_part then holds 4 * (Np / 128) partials per candidate (row stride mc)
 int launch_cross_build_small(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk,
                              double* Kst, double* mean_part, int raw_affine) {
+    GPRY_TRY(ensure_pred_xs(ctx));
     hipStream_t st = ctx->stream;
     KernParams kp = make_kp(ctx);
     kp.has_aff = raw_affine && ctx->tf.has_x_affine;
@@ -465,6 +479,7 @@ int launch_cross_build_small(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_
 
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk,
                        double* Kst, double* mean_part, int raw_affine, hipStream_t st) {
+    GPRY_TRY(ensure_pred_xs(ctx));
     if (!st) st = ctx->stream;
     KernParams kp = make_kp(ctx);
     kp.has_aff = raw_affine && ctx->tf.has_x_affine;
@@ -749,6 +764,7 @@ __global__ __launch_bounds__(256) void gradx_contract_kernel(const double* __res
 // scratch u, w (Np each), part ((Np/128) x Np).
 int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, double* kstar, double* G,
                  double* u, double* w, double* part, double* out) {
+    GPRY_TRY(ensure_pred_xs(ctx));
     KernParams kp = make_kp(ctx);
     kp.has_aff = raw_affine && ctx->tf.has_x_affine;
     AffParams ap = make_ap(ctx, kp.has_aff);
@@ -838,6 +854,7 @@ __global__ __launch_bounds__(256) void gradx_batch_kernel(const double* __restri
 }
 int launch_gradx_batch(gpry_ctx* ctx, const double* Xb, int64_t m, int raw_affine, const double* Wm, int64_t ldw,
                        double* out) {
+    GPRY_TRY(ensure_pred_xs(ctx));
     KernParams kp = make_kp(ctx);
     kp.has_aff = raw_affine && ctx->tf.has_x_affine;
     AffParams ap = make_ap(ctx, kp.has_aff);
@@ -870,6 +887,7 @@ __global__ __launch_bounds__(256) void predict_mean_small_kernel(
 // part_out: M x nsplit partial sums of K* alpha_ (transformed units); the caller adds them and
 // applies y_std, y_mean, the clip and the mask.
 int launch_predict_mean_small(gpry_ctx* ctx, const double* Xc, int64_t M, int nsplit, double* part_out) {
+    GPRY_TRY(ensure_pred_xs(ctx));
     KernParams kp = make_kp(ctx);
     kp.has_aff = ctx->tf.has_x_affine;
     AffParams ap = make_ap(ctx, kp.has_aff);
@@ -981,6 +999,7 @@ __global__ __launch_bounds__(256) void trmv_multi_kernel(const double* __restric
 // kstar: M x Np device scratch; mean_part: M x (Np/256), ss_part: M x (Np/16) (pinned host is fine)
 int launch_predict_small_std(gpry_ctx* ctx, const double* Xc, int M, double* kstar, double* mean_part,
                              double* ss_part) {
+    GPRY_TRY(ensure_pred_xs(ctx));
     KernParams kp = make_kp(ctx);
     kp.has_aff = ctx->tf.has_x_affine;
     AffParams ap = make_ap(ctx, kp.has_aff);

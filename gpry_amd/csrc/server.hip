@@ -312,6 +312,7 @@ static int srv_launch(gpry_ctx* ctx, SrvHost* s) {
     a.res = reinterpret_cast<SrvUnit*>(s->d + SrvHost::RES);
     a.state = reinterpret_cast<SrvUnit*>(s->d + SrvHost::STATE);
     a.dseq = s->dflags; a.dhdr = s->dflags + 1; a.dexit = s->dflags + 2; a.dx = s->dx;
+    GPRY_TRY(ensure_pred_xs(ctx));
     a.Xs = ctx->dXs; a.alpha_ = ctx->dalpha_;
     a.gen = ++s->gen;
     a.seq0 = s->seq - 1;

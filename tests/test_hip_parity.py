@@ -462,6 +462,60 @@ def test_cholesky_with_concurrent_trailing_update_is_bit_identical(dev):
         dev.set_option("chol_outer", 0)
 
 
+def test_predictions_after_an_objective_evaluation_at_another_theta():
+    """gpry_lml scales the training coordinates for ITS theta and no longer puts the prediction factor's back itself
+    (one dispatch per evaluation of every fit): every reader on behalf of the prediction factor restores them first --
+    the panel build of predict / sweep, the one-launch and the resident mean paths, x-gradients, bordered appends."""
+    from gpry_amd import _lib
+    rng = np.random.default_rng(12)
+    N, d = 300, 4
+    X = rng.uniform(size=(N, d)); y = np.sin(3 * X).sum(1)
+    th1 = np.log(np.array([2.0, 0.3, 0.4, 0.5, 0.35])); th2 = th1 + 0.3
+    Xc = rng.uniform(size=(50, d))
+    dv = _lib.Device(0)
+    try:
+        dv.set_train(X, y, np.full(N, 1e-6)); dv.set_theta(3, th1)
+        assert dv.factorize() == 0
+        ref_ms = dv.predict(Xc, return_std=True)
+        ref_m = dv.predict(Xc)
+        ref_1 = [dv.predict(Xc[i:i + 1])[0] for i in range(5)]            # resident kernel
+        dv.set_option("predict_serve", 0)
+        ref_1l = [dv.predict(Xc[i:i + 1])[0] for i in range(5)]           # one launch per call
+        dv.set_option("predict_serve", 1)
+        ref_g = dv.predict_grad(Xc[0]) + dv.predict_grad_batch(Xc[:7])
+        for reader in ("std", "mean", "serve", "launch", "grad", "append"):
+            dv.lml(th2, True)                                             # leaves its own scaled coordinates behind
+            if reader == "std":
+                got = dv.predict(Xc, return_std=True)
+                assert np.array_equal(got[0], ref_ms[0]) and np.array_equal(got[1], ref_ms[1])
+            elif reader == "mean":
+                assert np.array_equal(dv.predict(Xc), ref_m)
+            elif reader == "serve":
+                assert [dv.predict(Xc[i:i + 1])[0] for i in range(5)] == ref_1
+            elif reader == "launch":
+                dv.set_option("predict_serve", 0)
+                assert [dv.predict(Xc[i:i + 1])[0] for i in range(5)] == ref_1l
+                dv.set_option("predict_serve", 1)
+            elif reader == "grad":
+                got = dv.predict_grad(Xc[0])
+                dv.lml(th2, True)
+                got = got + dv.predict_grad_batch(Xc[:7])
+                for a, b in zip(got, ref_g):
+                    assert np.array_equal(np.asarray(a), np.asarray(b))
+            elif reader == "append":
+                xn = rng.uniform(size=(3, d)); yn = np.sin(3 * xn).sum(1)
+                assert dv.append_rows(xn, yn, 1e-6) == 0
+                fresh = _lib.Device(0)
+                try:
+                    fresh.set_train(np.vstack([X, xn]), np.concatenate([y, yn]), np.full(N + 3, 1e-6)); fresh.set_theta(3, th1)
+                    assert fresh.factorize() == 0
+                    np.testing.assert_allclose(dv.predict(Xc), fresh.predict(Xc), rtol=1e-9, atol=1e-10)
+                finally:
+                    fresh.close()
+    finally:
+        dv.close()
+
+
 def test_an_x_map_of_another_dimension_is_refused():
     """A gpry_set_affine made for a model of fewer dimensions has zero spans in the new ones: the prediction entry points
     say so instead of returning NaN."""
