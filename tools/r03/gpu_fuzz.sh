@@ -7,7 +7,7 @@ sys.path.insert(0, "tests/tools"); sys.path.insert(0, "tests"); sys.path.insert(
 import fuzz_parity, fuzz_mirror, fuzz_gates
 t0 = time.time()
 tot = 0
-for seed in range(100, 112):
+for seed in range(int(__import__("os").environ.get("FUZZ_SEED0", "100")), int(__import__("os").environ.get("FUZZ_SEED0", "100")) + 12):
     bad, worst = fuzz_parity.run(n_cases=50, seed=seed)
     tot += bad
     print("fuzz_parity seed", seed, "violations", bad, {k: float("%.2e" % v) for k, v in worst.items()}, flush=True)
