@@ -543,6 +543,48 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
         HIP_TRY(ctx, hipEventSynchronize(e1));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
         *value = (double)ms * 1e3 / reps;
+    } else if (kind == 8) {   // covariance build + potrf (serial chain) of the resident model, us per repetition; bytes & 1: replayed
+                              // as a captured hipGraph instead of launched kernel by kernel; bytes >> 1: repetitions (default 20)
+        if (ctx->N <= 0 || !ctx->have_theta) return gpry_fail(ctx, -1, "microbench 8 needs set_train + set_theta");
+        const bool graph = bytes & 1;
+        const int reps = (bytes >> 1) >= 1 ? (int)(bytes >> 1) : 20;
+        ctx->lml_cache = false;
+        ctx->factor_valid = false;
+        GPRY_TRY(launch_scale_train(ctx));
+        auto once = [&]() -> int {
+            GPRY_TRY(launch_kernel_train(ctx, ctx->dW, 1));
+            ctx->info_cleared = false;
+            GPRY_TRY(potrf_lower_overlap(ctx, ctx->dW, ctx->Np));
+            return 0;
+        };
+        GPRY_TRY(once());                                   // plans, allocations
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (!graph) {
+            HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+            for (int r = 0; r < reps; r++) GPRY_TRY(once());
+            HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        } else {
+            hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+            HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+            const int rc = once();
+            const hipError_t ee = hipStreamEndCapture(ctx->stream, &g);
+            if (rc) return rc;
+            HIP_TRY(ctx, ee);
+            HIP_TRY(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            HIP_TRY(ctx, hipGraphLaunch(ge, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+            for (int r = 0; r < reps; r++) HIP_TRY(ctx, hipGraphLaunch(ge, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+            HIP_TRY(ctx, hipEventSynchronize(e1));
+            (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+        }
+        HIP_TRY(ctx, hipEventSynchronize(e1));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        int inf[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpy(inf, ctx->dinfo, sizeof(inf), hipMemcpyDeviceToHost));
+        if (inf[0] != 0) return gpry_fail(ctx, -1, "microbench 8: the matrix is not positive definite (info %d)", inf[0]);
+        *value = (double)ms * 1e3 / reps;
     } else if (kind == 4) {   // dispatch probe: fraction of blocks b that run on XCC (b % 8 + c) % 8
         const int nblk = 4096;
         int* d = nullptr;
