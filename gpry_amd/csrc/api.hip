@@ -729,6 +729,61 @@ int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgr
     return 0;
 }
 
+// ONE point: posterior mean, std and the two x-gradient contractions in one call (what GaussianProcessRegressor.predict
+// with return_mean_grad / return_std_grad asks for, once per L-BFGS step of the acquisition optimiser).  Mean and std are
+// finalised as by gpry_predict (affine map of y, clipping, mask bits); the gradients are the raw contractions of
+// gpry_predict_grad.
+int gpry_predict_point(gpry_ctx* ctx, const double* x, int mask_bits, int want_kinv, double* mean, double* std,
+                       double* mean_grad, double* kinvk_grad) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_predict_point: ctx is NULL");
+    GPRY_TRY(serve_stop(ctx));
+    GPRY_TRY(require_model(ctx, true));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!x || !mean || !std || !mean_grad || (want_kinv && !kinvk_grad))
+        return gpry_fail(ctx, -1, "predict_point: x, mean, std, mean_grad and (with want_kinv) kinvk_grad must not be NULL");
+    const int64_t Np = ctx->Np;
+    const int dpad = ctx->dpad, d = ctx->d;
+    if (Np * dpad > ctx->g_cap) {
+        if (ctx->dG) GPRY_TRY(dev_free(ctx, ctx->dG));
+        ctx->dG = nullptr; ctx->g_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dG, Np * dpad));
+        ctx->g_cap = Np * dpad;
+    }
+    if (want_kinv) GPRY_TRY(ensure_part(ctx, (Np / 128) * Np));
+    const int64_t nmb = (Np + 255) / 256, nsb = Np / 16;
+    const int64_t xb = round_up((int64_t)sizeof(double) * GPRY_MAX_DIM, 256);
+    GPRY_TRY(ensure_pinned(ctx, xb + (int64_t)sizeof(double) * (nmb + nsb + 2 * GPRY_MAX_DIM)));
+    char* h = (char*)ctx->hpin;
+    char* hd = (char*)ctx->hpin_dev;
+    memcpy(h, x, sizeof(double) * d);
+    double* hm = (double*)(h + xb);
+    double* hs = hm + nmb;
+    double* ho = hs + nsb;
+    double* dm = (double*)(hd + xb);
+    {
+        StageScope s(ctx, "predict_point");
+        GPRY_TRY(launch_point_full(ctx, (const double*)hd, want_kinv, ctx->dvec, ctx->dG, ctx->dvec + Np, ctx->dpart,
+                                   dm, dm + nmb, dm + nmb + nsb));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double mu_ = 0.0, ss = 0.0;
+    for (int64_t b = 0; b < nmb; b++) mu_ += hm[b];
+    for (int64_t b = 0; b < nsb; b++) ss += hs[b];
+    double y = fmin(mu_ * ctx->tf.y_std + ctx->tf.y_mean, ctx->tf.clip_hi);
+    if (mask_bits) y = -INFINITY;
+    *mean = y;
+    double var = exp(ctx->theta[0]) - ss;
+    if (var < 0.0) var = 0.0;
+    double sd = sqrt(var) * ctx->tf.y_std;
+    if (mask_bits & GPRY_MASK_CLASSIFIED_INF) sd = 0.0;
+    *std = sd;
+    for (int k = 0; k < d; k++) {
+        mean_grad[k] = ho[k];
+        if (kinvk_grad) kinvk_grad[k] = want_kinv ? ho[dpad + k] : 0.0;
+    }
+    return 0;
+}
+
 // column sums of squares of U (Np x ld): ss[i] = |u_i|^2, one workgroup per column
 __global__ __launch_bounds__(256) void colsumsq_kernel(const double* __restrict__ U, int64_t ld, int64_t nrow,
                                                        double* __restrict__ ss) {

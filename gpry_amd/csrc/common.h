@@ -263,6 +263,8 @@ int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
 int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right = false);   // chol_panel.hip
 // re-scales the training coordinates for the prediction factor if the last LML evaluation left its own in dXs
 int ensure_pred_xs(gpry_ctx* ctx);   // kernel_build.hip
+int launch_point_full(gpry_ctx* ctx, const double* x, int want_kinv, double* kstar, double* G, double* u, double* part,
+                      double* mean_part, double* ss_part, double* out);
 int launch_trtri_diag128(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right);   // trtri_small.hip
 int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st);
 bool gemm_dma_usable(const GemmArgs& g, int M, int N, int K);

@@ -726,8 +726,20 @@ __global__ __launch_bounds__(256) void gx_trmv_lower_t_part_kernel(const double*
     const int64_t i0 = (int64_t)blockIdx.y * 128;
     double s = 0.0;
     if (j < n && i0 + 127 >= j) {
-        const int64_t ib = i0 > j ? i0 : j;
-        for (int64_t i = ib; i < i0 + 128 && i < n; i++) s = fma(V[i * ld + j], u[i], s);
+        // eight loads in flight per step (one load per multiply-add was a chain of up to 128 memory latencies: 15 us per
+        // call whatever the size); rows above the diagonal enter as 0 * 0, which leaves the bits of the sum alone
+        for (int64_t ib = i0; ib < i0 + 128; ib += 8) {
+            double v[8], uu[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int64_t i = ib + q;
+                const bool in = i >= j && i < n;
+                v[q] = in ? V[i * ld + j] : 0.0;
+                uu[q] = in ? u[i] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) s = fma(v[q], uu[q], s);
+        }
     }
     if (j < n) part[(int64_t)blockIdx.y * n + j] = s;
 }
@@ -955,7 +967,7 @@ __global__ __launch_bounds__(256) void kstar_rows_kernel(
 template <int MM>
 __global__ __launch_bounds__(256) void trmv_multi_kernel(const double* __restrict__ V, int64_t ld,
                                                          const double* __restrict__ kstar, int M,
-                                                         double* __restrict__ ss_part) {
+                                                         double* __restrict__ ss_part, double* __restrict__ u_out = nullptr) {
     __shared__ double wsum[4][MM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t i0 = (int64_t)blockIdx.x * 16 + w * 4;
@@ -986,6 +998,7 @@ __global__ __launch_bounds__(256) void trmv_multi_kernel(const double* __restric
                 double u = acc[r][m];
                 for (int o = 32; o >= 1; o >>= 1) u += __shfl_xor(u, o);
                 ss = fma(u, u, ss);
+                if (m == 0 && u_out != nullptr && lane == 0) u_out[i0 + r] = u;      // (one-point calls that go on to V^T u)
             }
         }
         if (lane == 0) wsum[w][m] = ss;
@@ -1015,6 +1028,122 @@ int launch_predict_small_std(gpry_ctx* ctx, const double* Xc, int M, double* kst
 #undef KS2
     if (M <= 4) hipLaunchKernelGGL(trmv_multi_kernel<4>, dim3((unsigned)(Np / 16)), dim3(256), 0, ctx->stream, ctx->dV, Np, kstar, M, ss_part);
     else hipLaunchKernelGGL(trmv_multi_kernel<16>, dim3((unsigned)(Np / 16)), dim3(256), 0, ctx->stream, ctx->dV, Np, kstar, M, ss_part);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// ONE point, everything the acquisition optimiser asks of it in one call (gpry/gpr.py:1236-1266 as driven by
+// gpry/gp_acquisition.py:309-342: posterior mean, std and both x-gradients of a single point per L-BFGS step):
+//   gradx_rows_kernel      k*[j], G[j][k] = d k*_j / d x_k (the arithmetic of gradx_kernel) + per-workgroup partials of k*.alpha
+//   trmv_multi_kernel<4>   u = V k* (stored) + partials of |u|^2
+//   gx_trmv_lower_t_part   partials of w = V^T u                       (only when the std gradient is wanted)
+//   gradx_contract1_kernel G^T alpha and G^T w, w summed from its partials on the fly
+// The partials and the 2 d contractions land in the pinned, device-mapped staging buffer; the host adds them in a fixed order.
+// Four launches and one stream wait instead of predict (2 launches, a wait) + predict_grad (5 launches, two copies, a wait).
+template <int KID>
+__global__ __launch_bounds__(256) void gradx_rows_kernel(const double* __restrict__ x, const double* __restrict__ Xs,
+                                                         const double* __restrict__ alpha_, double* __restrict__ kstar,
+                                                         double* __restrict__ G, double* __restrict__ mean_part,
+                                                         int64_t Np, KernParams kp, AffParams ap) {
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * 256 + t;
+    double ks = 0.0;
+    if (j < Np) {
+        double diff[32];
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            diff[k] = 0.0;
+            if (k < kp.d) {
+                double v = x[k];
+                if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
+                v = v / ap.ls[k];
+                diff[k] = v - Xs[j * kp.dpad + k];
+                r2 = fma(diff[k], diff[k], r2);
+            }
+        }
+        const bool real = j < kp.N;
+        double kv, coef;
+        if (KID == GPRY_RBF) { kv = exp(-0.5 * r2); coef = -kv; }
+        else if (KID == GPRY_MATERN12) { double r = sqrt(r2); kv = exp(-r); coef = r != 0.0 ? -kv / r : 0.0; }
+        else if (KID == GPRY_MATERN32) { double tt = sqrt(r2) * SQRT3; double e = exp(-tt); kv = (1.0 + tt) * e; coef = -3.0 * e; }
+        else { double tt = sqrt(r2) * SQRT5; double e = exp(-tt); kv = (1.0 + tt + tt * tt * (1.0 / 3.0)) * e; coef = -(5.0 / 3.0) * (1.0 + tt) * e; }
+        ks = real ? kp.C * kv : 0.0;
+        kstar[j] = ks;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            if (k < kp.dpad) {
+                double g = 0.0;
+                if (real && k < kp.d) {
+                    g = kp.C * coef * diff[k] / ap.ls[k];
+                    if (KID == GPRY_MATERN12 && r2 == 0.0) g = -kp.C / ap.ls[k];
+                }
+                G[j * kp.dpad + k] = g;
+            }
+        }
+    }
+    red[t] = j < kp.N ? alpha_[j] * ks : 0.0;
+    __syncthreads();
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (t < sft) red[t] += red[t + sft];
+        __syncthreads();
+    }
+    if (t == 0) mean_part[blockIdx.x] = red[0];
+}
+// out[k] = sum_j G[j][k] alpha[j], out[dpad + k] = sum_j G[j][k] w[j] with w[j] = sum_r part[r][j] (ascending r, as gx_colsum_kernel)
+__global__ __launch_bounds__(256) void gradx_contract1_kernel(const double* __restrict__ G, int dpad,
+                                                              const double* __restrict__ a, const double* __restrict__ part,
+                                                              int nrow, int64_t n, double* __restrict__ out) {
+    __shared__ double ra[256], rw[256];
+    const int k = blockIdx.x, t = threadIdx.x;
+    double sa = 0.0, sw = 0.0;
+    for (int64_t j = t; j < n; j += 256) {
+        const double g = G[j * dpad + k];
+        sa = fma(g, a[j], sa);
+        if (part) {
+            double w = 0.0;
+            for (int r = 0; r < nrow; r++) w += part[(int64_t)r * n + j];
+            sw = fma(g, w, sw);
+        }
+    }
+    ra[t] = sa; rw[t] = sw;
+    __syncthreads();
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (t < sft) { ra[t] += ra[t + sft]; rw[t] += rw[t + sft]; }
+        __syncthreads();
+    }
+    if (t == 0) { out[k] = ra[0]; out[dpad + k] = rw[0]; }
+}
+// x, mean_part (Np/256 doubles), ss_part (Np/16), out (2 dpad): pinned, device-mapped; kstar, u: Np; G: Np x dpad; part: (Np/128) x Np
+int launch_point_full(gpry_ctx* ctx, const double* x, int want_kinv, double* kstar, double* G, double* u, double* part,
+                      double* mean_part, double* ss_part, double* out) {
+    GPRY_TRY(ensure_pred_xs(ctx));
+    KernParams kp = make_kp(ctx);
+    kp.has_aff = ctx->tf.has_x_affine;
+    AffParams ap = make_ap(ctx, kp.has_aff);
+    const int64_t Np = ctx->Np;
+    hipStream_t st = ctx->stream;
+#define GR(KID) hipLaunchKernelGGL((gradx_rows_kernel<KID>), dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, \
+                                   x, ctx->dXs, ctx->dalpha_, kstar, G, mean_part, Np, kp, ap)
+    DISPATCH_KID(ctx->kernel_id, GR)
+#undef GR
+    hipLaunchKernelGGL(trmv_multi_kernel<4>, dim3((unsigned)(Np / 16)), dim3(256), 0, st, ctx->dV, Np, kstar, 1, ss_part, u);
+    const int nrb = (int)(Np / 128);
+    const double* wsrc = nullptr;
+    int wrows = 0;
+    if (want_kinv) {
+        hipLaunchKernelGGL(gx_trmv_lower_t_part_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)nrb), dim3(256), 0, st,
+                           ctx->dV, Np, u, part, Np);
+        wsrc = part; wrows = nrb;
+        if (nrb > 8) {      // many row blocks: add them up once (into k*, which is no longer needed) instead of once per dimension
+            hipLaunchKernelGGL(gx_colsum_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, part, nrb, Np, kstar);
+            wsrc = kstar; wrows = 1;
+        }
+    }
+    hipLaunchKernelGGL(gradx_contract1_kernel, dim3((unsigned)ctx->dpad), dim3(256), 0, st, G, ctx->dpad, ctx->dalpha_,
+                       wsrc, wrows, Np, out);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

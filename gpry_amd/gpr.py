@@ -886,9 +886,17 @@ class GaussianProcessRegressor(_RM, _BE):
                 self.device.set_gates()          # host verdicts for this call: nothing may be ORed in on the device
                 self._dev_gates = None
             mask = self._masks(X, validate, ignore_trust_region)
-        res = self.device.predict(X, return_std=return_std, mask=mask)
-        y_mean = res[0] if return_std else res
-        y_std = res[1] if return_std else None
+        # one point with std and gradients (an acquisition optimiser's step): a single device call where the device has one
+        point_call = (return_mean_grad and return_std and hasattr(self.device, "predict_point")
+                      and not (mask is not None and bool(mask[0] & _lib.MASK_CLASSIFIED_INF)))
+        if point_call:
+            m1, s1, mg, kg = self.device.predict_point(X[0], mask_bits=0 if mask is None else int(mask[0]),
+                                                       want_kinv=bool(return_std_grad))
+            y_mean, y_std = np.array([m1]), np.array([s1])
+        else:
+            res = self.device.predict(X, return_std=return_std, mask=mask)
+            y_mean = res[0] if return_std else res
+            y_std = res[1] if return_std else None
         if self.minus_inf_value != -np.inf:
             y_mean[np.isneginf(y_mean)] = self.minus_inf_value
         if not return_mean_grad:
@@ -901,8 +909,10 @@ class GaussianProcessRegressor(_RM, _BE):
             grad_std = np.zeros((1, n_dims))
         else:
             _, std_y = self._y_affine()
-            want_std_grad = bool(return_std_grad) and not np.allclose(y_std, np.zeros(n_dims))
-            mg, kg = self.device.predict_grad(X[0], want_kinv=want_std_grad)
+            # (np.allclose(y_std, 0) of the reference for the single value there is: |std| <= 1e-8, False for NaN)
+            want_std_grad = bool(return_std_grad) and not abs(float(y_std[0])) <= 1e-8
+            if not point_call:
+                mg, kg = self.device.predict_grad(X[0], want_kinv=want_std_grad)
             grad_mean = mg * std_y
             grad_std = np.zeros(n_dims)
             if want_std_grad:

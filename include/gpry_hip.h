@@ -177,6 +177,15 @@ int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgr
 int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_kinv, double* mean,
                             double* std, double* mean_grad, double* kinvk_grad);
 
+/* ONE point, everything in one call: what gpry/gpr.py:1022-1273 returns for predict(x, return_std=True,
+ * return_mean_grad=True[, return_std_grad=True]) -- the call the acquisition optimiser makes once per L-BFGS step
+ * (gpry/gp_acquisition.py:309-342, gpry/acquisition_functions.py:937-1009).  mean / std as gpry_predict finalises them
+ * (y map, clipping; mask_bits: GPRY_MASK_* verdicts of the caller for this point: mean -inf, and std 0 for the
+ * classifier bit), mean_grad / kinvk_grad (d each; kinvk_grad only with want_kinv) as gpry_predict_grad.  Four launches
+ * and one stream wait instead of gpry_predict + gpry_predict_grad (seven launches, two copies, two waits). */
+int gpry_predict_point(gpry_ctx* ctx, const double* x, int mask_bits, int want_kinv, double* mean, double* std,
+                       double* mean_grad, double* kinvk_grad);
+
 /* ---- f4: gates of the sweep evaluated on the device --------------------------------- */
 /* Replaces the host-side verdicts that gpry/gpr.py:1107-1112 (trust region, raw coordinates,
  * closed box) and :1145-1150 -> gpry/svm.py:308-347 (sklearn SVC, RBF kernel, two classes:

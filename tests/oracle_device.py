@@ -126,6 +126,13 @@ class OracleDevice:
                 kg = np.dot(Kt, np.dot(V.T.dot(V), G))[0]
         return (mg, kg, G) if want_kgrad else (mg, kg)
 
+    def predict_point(self, x, mask_bits=0, want_kinv=True):
+        x = np.asarray(x, dtype=float)
+        mask = None if not mask_bits else np.array([mask_bits], dtype=np.uint8)
+        mean, std = self.predict(x[None, :], return_std=True, mask=mask)
+        mg, kg = self.predict_grad(x, want_kinv=want_kinv)
+        return float(mean[0]), float(std[0]), mg, kg
+
     def predict_grad_batch(self, X, want_kinv=True):
         X = np.atleast_2d(np.asarray(X, dtype=float))
         mean, std = self.predict(X, return_std=True)

@@ -524,6 +524,11 @@ def test_predict_leaves_classifier_and_trust_box_to_a_device_that_applies_them()
                 mask = self._gate_bits(np.atleast_2d(X))
             return super().predict(X, return_std=return_std, mask=mask)
 
+        def predict_point(self, x, mask_bits=0, want_kinv=True):
+            type(self).n_masked_calls += 1           # the host's verdict arrives with the call (as bits)
+            assert getattr(self, "gates", None) is None
+            return super().predict_point(x, mask_bits=mask_bits, want_kinv=want_kinv)
+
     bounds, X, y, Xc = orc.synthetic_like_goldens(150, 3, 400, seed=9)
     y = y.copy()
     y[X[:, 0] > 1.0] = -np.inf

@@ -462,6 +462,44 @@ def test_cholesky_with_concurrent_trailing_update_is_bit_identical(dev):
         dev.set_option("chol_outer", 0)
 
 
+@pytest.mark.parametrize("N,d,kid", [(60, 2, 0), (300, 5, 3), (1100, 7, 1), (2500, 3, 2)])
+def test_one_point_call_equals_predict_plus_predict_grad(N, d, kid):
+    """gpry_predict_point (mean, std and both x-gradient contractions of ONE point in one call: the acquisition
+    optimiser's step) against gpry_predict + gpry_predict_grad, with an X map, clipping and the two mask bits."""
+    from gpry_amd import _lib
+    rng = np.random.default_rng(N)
+    X = rng.uniform(size=(N, d)); y = np.sin(3 * X).sum(1)
+    dv = _lib.Device(0)
+    try:
+        dv.set_train(X, y, np.full(N, 1e-6)); dv.set_theta(kid, np.log(np.array([2.0] + [0.4] * d)))
+        lo, span = -0.5 * np.ones(d), 2.0 * np.ones(d)
+        dv.set_affine(lo, span, 0.3, 1.7, 1.2)
+        assert dv.factorize() == 0
+        for trial in range(6):
+            x = lo + span * rng.uniform(size=d)
+            if trial == 5:
+                x = lo + span * X[3]                                  # on a training point: std ~ 0
+            m0, s0 = dv.predict(x[None, :], return_std=True)
+            mg0, kg0 = dv.predict_grad(x)
+            m1, s1, mg1, kg1 = dv.predict_point(x)
+            C = 2.0 * 1.7 ** 2
+            assert abs(m1 - m0[0]) <= 1e-10 * max(1.0, abs(m0[0]))
+            assert abs(s1 ** 2 - s0[0] ** 2) <= 1e-10 * C
+            np.testing.assert_allclose(mg1, mg0, rtol=1e-10, atol=1e-11)
+            np.testing.assert_allclose(kg1, kg0, rtol=1e-9, atol=1e-10 * max(1.0, np.max(np.abs(kg0))))
+            _, _, mg2, kg2 = dv.predict_point(x, want_kinv=False)
+            np.testing.assert_array_equal(mg2, mg1)
+            assert np.all(kg2 == 0.0)
+        for bits, exp_std in ((_lib.MASK_OUTSIDE_TRUST, None), (_lib.MASK_CLASSIFIED_INF, 0.0)):
+            m1, s1, _, _ = dv.predict_point(x, mask_bits=bits)
+            mk = np.array([bits], dtype=np.uint8)
+            m0, s0 = dv.predict(x[None, :], return_std=True, mask=mk)
+            assert np.isneginf(m1) and np.isneginf(m0[0])
+            assert s1 == (exp_std if exp_std is not None else s1) and abs(s1 - s0[0]) <= 1e-12 * max(1.0, s0[0])
+    finally:
+        dv.close()
+
+
 def test_predictions_after_an_objective_evaluation_at_another_theta():
     """gpry_lml scales the training coordinates for ITS theta and no longer puts the prediction factor's back itself
     (one dispatch per evaluation of every fit): every reader on behalf of the prediction factor restores them first --
