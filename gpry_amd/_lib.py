@@ -61,7 +61,7 @@ SIGNATURES = {
     "gpry_debug_serve_stats": (C.c_int, [_vp, _P(C.c_int64), _P(C.c_int64)]),
     "gpry_predict_grad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     "gpry_predict_grad_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
-    "gpry_predict_point": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "gpry_predict_point": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "gpry_set_gates": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_int, _vp]),
     "gpry_sweep_logexp": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_double, C.c_double,
                                     C.c_double, _vp, _vp, _vp, _P(C.c_int64)]),
@@ -365,20 +365,21 @@ class Device:
         return (mg, kg, G) if want_kgrad else (mg, kg)
 
     def predict_point(self, x, mask_bits=0, want_kinv=True):
-        """``(mean, std, G^T alpha_, G^T K^-1 k*)`` of ONE point in one call (mean / std finalised as by ``predict``).
+        """``(mean, std, G^T alpha_, G^T K^-1 k*, verdict)`` of ONE point in one call (mean / std finalised as by ``predict``;
+        ``verdict``: the mask bits that were applied -- ``mask_bits`` and, with option "predict_gates", the device's own gates).
         Called once per step of an acquisition optimiser: argument buffers and their pointers are kept."""
         buf = getattr(self, "_point_buf", None)
         if buf is None or len(buf[0]) != self.d:
             xin, mg, kg = np.zeros(self.d), np.zeros(self.d), np.zeros(self.d)
-            mean, std = C.c_double(0.0), C.c_double(0.0)
-            buf = self._point_buf = (xin, mg, kg, mean, std, C.c_void_p(xin.ctypes.data), C.byref(mean), C.byref(std),
-                                     C.c_void_p(mg.ctypes.data), C.c_void_p(kg.ctypes.data))
-        xin, mg, kg, mean, std, px, pmean, pstd, pmg, pkg = buf
+            mean, std, bits = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+            buf = self._point_buf = (xin, mg, kg, mean, std, bits, C.c_void_p(xin.ctypes.data), C.byref(mean), C.byref(std),
+                                     C.c_void_p(mg.ctypes.data), C.c_void_p(kg.ctypes.data), C.byref(bits))
+        xin, mg, kg, mean, std, bits, px, pmean, pstd, pmg, pkg, pbits = buf
         xin[:] = x                                 # (raises on a shape mismatch; converts dtype / strides)
-        rc = self._lib.gpry_predict_point(self._h, px, int(mask_bits), 1 if want_kinv else 0, pmean, pstd, pmg, pkg)
+        rc = self._lib.gpry_predict_point(self._h, px, int(mask_bits), 1 if want_kinv else 0, pmean, pstd, pmg, pkg, pbits)
         if rc != 0:
             self._check(rc, "gpry_predict_point")
-        return mean.value, std.value, mg.copy(), kg.copy()
+        return mean.value, std.value, mg.copy(), kg.copy(), bits.value
 
     def predict_grad_batch(self, X, want_kinv=True):
         """``(mean, std, G^T alpha_, G^T K^-1 k*)`` for every row of ``X`` in one call."""

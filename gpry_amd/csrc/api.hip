@@ -734,7 +734,7 @@ int gpry_predict_grad(gpry_ctx* ctx, const double* x, int want_kinv, double* kgr
 // finalised as by gpry_predict (affine map of y, clipping, mask bits); the gradients are the raw contractions of
 // gpry_predict_grad.
 int gpry_predict_point(gpry_ctx* ctx, const double* x, int mask_bits, int want_kinv, double* mean, double* std,
-                       double* mean_grad, double* kinvk_grad) {
+                       double* mean_grad, double* kinvk_grad, int* verdict) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_predict_point: ctx is NULL");
     GPRY_TRY(serve_stop(ctx));
     GPRY_TRY(require_model(ctx, true));
@@ -752,7 +752,7 @@ int gpry_predict_point(gpry_ctx* ctx, const double* x, int mask_bits, int want_k
     if (want_kinv) GPRY_TRY(ensure_part(ctx, (Np / 128) * Np));
     const int64_t nmb = (Np + 255) / 256, nsb = Np / 16;
     const int64_t xb = round_up((int64_t)sizeof(double) * GPRY_MAX_DIM, 256);
-    GPRY_TRY(ensure_pinned(ctx, xb + (int64_t)sizeof(double) * (nmb + nsb + 2 * GPRY_MAX_DIM)));
+    GPRY_TRY(ensure_pinned(ctx, xb + (int64_t)sizeof(double) * (nmb + nsb + 2 * GPRY_MAX_DIM) + 256));
     char* h = (char*)ctx->hpin;
     char* hd = (char*)ctx->hpin_dev;
     memcpy(h, x, sizeof(double) * d);
@@ -760,12 +760,22 @@ int gpry_predict_point(gpry_ctx* ctx, const double* x, int mask_bits, int want_k
     double* hs = hm + nmb;
     double* ho = hs + nsb;
     double* dm = (double*)(hd + xb);
+    // "predict_gates" = 1: the classifier / trust-box verdict of gpry_set_gates for this point, ORed into mask_bits (one more
+    // small launch in the same stream; the host-side libsvm call it replaces costs 40 us per step of the optimiser)
+    const bool dev_gates = ctx->gates_on && ctx->opt_predict_gates;
+    uint8_t* hmask = (uint8_t*)(ho + 2 * GPRY_MAX_DIM);
+    if (dev_gates) {
+        hmask[0] = 0;
+        GPRY_TRY(launch_gates(ctx, (const double*)hd, 1, (uint8_t*)(hd + ((char*)hmask - h))));
+    }
     {
         StageScope s(ctx, "predict_point");
         GPRY_TRY(launch_point_full(ctx, (const double*)hd, want_kinv, ctx->dvec, ctx->dG, ctx->dvec + Np, ctx->dpart,
                                    dm, dm + nmb, dm + nmb + nsb));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (dev_gates) mask_bits |= hmask[0];
+    if (verdict) *verdict = mask_bits;
     double mu_ = 0.0, ss = 0.0;
     for (int64_t b = 0; b < nmb; b++) mu_ += hm[b];
     for (int64_t b = 0; b < nsb; b++) ss += hs[b];

@@ -877,7 +877,9 @@ class GaussianProcessRegressor(_RM, _BE):
         self._push_affine()
         # classifier and trust box: on the device with the points (``gpry_predict`` with "predict_gates") when they have
         # a device form; the x-gradient branch below needs the verdict on the host
-        if (not return_mean_grad and getattr(self.device, "applies_gates_in_predict", False)
+        # (the x-gradient branch reads the verdict: the one-point call returns it, the older entry points do not)
+        one_point = return_mean_grad and return_std and hasattr(self.device, "predict_point")
+        if ((not return_mean_grad or one_point) and getattr(self.device, "applies_gates_in_predict", False)
                 and (self.infinities_classifier is not None or self.trust_bounds is not None)
                 and self._sync_gates(ignore_trust_region)):
             mask = None
@@ -887,11 +889,10 @@ class GaussianProcessRegressor(_RM, _BE):
                 self._dev_gates = None
             mask = self._masks(X, validate, ignore_trust_region)
         # one point with std and gradients (an acquisition optimiser's step): a single device call where the device has one
-        point_call = (return_mean_grad and return_std and hasattr(self.device, "predict_point")
-                      and not (mask is not None and bool(mask[0] & _lib.MASK_CLASSIFIED_INF)))
+        point_call = one_point and not (mask is not None and bool(mask[0] & _lib.MASK_CLASSIFIED_INF))
+        verdict = 0 if mask is None else int(mask[0])
         if point_call:
-            m1, s1, mg, kg = self.device.predict_point(X[0], mask_bits=0 if mask is None else int(mask[0]),
-                                                       want_kinv=bool(return_std_grad))
+            m1, s1, mg, kg, verdict = self.device.predict_point(X[0], mask_bits=verdict, want_kinv=bool(return_std_grad))
             y_mean, y_std = np.array([m1]), np.array([s1])
         else:
             res = self.device.predict(X, return_std=return_std, mask=mask)
@@ -903,7 +904,7 @@ class GaussianProcessRegressor(_RM, _BE):
             return (y_mean, y_std) if return_std else y_mean
         # ---- one point: gradients (gpry/gpr.py:1236-1266)
         n_dims = X.shape[1]
-        classified_inf = mask is not None and bool(mask[0] & _lib.MASK_CLASSIFIED_INF)
+        classified_inf = bool(verdict & _lib.MASK_CLASSIFIED_INF)
         if classified_inf:     # :1157-1171: mean -inf, std 0, mean gradient +inf, std gradient 0
             grad_mean = np.ones((1, n_dims)) * self.inf_value
             grad_std = np.zeros((1, n_dims))

@@ -181,10 +181,11 @@ int gpry_predict_grad_batch(gpry_ctx* ctx, const double* X, int64_t m, int want_
  * return_mean_grad=True[, return_std_grad=True]) -- the call the acquisition optimiser makes once per L-BFGS step
  * (gpry/gp_acquisition.py:309-342, gpry/acquisition_functions.py:937-1009).  mean / std as gpry_predict finalises them
  * (y map, clipping; mask_bits: GPRY_MASK_* verdicts of the caller for this point: mean -inf, and std 0 for the
- * classifier bit), mean_grad / kinvk_grad (d each; kinvk_grad only with want_kinv) as gpry_predict_grad.  Four launches
+ * classifier bit; with option "predict_gates" the device's own verdict of gpry_set_gates is ORed in; *verdict (nullable)
+ * returns the bits that were applied), mean_grad / kinvk_grad (d each; kinvk_grad only with want_kinv) as gpry_predict_grad.  Four launches
  * and one stream wait instead of gpry_predict + gpry_predict_grad (seven launches, two copies, two waits). */
 int gpry_predict_point(gpry_ctx* ctx, const double* x, int mask_bits, int want_kinv, double* mean, double* std,
-                       double* mean_grad, double* kinvk_grad);
+                       double* mean_grad, double* kinvk_grad, int* verdict);
 
 /* ---- f4: gates of the sweep evaluated on the device --------------------------------- */
 /* Replaces the host-side verdicts that gpry/gpr.py:1107-1112 (trust region, raw coordinates,

@@ -128,10 +128,13 @@ class OracleDevice:
 
     def predict_point(self, x, mask_bits=0, want_kinv=True):
         x = np.asarray(x, dtype=float)
-        mask = None if not mask_bits else np.array([mask_bits], dtype=np.uint8)
-        mean, std = self.predict(x[None, :], return_std=True, mask=mask)
+        bits = int(mask_bits)
+        if getattr(self, "gates", None) is not None and getattr(self, "applies_gates_in_predict", False):
+            bits |= int(self._gate_bits(x[None, :])[0])
+        mask = None if not bits else np.array([bits], dtype=np.uint8)
+        mean, std = OracleDevice.predict(self, x[None, :], return_std=True, mask=mask)
         mg, kg = self.predict_grad(x, want_kinv=want_kinv)
-        return float(mean[0]), float(std[0]), mg, kg
+        return float(mean[0]), float(std[0]), mg, kg, bits
 
     def predict_grad_batch(self, X, want_kinv=True):
         X = np.atleast_2d(np.asarray(X, dtype=float))

@@ -525,8 +525,8 @@ def test_predict_leaves_classifier_and_trust_box_to_a_device_that_applies_them()
             return super().predict(X, return_std=return_std, mask=mask)
 
         def predict_point(self, x, mask_bits=0, want_kinv=True):
-            type(self).n_masked_calls += 1           # the host's verdict arrives with the call (as bits)
-            assert getattr(self, "gates", None) is None
+            if mask_bits:
+                type(self).n_masked_calls += 1
             return super().predict_point(x, mask_bits=mask_bits, want_kinv=want_kinv)
 
     bounds, X, y, Xc = orc.synthetic_like_goldens(150, 3, 400, seed=9)
@@ -558,13 +558,24 @@ def test_predict_leaves_classifier_and_trust_box_to_a_device_that_applies_them()
     assert GatedDouble.n_set_gates == 2
     np.testing.assert_array_equal(dev_g.predict(Xc[:50]), host_g.predict(Xc[:50]))     # (same batch size: same BLAS sums)
     assert GatedDouble.n_set_gates == 3
-    # the x-gradient branch needs the verdict on the host: the device gates are cleared for it, and come back afterwards
+    # the x-gradient branch reads the verdict: the one-point call applies the device's gates and returns it -- a finite
+    # point, a classifier-rejected one and one outside the trust box, with the reference's conventions for each
+    n1 = GatedDouble.n_set_gates
+    rejected = np.flatnonzero(np.isneginf(a))
+    for idx in (np.flatnonzero(np.isfinite(a))[0], rejected[0], rejected[-1]):
+        x1 = Xc[idx][None, :]
+        ga = dev_g.predict(x1, return_std=True, return_mean_grad=True, return_std_grad=True)
+        gb = host_g.predict(x1, return_std=True, return_mean_grad=True, return_std_grad=True)
+        for u, v in zip(ga, gb):
+            np.testing.assert_array_equal(u, v)
+    assert GatedDouble.n_masked_calls == 0 and dev_g.device.gates is not None and GatedDouble.n_set_gates == n1
+    # the two-call entry points (without std) still take host verdicts: the device gates are cleared for them, and come back
     x1 = Xc[np.flatnonzero(np.isfinite(a))[0]][None, :]
-    ga = dev_g.predict(x1, return_std=True, return_mean_grad=True)
-    gb = host_g.predict(x1, return_std=True, return_mean_grad=True)
+    ga = dev_g.predict(x1, return_mean_grad=True)
+    gb = host_g.predict(x1, return_mean_grad=True)
     for u, v in zip(ga, gb):
         np.testing.assert_array_equal(u, v)
-    assert GatedDouble.n_masked_calls == 1 and dev_g.device.gates is None
+    assert dev_g.device.gates is None
     np.testing.assert_array_equal(dev_g.predict(Xc[:50]), host_g.predict(Xc[:50]))
     assert dev_g.device.gates is not None
     # new data refits the classifier: its decision function reaches the device again

@@ -481,21 +481,32 @@ def test_one_point_call_equals_predict_plus_predict_grad(N, d, kid):
                 x = lo + span * X[3]                                  # on a training point: std ~ 0
             m0, s0 = dv.predict(x[None, :], return_std=True)
             mg0, kg0 = dv.predict_grad(x)
-            m1, s1, mg1, kg1 = dv.predict_point(x)
+            m1, s1, mg1, kg1, bits1 = dv.predict_point(x)
+            assert bits1 == 0
             C = 2.0 * 1.7 ** 2
             assert abs(m1 - m0[0]) <= 1e-10 * max(1.0, abs(m0[0]))
             assert abs(s1 ** 2 - s0[0] ** 2) <= 1e-10 * C
             np.testing.assert_allclose(mg1, mg0, rtol=1e-10, atol=1e-11)
             np.testing.assert_allclose(kg1, kg0, rtol=1e-9, atol=1e-10 * max(1.0, np.max(np.abs(kg0))))
-            _, _, mg2, kg2 = dv.predict_point(x, want_kinv=False)
+            _, _, mg2, kg2, _ = dv.predict_point(x, want_kinv=False)
             np.testing.assert_array_equal(mg2, mg1)
             assert np.all(kg2 == 0.0)
         for bits, exp_std in ((_lib.MASK_OUTSIDE_TRUST, None), (_lib.MASK_CLASSIFIED_INF, 0.0)):
-            m1, s1, _, _ = dv.predict_point(x, mask_bits=bits)
+            m1, s1, _, _, vb = dv.predict_point(x, mask_bits=bits)
+            assert vb == bits
             mk = np.array([bits], dtype=np.uint8)
             m0, s0 = dv.predict(x[None, :], return_std=True, mask=mk)
             assert np.isneginf(m1) and np.isneginf(m0[0])
             assert s1 == (exp_std if exp_std is not None else s1) and abs(s1 - s0[0]) <= 1e-12 * max(1.0, s0[0])
+        # the device's own gates (option predict_gates): a trust box that leaves the last point outside
+        dv.set_option("predict_gates", 1)
+        box = np.column_stack([x - 2.0, x - 1.0])
+        dv.set_gates(trust_bounds=box)
+        m1, s1, _, _, vb = dv.predict_point(x)
+        assert vb == _lib.MASK_OUTSIDE_TRUST and np.isneginf(m1) and s1 > 0.0
+        dv.set_gates(trust_bounds=np.column_stack([x - 1.0, x + 1.0]))
+        m1, s1, _, _, vb = dv.predict_point(x)
+        assert vb == 0 and np.isfinite(m1)
     finally:
         dv.close()
 
