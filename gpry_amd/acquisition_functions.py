@@ -91,5 +91,28 @@ class LogExp(AcquisitionFunction):
             return values, std_grad / (std[0] - sigma_n) + 2 * self.zeta * mu_grad
         return values, np.full_like(std_grad, np.inf)
 
+    def value_and_grad_rows(self, X, gp):
+        """``__call__(x, gp, eval_gradient=True)`` for every row of ``X`` from ONE batched posterior evaluation
+        (``gp.predict_with_gradients``): ``(values (m,), grads (m, d))`` with the single-point conventions row by row --
+        including the reference's two different tests for a usable gradient (:993-1007: the informative-point mask when
+        the GP hands out 2-d gradient arrays, i.e. has a classifier; ``std > sigma_n`` otherwise).  For the optimiser runs
+        that are stepped side by side (``gpry_amd.lockstep``); scalar noise only."""
+        X = self.check_X(X)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mu, std, mu_grad, std_grad = gp.predict_with_gradients(X)
+        noise, sigma_n = self._noise(gp)
+        if isinstance(sigma_n, Iterable):
+            raise ValueError("value_and_grad_rows needs a scalar noise level")
+        informative = (std ** 2 - noise ** 2. > 0) & np.isfinite(mu)
+        values = np.full_like(std, -np.inf)
+        if informative.any():
+            values[informative] = self.f(mu[informative], std[informative], gp.y_max, noise, self.zeta)
+        usable = informative if getattr(gp, "infinities_classifier", None) is not None else std > sigma_n
+        grads = np.full_like(std_grad, np.inf)
+        if usable.any():
+            grads[usable] = std_grad[usable] / (std[usable] - sigma_n)[:, None] + 2 * self.zeta * mu_grad[usable]
+        return values, grads
+
     def __repr__(self):
         return f"LogExp(zeta={self.zeta:.3f})"

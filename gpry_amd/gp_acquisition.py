@@ -90,9 +90,12 @@ class BatchOptimizer(GenericGPAcquisition):
     refactorises the model (gpry/gp_acquisition.py:488-491 -> gpry/gpr.py:1015-1017, O(N^3))."""
 
     def __init__(self, bounds, preprocessing_X=None, verbose=1, acq_func="LogExp", proposer=None,
-                 acq_optimizer="fmin_l_bfgs_b", n_restarts_optimizer="5d", n_repeats_propose=10):
+                 acq_optimizer="fmin_l_bfgs_b", n_restarts_optimizer="5d", n_repeats_propose=10, lockstep="auto"):
         super().__init__(bounds=bounds, preprocessing_X=preprocessing_X, verbose=verbose, acq_func=acq_func)
         self.obj_func = None
+        # "auto" / True: the L-BFGS-B runs of one proposal are stepped side by side and their posterior evaluations batched
+        # (gpry_amd.lockstep) when optimiser, acquisition function and model allow it; False: one run after another
+        self.lockstep = lockstep
         if proposer is None:
             proposer = PartialProposer(self.bounds_, CentroidsProposer(self.bounds_))
         elif not isinstance(proposer, Proposer):
@@ -140,12 +143,21 @@ class BatchOptimizer(GenericGPAcquisition):
             self.obj_func = self._objective(gpr)
         px = self.preprocessing_X
         tbounds = px.transform_bounds(use_bounds) if px is not None else use_bounds
+        x0, settled = self._starting_point(gpr, i, bounds, rng)
+        if settled is not None:
+            return x0, settled
+        return self._constrained_optimization(self.obj_func, x0, tbounds)
 
-        def start(x0):
-            return self._constrained_optimization(self.obj_func, px.transform(x0) if px is not None else x0, tbounds)
+    def _starting_point(self, gpr, i, bounds, rng):
+        """Where run ``i`` starts, in the optimiser's coordinates: ``(x0, None)``, or ``(x0, value)`` when there is
+        nothing to optimise (no finite proposal).  Consumes the generator exactly as the reference's run does."""
+        px = self.preprocessing_X
+
+        def coords(x0):
+            return px.transform(x0) if px is not None else x0
 
         if i == 0:
-            return start(next(X for X in gpr.X_train[::-1] if np.all(is_in_bounds(X, bounds, check_shape=False))))
+            return coords(next(X for X in gpr.X_train[::-1] if np.all(is_in_bounds(X, bounds, check_shape=False)))), None
         d = self.bounds_.shape[0]
         x0s = np.empty((self.n_repeats_propose + 1, d))
         values = np.empty(self.n_repeats_propose + 1)
@@ -159,10 +171,51 @@ class BatchOptimizer(GenericGPAcquisition):
             x0s[ifull], values[ifull] = x0, np.ravel(value)[0]
             ifull += 1
             if ifull > self.n_repeats_propose:
-                return start(x0s[np.argmax(values)])
+                return coords(x0s[np.argmax(values)]), None
         if ifull > 0:
-            return start(x0s[np.argmax(values[:ifull])])
-        return (px.transform(x0) if px is not None else x0), -1 * value
+            return coords(x0s[np.argmax(values[:ifull])]), None
+        return coords(x0), -1 * value
+
+    def _can_lockstep(self, gpr):
+        if self.lockstep is False or self.acq_optimizer != "fmin_l_bfgs_b":
+            return False
+        if not (hasattr(self.acq_func, "value_and_grad_rows") and hasattr(gpr, "predict_with_gradients")):
+            return False
+        if np.iterable(gpr.noise_level) and getattr(self.acq_func, "sigma_n", None) is None:
+            return False
+        from gpry_amd import lockstep
+        return lockstep.available()
+
+    def _optimize_side_by_side(self, gpr, n_runs, use_bounds, rng, proposal_X, acq_X):
+        """The ``n_runs`` optimiser runs of one proposal with their posterior evaluations batched: the starting points are
+        drawn run by run first (the optimiser itself draws nothing, so the generator is consumed as in the reference), then
+        the runs advance together (same routine, tolerances and stopping rules as ``fmin_l_bfgs_b``)."""
+        from gpry_amd import lockstep
+        self.proposer.update(gpr)
+        self.proposer.update_bounds(use_bounds)
+        px = self.preprocessing_X
+        tbounds = px.transform_bounds(use_bounds) if px is not None else use_bounds
+        todo = []
+        for i in range(n_runs):
+            # (the proposer's view of the model does not change between the runs of one proposal)
+            x0, settled = self._starting_point(gpr, i, use_bounds, rng)
+            proposal_X[i] = x0
+            if settled is None:
+                todo.append(i)
+            else:
+                acq_X[i] = settled
+
+        def fg(Xt):
+            X = px.inverse_transform(Xt) if px is not None else Xt
+            if len(X) < 4:      # the last runs still going: the one-point call is cheaper than a batched one of so few rows
+                rows = [self.acq_func(x[None, :], gpr, eval_gradient=True) for x in X]
+                return (-1 * np.array([np.ravel(a)[0] for a, _ in rows]), -1 * np.array([np.ravel(g) for _, g in rows]))
+            acq, grad = self.acq_func.value_and_grad_rows(X, gpr)
+            return -1 * acq, -1 * grad
+
+        if todo:
+            Xo, Fo, _ = lockstep.minimize_lockstep(fg, proposal_X[todo], np.asarray(tbounds, dtype=float))
+            proposal_X[todo], acq_X[todo] = Xo, Fo
 
     def multi_add(self, gpr, n_points=1, bounds=None, rng=None, force_resample=False):
         """``n_points`` proposals, each the best of ``n_restarts_optimizer`` optimiser runs on the model
@@ -175,9 +228,13 @@ class BatchOptimizer(GenericGPAcquisition):
         gpr_ = deepcopy(gpr)                    # the lies go into a copy
         n_runs = self.n_restarts_optimizer
         proposal_X, acq_X = np.empty((n_runs, gpr_.d)), np.empty((n_runs,))
+        side_by_side = self._can_lockstep(gpr_)
         for ipoint in range(n_points):
-            for i in range(n_runs):
-                proposal_X[i], acq_X[i] = self.optimize_acquisition_function(gpr_, i, bounds=use_bounds, rng=rng)
+            if side_by_side:
+                self._optimize_side_by_side(gpr_, n_runs, use_bounds, rng, proposal_X, acq_X)
+            else:
+                for i in range(n_runs):
+                    proposal_X[i], acq_X[i] = self.optimize_acquisition_function(gpr_, i, bounds=use_bounds, rng=rng)
             self.obj_func = None
             best = np.argmin(acq_X) if np.any(np.isfinite(acq_X)) else len(acq_X) - 1
             X_opt = proposal_X[best]
@@ -190,7 +247,7 @@ class BatchOptimizer(GenericGPAcquisition):
                 gpr_.append_to_data(X_opt, y_lie, noise_level=lie_noise, fit_gpr=False, fit_classifier=False)
             X_opts[ipoint], y_lies[ipoint], acq_vals[ipoint] = X_opt[0], y_lie[0], -1 * acq_X[best]
         gpr.n_eval = gpr_.n_eval
-        self.stats = {"border_updates": getattr(gpr_, "n_border_updates", 0)}
+        self.stats = {"border_updates": getattr(gpr_, "n_border_updates", 0), "side_by_side": bool(side_by_side)}
         return X_opts, y_lies, acq_vals
 
     def _constrained_optimization(self, obj_func, initial_X, bounds):

@@ -441,10 +441,55 @@ def test_batch_optimizer_mirror_vs_reference_vectors():
     np.testing.assert_allclose(yl, g["f10b_y_lies"], rtol=1e-6)
     np.testing.assert_allclose(av, g["f10b_acq_vals"], rtol=1e-6)
     assert gpr.n == 60                               # the lies went into a copy
+    assert acq.stats["side_by_side"] is True         # the runs of a proposal advanced together, evaluations batched
+    # ... and one after another (the reference's form): the same generator state afterwards, the same proposals
+    gpr1, gpr2 = model(), model()
+    kw = dict(proposer=None, n_restarts_optimizer=3, n_repeats_propose=2, verbose=0)
+    r1, r2 = np.random.default_rng(5), np.random.default_rng(5)
+    a1 = BatchOptimizer(bounds, lockstep=False, **kw)
+    a2 = BatchOptimizer(bounds, **kw)
+    o1 = a1.multi_add(gpr1, n_points=3, rng=r1)
+    o2 = a2.multi_add(gpr2, n_points=3, rng=r2)
+    assert a1.stats["side_by_side"] is False and a2.stats["side_by_side"] is True
+    assert r1.random() == r2.random()
+    np.testing.assert_allclose(o2[0], o1[0], atol=1e-5)
+    np.testing.assert_allclose(o2[1], o1[1], rtol=1e-6)
+    np.testing.assert_allclose(o2[2], o1[2], rtol=1e-6)
     with pytest.raises(TypeError):
         BatchOptimizer(bounds, proposer="uniform")
     with pytest.raises(ValueError):
         acq.multi_add(gpr, n_points=0)
+
+
+def test_lockstep_driver_reproduces_fmin_l_bfgs_b():
+    """``gpry_amd.lockstep``: scipy's L-BFGS-B routine driven for several starts at once takes, start by start, the steps of
+    ``fmin_l_bfgs_b`` (same bits), whatever the mix of finished and running starts, with evaluations arriving in batches."""
+    import scipy.optimize
+    from gpry_amd import lockstep
+    assert lockstep.available(), lockstep._STATE
+    rng = np.random.default_rng(3)
+    n = 5
+    A = rng.standard_normal((n, n)); A = A @ A.T + 0.5 * np.eye(n)
+    c = rng.standard_normal(n)
+
+    def fg(x):
+        return 0.5 * x @ A @ x - c @ x + np.sum(np.cos(2 * x)), A @ x - c - 2 * np.sin(2 * x)
+
+    bnds = np.array([[-1.0, 1.0], [-0.3, 0.2], [-np.inf, 0.5], [-2.0, np.inf], [-np.inf, np.inf]])
+    starts = rng.uniform(-1, 1, (9, n))
+    batches = []
+
+    def fgb(X):
+        batches.append(len(X))
+        out = [fg(x) for x in X]
+        return np.array([o[0] for o in out]), np.array([o[1] for o in out])
+
+    X, F, nfev = lockstep.minimize_lockstep(fgb, starts, bnds)
+    for s0, x, f, ne in zip(starts, X, F, nfev):
+        rx, rf, info = scipy.optimize.fmin_l_bfgs_b(fg, s0, bounds=[tuple(b) for b in bnds], approx_grad=False)
+        np.testing.assert_array_equal(x, rx)
+        assert f == rf and ne == info["funcalls"]
+    assert batches[0] == 9 and min(batches) < 9 and sum(batches) == nfev.sum()
 
 
 def test_proposers_draw_in_the_reference_order():

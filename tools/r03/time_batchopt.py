@@ -10,16 +10,18 @@ for N, d in ((64, 2), (256, 4), (1024, 8)):
     bounds, X, y, Xc, truth = bench.synthetic(N, d, 16)
     gpr = bench.make_gpr(bounds)
     gpr.append_to_data(X, y, fit_gpr="simple")
-    acq = BatchOptimizer(bounds, n_restarts_optimizer=5 * d, n_repeats_propose=10, verbose=0)
-    rng = np.random.default_rng(1)
-    acq.multi_add(gpr, n_points=2, rng=rng)
-    e0 = gpr.n_eval
-    t0 = time.perf_counter()
-    Xn, yl, av = acq.multi_add(gpr, n_points=2, rng=rng)
-    dt = time.perf_counter() - t0
-    ne = gpr.n_eval - e0
-    print(f"N={N} d={d}: multi_add(n_points=2, {5 * d} restarts) {dt * 1e3:.1f} ms, {ne} posterior evaluations, {dt / max(ne, 1) * 1e6:.1f} us each", flush=True)
-    if N == 256:
+    for lock in (False, "auto"):
+        acq = BatchOptimizer(bounds, n_restarts_optimizer=5 * d, n_repeats_propose=10, verbose=0, lockstep=lock)
+        rng = np.random.default_rng(1)
+        acq.multi_add(gpr, n_points=2, rng=rng)
+        e0 = gpr.n_eval
+        t0 = time.perf_counter()
+        Xn, yl, av = acq.multi_add(gpr, n_points=2, rng=rng)
+        dt = time.perf_counter() - t0
+        ne = gpr.n_eval - e0
+        print(f"N={N} d={d} {'side by side' if acq.stats['side_by_side'] else 'one after another'}: multi_add(n_points=2, {5 * d} restarts) {dt * 1e3:.1f} ms, "
+              f"{ne} posterior evaluations, {dt / max(ne, 1) * 1e6:.1f} us each; first proposal {np.round(Xn[0], 5)}", flush=True)
+    if N == -1:
         pr = cProfile.Profile(); pr.enable()
         acq.multi_add(gpr, n_points=2, rng=rng)
         pr.disable()
