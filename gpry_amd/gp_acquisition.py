@@ -84,10 +84,11 @@ class GenericGPAcquisition:
 class BatchOptimizer(GenericGPAcquisition):
     """Batch acquisition by optimising the acquisition function from several starting points and
     appending "lies" (gpry/gp_acquisition.py:127-525): same control flow, random-number order and
-    optimiser (scipy ``fmin_l_bfgs_b`` with the analytic x-gradient) as the reference.  On the device:
-    every objective evaluation is one ``predict`` with x-gradients (``gpry_predict_grad``), and each lie
-    extends the factor by a border row (``gpry_append_rows``, O(N^2)) where the reference rebuilds and
-    refactorises the model (gpry/gp_acquisition.py:488-491 -> gpry/gpr.py:1015-1017, O(N^3))."""
+    optimiser (scipy's L-BFGS-B with the analytic x-gradient) as the reference.  On the device: the optimiser
+    runs of a proposal advance side by side, the posterior evaluations of a round in one ``gpry_predict_grad_batch``
+    (``lockstep``; one ``gpry_predict_point`` per step with ``lockstep=False``, the reference's one-run-after-another
+    form), and each lie extends the factor by a border row (``gpry_append_rows``, O(N^2)) where the reference rebuilds
+    and refactorises the model (gpry/gp_acquisition.py:488-491 -> gpry/gpr.py:1015-1017, O(N^3))."""
 
     def __init__(self, bounds, preprocessing_X=None, verbose=1, acq_func="LogExp", proposer=None,
                  acq_optimizer="fmin_l_bfgs_b", n_restarts_optimizer="5d", n_repeats_propose=10, lockstep="auto"):
