@@ -164,15 +164,23 @@ class BatchOptimizer(GenericGPAcquisition):
         values = np.empty(self.n_repeats_propose + 1)
         ifull = 0
         x0 = value = None
-        for _ in range(10 * d * self.n_restarts_optimizer):
-            x0 = self.proposer.get(rng=rng)
-            value = self.acq_func(x0, gpr)
-            if not np.isfinite(value):
-                continue
-            x0s[ifull], values[ifull] = x0, np.ravel(value)[0]
-            ifull += 1
-            if ifull > self.n_repeats_propose:
-                return coords(x0s[np.argmax(values)]), None
+        # The reference draws a proposal, evaluates it and goes on until it holds n_repeats_propose + 1 finite values (or runs
+        # out of tries).  Drawn in rounds of exactly as many as are still missing, the proposals are the same ones in the same
+        # order -- the last finite one of the reference's loop is the last of a round -- and a round is ONE posterior evaluation.
+        tries = 10 * d * self.n_restarts_optimizer
+        while tries > 0 and ifull <= self.n_repeats_propose:
+            k = min(self.n_repeats_propose + 1 - ifull, tries)
+            tries -= k
+            batch = np.array([self.proposer.get(rng=rng) for _ in range(k)])
+            vals = np.ravel(self.acq_func(batch, gpr)) if self.lockstep is not False else \
+                np.array([np.ravel(self.acq_func(x, gpr))[0] for x in batch])
+            x0, value = batch[-1], vals[-1:]
+            for x, v in zip(batch, vals):
+                if np.isfinite(v):
+                    x0s[ifull], values[ifull] = x, v
+                    ifull += 1
+        if ifull > self.n_repeats_propose:
+            return coords(x0s[np.argmax(values)]), None
         if ifull > 0:
             return coords(x0s[np.argmax(values[:ifull])]), None
         return coords(x0), -1 * value
