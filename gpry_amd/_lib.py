@@ -57,6 +57,7 @@ SIGNATURES = {
     "gpry_get_factor": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gpry_append_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _P(C.c_int)]),
     "gpry_lml": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_double), _vp, _P(C.c_int)]),
+    "gpry_lml_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "gpry_predict": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "gpry_debug_serve_stats": (C.c_int, [_vp, _P(C.c_int64), _P(C.c_int64)]),
     "gpry_predict_grad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
@@ -303,6 +304,20 @@ class Device:
         if eval_gradient:
             return val.value, gr.copy(), info.value
         return val.value, info.value
+
+    def lml_batch(self, thetas, eval_gradient=True):
+        """``lml`` for every row of ``thetas`` in one call: ``(lml (B,), grad (B, 1 + d), info (B,))`` (``(lml, info)``
+        without gradients).  N <= 128, d <= 16: one launch, one workgroup per theta, the bits of single ``lml`` calls."""
+        thetas = _f64(np.atleast_2d(thetas))
+        B, w = thetas.shape
+        if w != self.d + 1:
+            raise ValueError(f"expected {self.d + 1} columns, got {w}")
+        lml = np.empty(B)
+        grad = np.zeros((B, w)) if eval_gradient else None
+        info = np.zeros(B, dtype=np.int32)
+        self._check(self._lib.gpry_lml_batch(self._h, _ptr(thetas), B, int(bool(eval_gradient)), _ptr(lml), _ptr(grad),
+                                             _ptr(info)), "gpry_lml_batch")
+        return (lml, grad, info) if eval_gradient else (lml, info)
 
     # -- predict / sweep ------------------------------------------------------------
     def predict(self, X, return_std=False, mask=None):

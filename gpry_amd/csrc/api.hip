@@ -290,6 +290,53 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     return 0;
 }
 
+// B objective evaluations in one call: the optimiser runs of a multi-restart fit stepped side by side (gpry/gpr.py:883-994 runs
+// them one after another).  N <= 128, d <= 16: ONE launch, one workgroup per theta (lml_small.hip) -- every theta gets the
+// arithmetic of a single gpry_lml call, hence the same bits; otherwise the thetas are evaluated one after another.
+int gpry_lml_batch(gpry_ctx* ctx, const double* thetas, int64_t B, int want_grad, double* lml, double* grad, int* info) {
+    if (!ctx) return gpry_fail(nullptr, -1, "gpry_lml_batch: ctx is NULL");
+    if (B <= 0) return 0;
+    if (!thetas || !lml || (want_grad && !grad)) return gpry_fail(ctx, -1, "lml_batch: thetas, lml and (with want_grad) grad must not be NULL");
+    const int w = ctx->d + 1;
+    bool fused = ctx->N > 0 && ctx->opt_lml_small && ctx->opt_chol == 0 && ctx->Np == 128 && ctx->d <= 16 && B <= 256;
+    for (int64_t i = 0; fused && i < B * w; i++) fused = isfinite(thetas[i]);
+    if (!fused) {
+        for (int64_t b = 0; b < B; b++) {
+            int inf = 0;
+            GPRY_TRY(gpry_lml(ctx, thetas + b * w, want_grad, lml + b, want_grad ? grad + b * w : nullptr, &inf));
+            if (info) info[b] = inf;
+        }
+        return 0;
+    }
+    GPRY_TRY(serve_stop(ctx));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<double> par((size_t)B * 17, 1.0), out((size_t)B * (2 + 1 + GPRY_MAX_DIM), 0.0);
+    std::vector<int> inf((size_t)B, 0);
+    for (int64_t b = 0; b < B; b++) {
+        par[b * 17] = exp(thetas[b * w]);                                   // as make_kp / make_ap for one evaluation
+        for (int k = 0; k < ctx->d; k++) par[b * 17 + 1 + k] = exp(thetas[b * w + 1 + k]);
+    }
+    {
+        StageScope s(ctx, "lml_small");
+        const int r = launch_lml_small_batch(ctx, (int)B, par.data(), want_grad, out.data(), inf.data());
+        if (r < 0) return r;
+        if (r != 0) return gpry_fail(ctx, -1, "lml_batch: the model does not fit the single-launch kernel");
+    }
+    ctx->lml_cache = false;
+    for (int64_t b = 0; b < B; b++) {
+        const double* o = out.data() + b * (2 + 1 + GPRY_MAX_DIM);
+        if (info) info[b] = inf[b];
+        if (inf[b] != 0) {   // sklearn:_gpr.py:586-589
+            lml[b] = -INFINITY;
+            if (want_grad) for (int k = 0; k < w; k++) grad[b * w + k] = 0.0;
+            continue;
+        }
+        lml[b] = -0.5 * o[1] - o[0] - 0.5 * (double)ctx->N * log(2.0 * M_PI);
+        if (want_grad) for (int k = 0; k < w; k++) grad[b * w + k] = o[2 + k];
+    }
+    return 0;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------

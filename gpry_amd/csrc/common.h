@@ -292,6 +292,7 @@ int launch_gradx(gpry_ctx* ctx, const double* x, int raw_affine, int want_kinv, 
 int launch_gradx_batch(gpry_ctx* ctx, const double* Xb, int64_t m, int raw_affine, const double* Wm, int64_t ldw,
                        double* out);
 int launch_lml_small(gpry_ctx* ctx, int want_grad, double* out, int* info);   // lml_small.hip: N <= 128, d <= 16 in one launch, results picked up as they land; 1 = not applicable
+int launch_lml_small_batch(gpry_ctx* ctx, int B, const double* params, int want_grad, double* out, int* info);   // out: B x (2 + 1 + GPRY_MAX_DIM)
 int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
                       double* grad_out_dev, const double* lq_dev, double* host_res, int info_at);
 // host_res (nullable, mapped host memory): [logdet/2, quad, grad...] and dinfo[0..1] as doubles at info_at, status last

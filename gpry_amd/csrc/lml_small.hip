@@ -52,7 +52,10 @@ struct LmlSmallArgs {
     unsigned long long seq; // stamp of this evaluation
     int want_grad;
     unsigned long long* dbg;   // nullable: cycles per phase (B, C, E, F, G, H) of the launch, added up (gpry_debug_read_diag)
+    const double* batch;       // nullable: several thetas in ONE launch, workgroup b evaluates [C, l_1 .. l_16] = batch[17 b ..] (the values
+                               // the host computes for a single evaluation: same bits) and reports into host_res + LS_UNITS * b
 };
+#define LS_UNITS (LS_INFO_UNIT + 1)
 
 template <int DP, int KID>
 __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernParams kp, AffParams ap) {
@@ -66,6 +69,13 @@ __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernPa
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int N = (int)kp.N;
+    if (a.batch != nullptr) {      // this workgroup's theta and result units (the restarts of a fit evaluated side by side)
+        const double* bp = a.batch + 17 * (int64_t)blockIdx.x;
+        kp.C = bp[0];
+#pragma unroll
+        for (int k = 0; k < DP; k++) ap.ls[k] = bp[1 + k];
+        a.host_res += LS_UNITS * (int64_t)blockIdx.x;
+    }
     const int nb = (N + 15) >> 4;            // 16-row blocks that hold training rows (the others are identity padding)
     unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
     const bool stamp = a.dbg != nullptr && t == 0;
@@ -331,17 +341,24 @@ __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernPa
     }
 }
 
-// N <= 128, d <= 16: the single-launch evaluation.  out: [sum log L_ii, quad, grad (1 + d) ...], *info: 0 or the failing
+// N <= 128, d <= 16: the single-launch evaluation, for B thetas at once (B workgroups of one launch; B = 1: gpry_lml).
+// params: B x 17 doubles [C, l_1 .. l_16] as the host computes them for a single evaluation (nullptr with B = 1: the
+// context's theta); out: B x (2 + 33) doubles [sum log L_ii, quad, grad (1 + d) ...] per theta, info[B]: 0 or the failing
 // column.  The results are picked up from the stamped units as they land (see LsUnit); the stream is only queried now and
 // then, to notice a launch that failed.  Returns 1 if the model does not fit this kernel (the caller takes the general
 // chain), 0 when `out` / `info` are filled, < 0 on errors.
-int launch_lml_small(gpry_ctx* ctx, int want_grad, double* out, int* info) {
+#define LS_OUT_STRIDE (2 + 1 + GPRY_MAX_DIM)
+int launch_lml_small_batch(gpry_ctx* ctx, int B, const double* params, int want_grad, double* out, int* info) {
     if (ctx->Np != LS_NP || ctx->d > 16) return 1;
+    if (B < 1 || (B > 1 && !params)) return gpry_fail(ctx, -1, "lml_small: bad batch");
     KernParams kp;
     kp.C = exp(ctx->theta[0]); kp.d = ctx->d; kp.dpad = ctx->dpad; kp.has_aff = 0; kp.N = ctx->N;
     AffParams ap = make_ap(ctx, false);
-    GPRY_TRY(ensure_pinned(ctx, 4096));
-    // the units live in the second KiB of the staging buffer (the general chain writes plain doubles into the first)
+    // the units live behind the first KiB of the staging buffer (the general chain writes plain doubles into that), the
+    // parameter rows of a batch behind the units
+    const int64_t unit_bytes = (int64_t)sizeof(LsUnit) * LS_UNITS * B;
+    const int64_t par_off = round_up(1024 + unit_bytes, 256);
+    GPRY_TRY(ensure_pinned(ctx, par_off + (int64_t)sizeof(double) * 17 * B + 256));
     LsUnit* hu = reinterpret_cast<LsUnit*>(static_cast<char*>(ctx->hpin) + 1024);
     LmlSmallArgs a;
     a.X = ctx->dX; a.y = ctx->dy; a.noise = ctx->dnoise;
@@ -349,32 +366,39 @@ int launch_lml_small(gpry_ctx* ctx, int want_grad, double* out, int* info) {
     a.seq = ++ctx->lml_seq;
     a.want_grad = want_grad;
     a.dbg = nullptr;
-    if (ctx->opt_chol_dbg) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); a.dbg = ctx->dsel + 16; }
-#define LS2(DP, KID) hipLaunchKernelGGL((lml_small_kernel<DP, KID>), dim3(1), dim3(LS_NT), 0, ctx->stream, a, kp, ap)
+    a.batch = nullptr;
+    if (params) {
+        memcpy(static_cast<char*>(ctx->hpin) + par_off, params, sizeof(double) * 17 * B);
+        a.batch = reinterpret_cast<const double*>(static_cast<char*>(ctx->hpin_dev) + par_off);
+    }
+    if (ctx->opt_chol_dbg && B == 1) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); a.dbg = ctx->dsel + 16; }
+#define LS2(DP, KID) hipLaunchKernelGGL((lml_small_kernel<DP, KID>), dim3((unsigned)B), dim3(LS_NT), 0, ctx->stream, a, kp, ap)
 #define LS4(KID) { if (ctx->d <= 4) LS2(4, KID); else if (ctx->d <= 8) LS2(8, KID); else LS2(16, KID); }
     DISPATCH_KID(ctx->kernel_id, LS4)
 #undef LS4
 #undef LS2
     HIP_TRY(ctx, hipGetLastError());
-    volatile LsUnit* vu = hu;
     const unsigned long long seq = a.seq;
+    const int need = 2 + (want_grad ? ctx->d + 1 : 0);
     long long spins = 0;
     bool finished = false;         // the stream has drained: whatever has not landed by now never will
+    int done = 0;                  // thetas 0 .. done - 1 have been picked up
     for (;;) {
-        if (vu[LS_INFO_UNIT].stamp == seq) {
+        while (done < B) {
+            volatile LsUnit* vu = hu + (int64_t)LS_UNITS * done;
+            if (vu[LS_INFO_UNIT].stamp != seq) break;
             unsigned long long b = vu[LS_INFO_UNIT].payload;
             double col; memcpy(&col, &b, 8);
-            if (col != 0.0) { *info = (int)col; return 0; }
-            const int need = 2 + (want_grad ? ctx->d + 1 : 0);
+            if (col != 0.0) { info[done] = (int)col; done++; continue; }
             bool all = true;
             for (int u = 0; u < need; u++) if (vu[u].stamp != seq) { all = false; break; }
-            if (all) {
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                for (int u = 0; u < need; u++) { b = vu[u].payload; memcpy(&out[u], &b, 8); }
-                *info = 0;
-                return 0;
-            }
+            if (!all) break;
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            for (int u = 0; u < need; u++) { b = vu[u].payload; memcpy(&out[(int64_t)LS_OUT_STRIDE * done + u], &b, 8); }
+            info[done] = 0;
+            done++;
         }
+        if (done == B) return 0;
         if (finished) return gpry_fail(ctx, -2, "lml: the single-launch evaluation did not deliver its results");
         if ((++spins & 0x3ff) == 0) {
             const hipError_t e = hipStreamQuery(ctx->stream);
@@ -382,4 +406,7 @@ int launch_lml_small(gpry_ctx* ctx, int want_grad, double* out, int* info) {
             else if (e != hipErrorNotReady) return gpry_fail(ctx, -2, "lml: %s", hipGetErrorString(e));
         }
     }
+}
+int launch_lml_small(gpry_ctx* ctx, int want_grad, double* out, int* info) {
+    return launch_lml_small_batch(ctx, 1, nullptr, want_grad, out, info);
 }

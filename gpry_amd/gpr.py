@@ -647,13 +647,15 @@ class GaussianProcessRegressor(_RM, _BE):
         self._rng = check_random_state(self.random_state)
         ctx_devs = (fit_context_devices(getattr(self.device, "device", 0), n_restarts, getattr(self, "fit_devices", None))
                     if self.optimizer == "fmin_l_bfgs_b" else [0])
-        if len(ctx_devs) > 1:
+        side_by_side = n_restarts > 1 and self._can_step_restarts_together()
+        if side_by_side or len(ctx_devs) > 1:
             # the optimiser never touches the RNG: drawing the start points up front gives the reference's
             # sequence (gpry/gpr.py:969-978)
             starts = [np.array(self.kernel_.theta) if (it == 0 and start_from_current) else
                       self._rng.uniform(hyperparameter_bounds[:, 0], hyperparameter_bounds[:, 1])
                       for it in range(n_restarts)]
-            optima = self._concurrent_restarts(starts, hyperparameter_bounds, ctx_devs)
+            optima = (self._restarts_side_by_side(starts, hyperparameter_bounds) if side_by_side
+                      else self._concurrent_restarts(starts, hyperparameter_bounds, ctx_devs))
         else:
             optima = []
             for iteration in range(n_restarts):
@@ -669,6 +671,57 @@ class GaussianProcessRegressor(_RM, _BE):
         self._update_model()
         self._fitted = True
         return self
+
+    def _can_step_restarts_together(self):
+        """Small training sets (the single-launch objective: N <= 128, d <= 16; ``gpry_lml_batch``): the optimiser runs
+        of a fit advance together and every round is ONE launch with a workgroup per run."""
+        if (self.optimizer != "fmin_l_bfgs_b" or getattr(self, "fit_lockstep", True) is False
+                or os.environ.get("GPRY_HIP_FIT_LOCKSTEP", "1") == "0"):
+            return False
+        if not hasattr(self.device, "lml_batch") or self.n > 128 or self.d > 16:
+            return False
+        from gpry_amd import lockstep
+        return lockstep.available()
+
+    def _restarts_side_by_side(self, starts, bounds):
+        """The runs of a multi-restart fit stepped together (``gpry_amd.lockstep``: scipy's own L-BFGS-B routine, one
+        reverse-communication call per run and round), the objective of a round evaluated for all runs in one
+        ``gpry_lml_batch``.  Every run sees the values -- to the bit -- and takes the steps it would take alone, so
+        the optima and the selected one are those of the sequential loop."""
+        from gpry_amd import lockstep
+        self._upload_train()
+        kern = clone(self.kernel_)
+        fast = hasattr(kern, "set_theta_and_full")
+        dev, d = self.device, self.d
+
+        def fg(Thetas):
+            fulls = []
+            for th in Thetas:
+                if fast:
+                    fulls.append(np.array(kern.set_theta_and_full(th, d)[1], dtype=float))
+                else:
+                    kern.theta = np.asarray(th, dtype=float)
+                    fulls.append(np.array(kern.device_spec(d)[1], dtype=float))
+            lml, grad_full, _ = dev.lml_batch(np.array(fulls), True)
+            self.n_eval_loglike += len(Thetas)
+            F, G = np.empty(len(Thetas)), np.zeros((len(Thetas), len(Thetas[0])))
+            for j, th in enumerate(Thetas):
+                if not np.isfinite(lml[j]):
+                    F[j] = np.inf
+                    continue
+                if fast:
+                    kern.set_theta_and_full(th, d)
+                    G[j] = -kern.grad_from_full_fast(grad_full[j], d)
+                else:
+                    kern.theta = np.asarray(th, dtype=float)
+                    G[j] = -kern.grad_from_full(grad_full[j], d)
+                F[j] = -lml[j]
+            return F, G
+
+        X, F, nfev = lockstep.minimize_lockstep(fg, np.array(starts, dtype=float), np.asarray(bounds, dtype=float))
+        self.fit_stats = {"contexts": 1, "devices": [getattr(dev, "device", 0)], "side_by_side": True,
+                          "evals_per_run": [int(v) for v in nfev]}
+        return [(X[i], F[i]) for i in range(len(starts))]
 
     def _concurrent_restarts(self, starts, bounds, ctx_devs):
         """The optimiser runs of a multi-restart fit are independent: they are worked off by one host

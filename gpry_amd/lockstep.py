@@ -19,7 +19,8 @@ _STATE = {"checked": False, "ok": False, "why": ""}
 
 
 class _Run:
-    __slots__ = ("x", "f", "g", "wa", "iwa", "task", "ln_task", "lsave", "isave", "dsave", "n_iter", "nfev", "done")
+    __slots__ = ("x", "f", "g", "wa", "iwa", "task", "ln_task", "lsave", "isave", "dsave", "n_iter", "nfev", "done",
+                 "seen_x", "seen_f", "seen_g")
 
     def __init__(self, x0, n, m):
         self.x = np.array(x0, dtype=np.float64)
@@ -35,6 +36,7 @@ class _Run:
         self.n_iter = 0
         self.nfev = 0
         self.done = False
+        self.seen_x = self.seen_f = self.seen_g = None      # the last point evaluated (scipy's ScalarFunction keeps it too)
 
 
 def minimize_lockstep(fg_batch, X0, bounds, m=10, factr=1e7, pgtol=1e-5, maxfun=15000, maxiter=15000, maxls=20):
@@ -69,6 +71,11 @@ def minimize_lockstep(fg_batch, X0, bounds, m=10, factr=1e7, pgtol=1e-5, maxfun=
                 _lbfgsb.setulb(m, r.x, low_bnd, upper_bnd, nbd, r.f, r.g, factr, pgtol, r.wa, r.iwa, r.task, r.lsave,
                                r.isave, r.dsave, maxls, r.ln_task)
                 if r.task[0] == 3:                     # wants f and g at r.x
+                    if r.seen_x is not None and np.array_equal(r.x, r.seen_x):
+                        # the routine asks again for the point it was just given (scipy's wrapper answers from its cache
+                        # without calling the function: neither do we)
+                        r.f, r.g = np.array(r.seen_f), np.array(r.seen_g)
+                        continue
                     waiting.append(i)
                     break
                 if r.task[0] == 1:                     # a new iteration has started
@@ -86,6 +93,7 @@ def minimize_lockstep(fg_batch, X0, bounds, m=10, factr=1e7, pgtol=1e-5, maxfun=
                 r = runs[i]
                 r.f = np.array(F[j], dtype=np.float64)
                 r.g = np.array(G[j], dtype=np.float64)
+                r.seen_x, r.seen_f, r.seen_g = r.x.copy(), r.f.copy(), r.g.copy()
                 r.nfev += 1
         active = [i for i in active if not runs[i].done]
     return (np.array([r.x for r in runs]), np.array([float(r.f) for r in runs]),

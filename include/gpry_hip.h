@@ -143,6 +143,12 @@ int gpry_append_rows(gpry_ctx* ctx, const double* Xnew_, const double* ynew_, co
 int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml,
              double* grad, int* info);
 
+/* B evaluations of the same objective in one call (thetas: B x (1 + d), lml: B, grad: B x (1 + d) or NULL, info: B or NULL,
+ * each as gpry_lml).  The optimiser runs of a multi-restart fit (gpry/gpr.py:883-994, one after another there) stepped side
+ * by side hand over one theta per run and round.  N <= 128, d <= 16: one launch, one workgroup per theta, every theta with
+ * the arithmetic -- and the bits -- of a single gpry_lml call; otherwise the thetas are evaluated one after another. */
+int gpry_lml_batch(gpry_ctx* ctx, const double* thetas, int64_t B, int want_grad, double* lml, double* grad, int* info);
+
 /* ---- a8-a11: posterior mean / std (gpry/gpr.py:1022-1273, 1275-1352) -------------- */
 /* X: M x d, raw if the affine map has_x_affine else already transformed.
  * mask (nullable): per-candidate GPRY_MASK_* bits.  mean/std in untransformed units,

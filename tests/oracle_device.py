@@ -90,6 +90,12 @@ class OracleDevice:
             return float(out[0]), np.array(out[1]), int(not np.isfinite(out[0]))
         return float(out), int(not np.isfinite(out))
 
+    def lml_batch(self, thetas, eval_gradient=True):
+        rows = [self.lml(th, eval_gradient) for th in np.atleast_2d(thetas)]
+        if eval_gradient:
+            return np.array([r[0] for r in rows]), np.array([r[1] for r in rows]), np.array([r[2] for r in rows])
+        return np.array([r[0] for r in rows]), np.array([r[1] for r in rows])
+
     # -- predict / sweep ----------------------------------------------------------------
     def _to_unit(self, X):
         X = np.atleast_2d(np.asarray(X, dtype=float))

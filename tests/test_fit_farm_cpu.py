@@ -52,6 +52,7 @@ def test_concurrent_restarts_select_the_sequential_optimum(monkeypatch):
     """The optimiser runs of a fit are shared by several device contexts / host threads
     (GaussianProcessRegressor._concurrent_restarts); the start points, every run and the selected
     optimum are those of the reference's sequential loop (GPRY_HIP_FIT_CONTEXTS=1)."""
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0")      # the thread farm is under test, not the side-by-side runs
     g = load_golden("fit")
     p = "f6_k3_"
     X, y = g[p + "X"], g[p + "y"]
@@ -69,10 +70,33 @@ def test_concurrent_restarts_select_the_sequential_optimum(monkeypatch):
         np.testing.assert_array_equal(out[n_ctx][3], out["1"][3])
 
 
+def test_restarts_stepped_side_by_side_select_the_sequential_optimum(monkeypatch):
+    """Small training sets: the optimiser runs of a fit advance together and every round is ONE batched objective call
+    (``_restarts_side_by_side`` / ``gpry_lml_batch``): start points, every run, the evaluation count and the selected
+    optimum are those of the sequential loop."""
+    g = load_golden("fit")
+    p = "f6_k3_"
+    X, y = g[p + "X"], g[p + "y"]
+    out = {}
+    for mode in ("sequential", "side by side"):
+        monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+        monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0" if mode == "sequential" else "1")
+        gpr = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=5, random_state=7)
+        gpr.append_to_data(X[:60], y[:60], fit_gpr=True)
+        assert bool(getattr(gpr, "fit_stats", {}).get("side_by_side")) == (mode == "side by side")
+        out[mode] = (gpr.kernel_.theta.copy(), gpr.log_marginal_likelihood_value_, gpr.n_eval_loglike,
+                     gpr.predict(g[p + "Xc"]), gpr._rng.random())
+    a, b = out["sequential"], out["side by side"]
+    np.testing.assert_array_equal(b[0], a[0])
+    assert b[1] == a[1] and b[2] == a[2] and b[4] == a[4]
+    np.testing.assert_array_equal(b[3], a[3])
+
+
 def test_fit_contexts_are_dealt_out_over_the_devices_of_the_process(monkeypatch):
     """``fit_context_devices``: own device first, GPUs round-robin (the first restarts land on distinct
     GPUs), ``GPRY_HIP_FIT_CONTEXTS`` contexts per GPU, never more contexts than restarts; one rank of a
     multi-process launch stays on its own GPU; an explicit list (repeats allowed) is taken as it is."""
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0")      # the thread farm is under test, not the side-by-side runs
     from gpry_amd import gpr as G
     from gpry_amd import _lib
     for var in ("GPRY_HIP_DEVICES", "WORLD_SIZE", "GPRY_HIP_FIT_CONTEXTS"):
@@ -103,6 +127,7 @@ def test_restart_farm_over_several_devices_in_one_process_equals_the_sequential_
     1238-1293): the restarts of a fit spread over the contexts of ``fit_devices`` give the start points,
     optima, selected theta, LML and evaluation count of the reference's sequential loop, and every context
     is created on the device it was dealt."""
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0")      # the thread farm is under test, not the side-by-side runs
     g = load_golden("fit")
     p = "f6_k3_"
     X, y = g[p + "X"], g[p + "y"]

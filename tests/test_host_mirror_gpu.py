@@ -56,6 +56,7 @@ def test_f6_fit_full_and_simple_vs_reference(kid, N):
 def test_concurrent_restarts_select_the_sequential_optimum_on_the_device(monkeypatch):
     """Three device contexts driven from three host threads share the restarts of one fit: same
     hyper-parameters, LML and evaluation count as the sequential loop, bit for bit."""
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0")      # the thread farm is under test, not the side-by-side runs
     g = load_golden("fit")
     p = "f6_k3_"
     X, y = g[p + "X"], g[p + "y"]
@@ -77,6 +78,7 @@ def test_restart_farm_over_the_devices_of_one_process_equals_the_sequential_fit(
     (here k contexts on device 0 -- on an 8-GPU node ``fit_context_devices`` deals them out over all GPUs, 3 per
     GPU) select the theta, LML and evaluation count of the reference's sequential loop bit for bit, and the F6
     golden optimum of the reference itself within the tolerances of ``test_f6_fit_full_and_simple_vs_reference``."""
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0")      # the thread farm is under test, not the side-by-side runs
     g = load_golden("fit")
     p = "f6_k3_"
     X, y, Xc = g[p + "X"], g[p + "y"], g[p + "Xc"]
@@ -112,6 +114,7 @@ def test_concurrent_fit_is_reproducible_over_many_runs(monkeypatch):
     hand-over of LML results shows up as a different evaluation count in a few percent of the fits -- host-side
     polling of results in mapped memory did exactly that while passing the single
     comparison above most of the time."""
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0")      # the thread farm is under test, not the side-by-side runs
     g = load_golden("fit")
     p = "f6_k3_"
     X, y = g[p + "X"], g[p + "y"]
@@ -519,6 +522,7 @@ def test_config4_one_gpu_share_of_the_restart_farm_at_full_size(monkeypatch):
     from the current theta), through the farm entry over a 1-rank RCCL communicator.  The restarts shared by three
     device contexts must select, bit for bit, what the reference's sequential loop selects; the optimum must be
     one: its LML is the device's own LML at that theta and the gradient vanishes on the free hyper-parameters."""
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0")      # the thread farm is under test, not the side-by-side runs
     import bench
     from gpry_amd import _lib
     from gpry_amd.parallel import fit_gpr_parallel
@@ -543,3 +547,24 @@ def test_config4_one_gpu_share_of_the_restart_farm_at_full_size(monkeypatch):
             assert free.sum() >= d // 2 and np.max(np.abs(grad[free])) <= 1e-2 * max(1.0, abs(lml)) ** 0.5
     np.testing.assert_array_equal(out["3"][0], out["1"][0])
     assert out["3"][1] == out["1"][1] and out["3"][2] == out["1"][2] and out["3"][2] > 10
+
+
+@pytest.mark.gpu
+def test_restarts_stepped_side_by_side_on_the_device_select_the_sequential_optimum(monkeypatch):
+    """A multi-restart fit at N <= 128: all optimiser runs advance together, one launch per round (a workgroup per run);
+    hyper-parameters, LML, evaluation count and predictions equal the sequential fit bit for bit."""
+    g = load_golden("fit")
+    p = "f6_k3_"
+    X, y = g[p + "X"], g[p + "y"]
+    out = {}
+    for mode in ("sequential", "side by side"):
+        monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+        monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0" if mode == "sequential" else "1")
+        gpr = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=8, random_state=11)
+        gpr.append_to_data(X[:60], y[:60], fit_gpr=True)
+        assert bool(getattr(gpr, "fit_stats", {}).get("side_by_side")) == (mode == "side by side")
+        out[mode] = (gpr.kernel_.theta.copy(), gpr.log_marginal_likelihood_value_, gpr.n_eval_loglike, gpr.predict(g[p + "Xc"]))
+    a, b = out["sequential"], out["side by side"]
+    np.testing.assert_array_equal(b[0], a[0])
+    assert b[1] == a[1] and b[2] == a[2]
+    np.testing.assert_array_equal(b[3], a[3])

@@ -90,3 +90,36 @@ def test_fit_through_the_single_launch_objective_selects_the_reference_optimum(m
         np.testing.assert_allclose(m, g[p + "mean_full"], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(s, g[p + "std_full"], rtol=1e-4, atol=1e-5)
         assert gpr.device.timing("lml_small")[1] == 0        # (timers are off unless asked for)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d,kid", [(40, 2, 0), (100, 5, 3), (128, 16, 3)])
+def test_batched_objective_has_the_bits_of_single_evaluations(N, d, kid):
+    """gpry_lml_batch at N <= 128: one launch, one workgroup per theta, every theta with the arithmetic of a single
+    gpry_lml call -- values, gradients and the not-positive-definite verdicts equal those of B separate calls bit for bit."""
+    from gpry_amd import _lib
+    rng = np.random.default_rng(N + d)
+    X = rng.uniform(size=(N, d)); y = np.sin(3 * X).sum(1) + 0.05 * rng.standard_normal(N)
+    dv = _lib.Device(0)
+    try:
+        dv.set_train(X, y, np.full(N, 1e-8 if kid == 0 else 1e-6)); dv.set_theta(kid, np.log(np.array([2.0] + [0.4] * d)))
+        thetas = np.log(np.array([2.0] + [0.4] * d)) + rng.uniform(-1.5, 1.5, (37, d + 1))
+        thetas[5, 1:] = np.log(300.0)                       # a nearly singular matrix: may fail to factorise
+        single = [dv.lml(th, True) for th in thetas]
+        lml, grad, info = dv.lml_batch(thetas, True)
+        for b, (l1, g1, i1) in enumerate(single):
+            assert info[b] == i1
+            assert (lml[b] == l1) or (np.isneginf(lml[b]) and np.isneginf(l1))
+            np.testing.assert_array_equal(grad[b], g1)
+        lml0, info0 = dv.lml_batch(thetas[:3], False)
+        assert [dv.lml(th, False)[0] for th in thetas[:3]] == list(lml0)
+        # larger training sets: the same entry point, evaluated one after another
+        X2 = rng.uniform(size=(200, d))
+        dv.set_train(X2, np.sin(3 * X2).sum(1), np.full(200, 1e-6)); dv.set_theta(kid, thetas[0])
+        lml2, grad2, info2 = dv.lml_batch(thetas[:4], True)
+        for b in range(4):
+            l1, g1, i1 = dv.lml(thetas[b], True)
+            assert lml2[b] == l1 and info2[b] == i1
+            np.testing.assert_array_equal(grad2[b], g1)
+    finally:
+        dv.close()
