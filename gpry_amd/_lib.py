@@ -48,6 +48,7 @@ SIGNATURES = {
     "gpry_last_error": (C.c_char_p, [_vp]),
     "gpry_ctx_sync": (C.c_int, [_vp]),
     "gpry_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "gpry_ctx_get_option": (C.c_int, [_vp, C.c_char_p, _vp]),
     "gpry_set_train": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int]),
     "gpry_set_theta": (C.c_int, [_vp, C.c_int, _vp]),
     "gpry_set_affine": (C.c_int, [_vp, _P(GpryAffine)]),
@@ -212,6 +213,17 @@ class Device:
     def set_option(self, key, value):
         self._check(self._lib.gpry_ctx_set_option(self._h, key.encode(), int(value)),
                     "gpry_ctx_set_option")
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        self._check(self._lib.gpry_ctx_get_option(self._h, key.encode(), C.byref(v)), "gpry_ctx_get_option")
+        return v.value
+
+    @property
+    def lml_batch_max(self):
+        """Largest training set whose ``lml_batch`` runs as ONE chain of launches (option ``lml_batch``; up to 128 points
+        the single-launch objective serves a batch whatever this says)."""
+        return self.get_option("lml_batch")
 
     def info(self):
         name = C.create_string_buffer(256)

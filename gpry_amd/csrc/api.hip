@@ -91,6 +91,161 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
     return 0;
 }
 
+// The launches of one objective evaluation (sklearn:_gpr.py:574-652) at the theta the context holds -- or, in a batched
+// evaluation (gpry_ctx::bn), at the bn thetas whose [C, l...] rows sit in the arena: covariance build, factor, V = L^-1,
+// alpha, log-det and quadratic form, and with want_grad K^-1 = V^T V and the traces.  The last kernel writes results and
+// factorisation status into `dres` (device view of pinned host memory; theta tb at row tb of GPRY_BRES_STRIDE doubles).
+constexpr int RES_INFO = 2 + 1 + GPRY_MAX_DIM;      // [logdet/2, quad, grad (1 + d) ..., info0, info1]
+static_assert(RES_INFO + 2 <= GPRY_BRES_STRIDE, "result row too short");
+static int lml_chain(gpry_ctx* ctx, int want_grad, double* dres) {
+    GPRY_TRY(build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, nullptr));
+    double* dz = ctx->dvec;                 // z = V y
+    double* da = ctx->dvec + ctx->Np;       // alpha
+    double* dout = ctx->dvec + 2 * ctx->Np; // device copy: [logdet/2, quad, grad...]
+    GPRY_TRY(solve_alpha(ctx, ctx->dW2, ctx->dy, dz, da, ctx->Np));
+    GPRY_TRY(logdet_and_quad(ctx, ctx->dW, dz, ctx->Np, dout, want_grad ? nullptr : dres, RES_INFO));
+    if (!want_grad) return 0;
+    {
+        StageScope s(ctx, "lauum");
+        GPRY_TRY(lauum_lower(ctx, ctx->dW2, ctx->dW3, ctx->Np));
+    }
+    StageScope s(ctx, "lml_traces");
+    return launch_lml_traces(ctx, ctx->dW3, da, dout + 2, dout, dres, RES_INFO);
+}
+
+// ---- B thetas in ONE chain of launches (128 < Np <= lml_batch) --------------------------------------------------
+// The reference runs the optimiser restarts of a fit one after another (gpry/gpr.py:968-984, 10 + 2 d of them by default,
+// gpry/run.py:315-325); stepped side by side (gpry_amd/lockstep.py) they hand a round's thetas to gpry_lml_batch.  Above
+// N = 128 one evaluation is a chain of 20-60 launches that keeps a handful of CUs busy (0.001-0.02 of the FP64 peak at
+// N = 256 ... 1024); here every launch of that chain carries all thetas (grid.z).  Same kernels, same launch geometry,
+// same operands per theta as a single gpry_lml: the per-theta results are bit-identical to it.
+struct BatchLayout {
+    int64_t w, w2, w3, xs, vec, part, split, par, info;     // offsets (doubles) within a theta's set
+    int64_t part_cap, split_cap, stride;
+};
+static int batch_layout(gpry_ctx* ctx, BatchLayout* L) {
+    const int64_t Np = ctx->Np, nn = Np * Np;
+    int slices = 0;
+    GPRY_TRY(factor_chain_slices(ctx, Np, &slices));
+    const int DPsel = ctx->d <= 4 ? 4 : ctx->d <= 8 ? 8 : ctx->d <= 16 ? 16 : ctx->d <= 24 ? 24 : 32;
+    const int64_t nb = Np / 64, ntile = nb * (nb + 1) / 2;
+    const int64_t p1 = ((Np + 255) / 256) * Np, p2 = ntile * (DPsel + 1);       // solve_alpha, launch_lml_traces
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += round_up(n, 32); return at; };      // 256-byte pieces
+    L->w = take(nn); L->w2 = take(nn); L->w3 = take(nn);
+    L->xs = take(Np * ctx->dpad);
+    L->vec = take(8 * Np + 4096);
+    L->part_cap = p1 > p2 ? p1 : p2; L->part = take(L->part_cap);
+    L->split_cap = (int64_t)slices * nn; L->split = take(L->split_cap > 0 ? L->split_cap : 1);
+    L->par = take(1 + GPRY_MAX_DIM);
+    L->info = take(8);                      // 16 status / arrival words
+    L->stride = o + 32 * 9;                 // not a multiple of a large power of two: consecutive sets start on different channels
+    return 0;
+}
+static int ensure_batch_buffers(gpry_ctx* ctx, int64_t arena_doubles, int64_t res_bytes) {
+    if (arena_doubles > ctx->barena_cap) {
+        if (ctx->barena) GPRY_TRY(dev_free(ctx, ctx->barena));
+        ctx->barena = nullptr; ctx->barena_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->barena, arena_doubles));
+        ctx->barena_cap = arena_doubles;
+    }
+    if (res_bytes > ctx->hbres_cap) {
+        if (ctx->hbres) HIP_TRY(ctx, hipHostFree(ctx->hbres));
+        ctx->hbres = nullptr; ctx->hbres_dev = nullptr; ctx->hbres_cap = 0;
+        HIP_TRY(ctx, hipHostMalloc(&ctx->hbres, (size_t)res_bytes, hipHostMallocMapped | hipHostMallocPortable));
+        HIP_TRY(ctx, hipHostGetDevicePointer(&ctx->hbres_dev, ctx->hbres, 0));
+        memset(ctx->hbres, 0, (size_t)res_bytes);
+        ctx->hbres_cap = res_bytes;
+    }
+    return 0;
+}
+// is the batched chain built for this context's size and options?  (the experiment switches of the single chain that the
+// batched launches do not carry fall back to one evaluation after another)
+static bool lml_batch_usable(const gpry_ctx* ctx) {
+    return ctx->N > 0 && ctx->Np > 128 && ctx->Np <= ctx->opt_lml_batch && ctx->d <= 32 && ctx->opt_chol == 0 && ctx->opt_chol_overlap &&
+           !ctx->opt_chol_lookahead && ctx->opt_chol_outer == 0 && !ctx->opt_chol_dbg && ctx->opt_kb_variant >= 1 && ctx->opt_kb_variant <= 3 &&
+           ctx->opt_trtri_diag_v1 != 1 && ctx->Np < ctx->opt_factor_pipeline_min;
+}
+static int lml_batch_general(gpry_ctx* ctx, const double* thetas, int64_t B, int want_grad, double* lml, double* grad, int* info) {
+    const int w = ctx->d + 1;
+    for (int64_t i = 0; i < B * w; i++)
+        if (!isfinite(thetas[i])) return gpry_fail(ctx, -1, "theta[%d] is not finite", (int)(i % w));
+    GPRY_TRY(serve_stop(ctx));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BatchLayout L;
+    GPRY_TRY(batch_layout(ctx, &L));
+    // thetas per chain: the diagonal workgroup of a panel step waits for the other workgroups of ITS theta to have read the
+    // block it overwrites -- only those wait, one per theta, so any number well below the GPU's workgroup slots is safe
+    int64_t chunk = B < 96 ? B : 96;
+    const int64_t mem_cap = (ctx->opt_lml_batch_mb << 20) / (8 * L.stride);
+    if (chunk > mem_cap) chunk = mem_cap;
+    if (chunk < 2) return 1;                // the caller evaluates them one after another
+    GPRY_TRY(ensure_batch_buffers(ctx, chunk * L.stride, (int64_t)sizeof(double) * chunk * (GPRY_BRES_STRIDE + 1 + GPRY_MAX_DIM)));
+    double* hres = static_cast<double*>(ctx->hbres);
+    double* hpar = hres + chunk * GPRY_BRES_STRIDE;         // [C, l_1 .. l_d] rows of a chunk, staged in the pinned buffer
+    // the chain below is the code of a single evaluation: it finds the buffers of theta 0 where the context keeps its own
+    struct Scope {
+        gpry_ctx* c;
+        double *dW, *dW2, *dW3, *dXs, *dvec, *dpart, *dsplit; int* dinfo;
+        int64_t part_cap, split_cap; bool xs_foreign, have_theta;
+        double theta[1 + GPRY_MAX_DIM];
+        explicit Scope(gpry_ctx* ctx) : c(ctx), dW(ctx->dW), dW2(ctx->dW2), dW3(ctx->dW3), dXs(ctx->dXs), dvec(ctx->dvec), dpart(ctx->dpart),
+                                        dsplit(ctx->dsplit), dinfo(ctx->dinfo), part_cap(ctx->part_cap), split_cap(ctx->split_cap),
+                                        xs_foreign(ctx->xs_foreign), have_theta(ctx->have_theta) {
+            memcpy(theta, ctx->theta, sizeof(theta));
+        }
+        ~Scope() {
+            c->dW = dW; c->dW2 = dW2; c->dW3 = dW3; c->dXs = dXs; c->dvec = dvec; c->dpart = dpart; c->dsplit = dsplit; c->dinfo = dinfo;
+            c->part_cap = part_cap; c->split_cap = split_cap; c->xs_foreign = xs_foreign; c->have_theta = have_theta;
+            c->info_cleared = false;
+            memcpy(c->theta, theta, sizeof(theta));
+            c->bn = 1; c->bstride = 0; c->bpar = nullptr;
+        }
+    } scope(ctx);
+    double* a0 = ctx->barena;
+    ctx->dW = a0 + L.w; ctx->dW2 = a0 + L.w2; ctx->dW3 = a0 + L.w3; ctx->dXs = a0 + L.xs; ctx->dvec = a0 + L.vec;
+    ctx->dpart = a0 + L.part; ctx->part_cap = L.part_cap; ctx->dsplit = a0 + L.split; ctx->split_cap = L.split_cap;
+    ctx->dinfo = reinterpret_cast<int*>(a0 + L.info);
+    ctx->bstride = L.stride; ctx->bpar = a0 + L.par;
+    ctx->have_theta = true;
+    const double log2pi = log(2.0 * M_PI);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        ctx->bn = (int)nb;
+        for (int64_t b = 0; b < nb; b++) {
+            const double* th = thetas + (b0 + b) * w;
+            double* row = hpar + b * (1 + GPRY_MAX_DIM);
+            for (int k = 0; k <= GPRY_MAX_DIM; k++) row[k] = 1.0;
+            row[0] = exp(th[0]);                                     // as make_kp / make_ap for one evaluation
+            for (int k = 0; k < ctx->d; k++) row[1 + k] = exp(th[1 + k]);
+            hres[b * GPRY_BRES_STRIDE + RES_INFO] = -1.0; hres[b * GPRY_BRES_STRIDE + RES_INFO + 1] = -1.0;     // "not written"
+        }
+        for (int k = 0; k < w; k++) ctx->theta[k] = thetas[b0 * w + k];      // (the launchers read the sizes, not these, in a batch)
+        HIP_TRY(ctx, hipMemcpy2DAsync(a0 + L.par, sizeof(double) * L.stride, hpar, sizeof(double) * (1 + GPRY_MAX_DIM),
+                                      sizeof(double) * (1 + GPRY_MAX_DIM), (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+        {
+            StageScope s(ctx, "lml_batch");
+            GPRY_TRY(lml_chain(ctx, want_grad, static_cast<double*>(ctx->hbres_dev)));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int64_t b = 0; b < nb; b++) {
+            const double* o = hres + b * GPRY_BRES_STRIDE;
+            if (o[RES_INFO] < 0.0) return gpry_fail(ctx, -2, "lml_batch: evaluation %lld did not deliver its status", (long long)(b0 + b));
+            const int i0 = (int)o[RES_INFO], i1 = (int)o[RES_INFO + 1];
+            const int inf = i0 != 0 ? i0 : i1;
+            if (info) info[b0 + b] = inf;
+            if (inf != 0) {   // sklearn:_gpr.py:586-589
+                lml[b0 + b] = -INFINITY;
+                if (want_grad) for (int k = 0; k < w; k++) grad[(b0 + b) * w + k] = 0.0;
+                continue;
+            }
+            lml[b0 + b] = -0.5 * o[1] - o[0] - 0.5 * (double)ctx->N * log2pi;
+            if (want_grad) for (int k = 0; k < w; k++) grad[(b0 + b) * w + k] = o[2 + k];
+        }
+    }
+    return 0;
+}
+
 __global__ void zero_upper_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t ld, int64_t n) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * n) return;
@@ -213,11 +368,9 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
     // values nobody reads); status and results come back together at the end.
     // Results and factorisation status land in the pinned, device-mapped staging buffer: the last kernels
     // of the evaluation write them there themselves (no copy-out operations behind the evaluation).
-    constexpr int RES_INFO = 2 + 1 + GPRY_MAX_DIM;      // [logdet/2, quad, grad (1 + d) ..., info0, info1]
     int rc = ensure_pinned(ctx, 4096);
     double* hres = static_cast<double*>(ctx->hpin);
     double* dres = static_cast<double*>(ctx->hpin_dev);     // the same buffer as the device sees it
-    double* dout = ctx->dvec + 2 * ctx->Np;                 // device copy: [logdet/2, quad, grad...]
     if (rc == 0) { hres[RES_INFO] = -1.0; hres[RES_INFO + 1] = -1.0; }      // "not written" marker
     // N <= 128, d <= 16: the whole evaluation in one launch of one workgroup (lml_small.hip); it leaves no factor in
     // dW / dW2 and does not touch the scaled coordinates of the prediction factor
@@ -231,23 +384,7 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
         fused = r == 0;
     }
     const bool rescaled = rc == 0 && !fused;        // build_factor scales the training coordinates for THIS theta
-    if (rescaled) rc = build_factor(ctx, ctx->dW, ctx->dW2, ctx->dW3, nullptr);
-    double* dz = ctx->dvec;                 // z = V y
-    double* da = ctx->dvec + ctx->Np;       // alpha
-    if (rc == 0 && !fused) {
-        rc = solve_alpha(ctx, ctx->dW2, ctx->dy, dz, da, ctx->Np);
-        if (rc == 0) rc = logdet_and_quad(ctx, ctx->dW, dz, ctx->Np, dout, want_grad ? nullptr : dres, RES_INFO);
-        if (rc == 0 && want_grad) {
-            {
-                StageScope s(ctx, "lauum");
-                rc = lauum_lower(ctx, ctx->dW2, ctx->dW3, ctx->Np);
-            }
-            if (rc == 0) {
-                StageScope s(ctx, "lml_traces");
-                rc = launch_lml_traces(ctx, ctx->dW3, da, dout + 2, dout, dres, RES_INFO);
-            }
-        }
-    }
+    if (rescaled) rc = lml_chain(ctx, want_grad, dres);
     memcpy(ctx->theta, saved, sizeof(saved));
     ctx->have_theta = had;
     // the scaled training coordinates belong to the prediction factor: whoever needs them next restores them
@@ -291,8 +428,9 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
 }
 
 // B objective evaluations in one call: the optimiser runs of a multi-restart fit stepped side by side (gpry/gpr.py:883-994 runs
-// them one after another).  N <= 128, d <= 16: ONE launch, one workgroup per theta (lml_small.hip) -- every theta gets the
-// arithmetic of a single gpry_lml call, hence the same bits; otherwise the thetas are evaluated one after another.
+// them one after another).  N <= 128, d <= 16: ONE launch, one workgroup per theta (lml_small.hip); up to Np = lml_batch
+// (default 2048): ONE chain of launches for all thetas (lml_batch_general) -- either way every theta gets the arithmetic of a
+// single gpry_lml call, hence the same bits; otherwise the thetas are evaluated one after another.
 int gpry_lml_batch(gpry_ctx* ctx, const double* thetas, int64_t B, int want_grad, double* lml, double* grad, int* info) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_lml_batch: ctx is NULL");
     if (B <= 0) return 0;
@@ -300,6 +438,10 @@ int gpry_lml_batch(gpry_ctx* ctx, const double* thetas, int64_t B, int want_grad
     const int w = ctx->d + 1;
     bool fused = ctx->N > 0 && ctx->opt_lml_small && ctx->opt_chol == 0 && ctx->Np == 128 && ctx->d <= 16 && B <= 256;
     for (int64_t i = 0; fused && i < B * w; i++) fused = isfinite(thetas[i]);
+    if (!fused && B >= 2 && lml_batch_usable(ctx)) {
+        const int r = lml_batch_general(ctx, thetas, B, want_grad, lml, grad, info);
+        if (r <= 0) return r;               // 1: no room for two sets, one after another below
+    }
     if (!fused) {
         for (int64_t b = 0; b < B; b++) {
             int inf = 0;

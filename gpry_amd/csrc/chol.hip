@@ -423,6 +423,13 @@ static int trtri_level_products(gpry_ctx* ctx, const double* L, double* V, doubl
     return 0;
 }
 
+// V <- 0 for every theta of a batched launch (one memset per theta otherwise)
+__global__ __launch_bounds__(256) void zero_sets_kernel(double2* __restrict__ p_, int64_t n2, int64_t bstride) {
+    double2* __restrict__ p = bset(p_, (int)blockIdx.z, bstride);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) p[i] = make_double2(0.0, 0.0);
+}
+
 // V = L^-1 by recursive doubling: [[L11,0],[L21,L22]]^-1 = [[V11,0],[-V22 L21 V11, V22]];
 // every level is two batched MFMA GEMMs.  T is an Np x Np scratch.
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np) {
@@ -436,9 +443,17 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
     // the diagonal stage clear the blocks to the right of their own (a memset is one more dependent dispatch, 5 us of
     // an evaluation that takes 200 at N = 256); above, one memset of the matrix is cheaper than their 64-row strips.
     const bool clear_in_diag = !single_wave && Np <= 1024 && ctx->opt_trtri_clear;
-    if (!clear_in_diag) HIP_TRY(ctx, hipMemsetAsync(V, 0, sizeof(double) * Np * Np, st));
+    if (!clear_in_diag && ctx->bn > 1) {
+        const int64_t n2 = Np * Np / 2;
+        int64_t nb = (n2 + 2047) / 2048;          // 8 double2 per thread
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(zero_sets_kernel, dim3((unsigned)nb, 1, (unsigned)ctx->bn), dim3(256), 0, st, reinterpret_cast<double2*>(V), n2,
+                           ctx->bstride);
+        HIP_TRY(ctx, hipGetLastError());
+    } else if (!clear_in_diag) HIP_TRY(ctx, hipMemsetAsync(V, 0, sizeof(double) * Np * Np, st));
     TrtriPlan* pl = nullptr;
     GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
+    if (single_wave && ctx->bn > 1) return gpry_fail(ctx, -1, "batched chain: the single-wave diagonal stage is not batched");
     if (single_wave) {
         hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)(Np / 64)), dim3(64), 0, st, L, V, Np, ctx->dinfo);
         HIP_TRY(ctx, hipGetLastError());
@@ -604,11 +619,42 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
     return gemm_f64_launch(ctx, g, true, false, EPI_STORE);
 }
 
+// Split-K slices (of Np x Np doubles each) that V = L^-1 followed by K^-1 = V^T V ask of gemm_split_scratch at this size:
+// what a batched evaluation reserves per theta before the first launch (its arena is never re-allocated under way).
+int factor_chain_slices(gpry_ctx* ctx, int64_t Np, int* slices) {
+    TrtriPlan* pl = nullptr;
+    GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
+    int m = 1;
+    for (size_t lev = 0; lev < pl->count.size(); lev++) {
+        if (pl->seg_t[lev] > 0 && Np <= ctx->opt_gemm_streamk) {
+            if (pl->sk_t[lev].max_slices > m) m = pl->sk_t[lev].max_slices;
+            if (pl->sk_v[lev].max_slices > m) m = pl->sk_v[lev].max_slices;
+        } else {
+            const int ns = trtri_level_nsplit(ctx, pl, lev);
+            if (ns > m) m = ns;
+        }
+    }
+    if (Np >= 512 && Np <= ctx->opt_gemm_streamk) {
+        if (pl->sk_lauum.max_slices > m) m = pl->sk_lauum.max_slices;
+    } else {
+        const int64_t tiles = (Np / 128) * (Np / 128 + 1) / 2;
+        int nsplit = 1;
+        if (ctx->opt_split_k) while (nsplit < 4 && tiles * nsplit * 2 <= 1100 && Np / (nsplit * 2) >= 256) nsplit *= 2;
+        if (ctx->opt_lauum_split > 0) nsplit = ctx->opt_lauum_split;
+        if (nsplit > m) m = nsplit;
+    }
+    *slices = m > 1 ? m : 0;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------
 // z = V y : one wave per row (row-contiguous, coalesced), fixed reduction tree.
-__global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ V, int64_t ld,
+// (batched launches, gpry_ctx::bn: V, z, part, alpha of theta blockIdx.z lie bstride doubles further on; y is shared)
+__global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ V_, int64_t ld,
                                                          const double* __restrict__ y,
-                                                         double* __restrict__ z, int64_t n) {
+                                                         double* __restrict__ z_, int64_t n, int64_t bstride) {
+    const double* __restrict__ V = bset(V_, (int)blockIdx.z, bstride);
+    double* __restrict__ z = bset(z_, (int)blockIdx.z, bstride);
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -619,10 +665,13 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
     if (lane == 0) z[row] = s;
 }
 // partial column sums of V^T z over 256-row chunks: part[chunk][col]
-__global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restrict__ V, int64_t ld,
-                                                           const double* __restrict__ z,
-                                                           double* __restrict__ part, int64_t n) {
+__global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restrict__ V_, int64_t ld,
+                                                           const double* __restrict__ z_,
+                                                           double* __restrict__ part_, int64_t n, int64_t bstride) {
     __shared__ double red[4][64];
+    const double* __restrict__ V = bset(V_, (int)blockIdx.z, bstride);
+    const double* __restrict__ z = bset(z_, (int)blockIdx.z, bstride);
+    double* __restrict__ part = bset(part_, (int)blockIdx.z, bstride);
     const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
     const int64_t col = (int64_t)blockIdx.x * 64 + c;
     const int64_t r0 = (int64_t)blockIdx.y * 256;
@@ -647,7 +696,9 @@ __global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restr
     __syncthreads();
     if (rq == 0) part[(int64_t)blockIdx.y * n + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
-__global__ void colsum_kernel(const double* __restrict__ part, int64_t n, int nchunk, double* __restrict__ out) {
+__global__ void colsum_kernel(const double* __restrict__ part_, int64_t n, int nchunk, double* __restrict__ out_, int64_t bstride) {
+    const double* __restrict__ part = bset(part_, (int)blockIdx.z, bstride);
+    double* __restrict__ out = bset(out_, (int)blockIdx.z, bstride);
     int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= n) return;
     double s = 0.0;
@@ -657,29 +708,37 @@ __global__ void colsum_kernel(const double* __restrict__ part, int64_t n, int nc
 
 int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha, int64_t Np) {
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, V, Np, y, z, Np);
+    const unsigned bn = (unsigned)ctx->bn;
+    hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((Np + 3) / 4), 1, bn), dim3(256), 0, st, V, Np, y, z, Np, ctx->bstride);
     int nchunk = (int)((Np + 255) / 256);
     int64_t need = (int64_t)nchunk * Np;
+    if (need > ctx->part_cap && ctx->bpar) return gpry_fail(ctx, -1, "batched chain: partial sums exceed the arena");
     if (need > ctx->part_cap) {
         if (ctx->dpart) dev_free(ctx, ctx->dpart);
         GPRY_TRY(dev_alloc(ctx, &ctx->dpart, need));
         ctx->part_cap = need;
     }
-    hipLaunchKernelGGL(trmv_lower_t_kernel, dim3((unsigned)(Np / 64), (unsigned)nchunk), dim3(256), 0, st,
-                       V, Np, z, ctx->dpart, Np);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, ctx->dpart, Np,
-                       nchunk, alpha);
+    hipLaunchKernelGGL(trmv_lower_t_kernel, dim3((unsigned)(Np / 64), (unsigned)nchunk, bn), dim3(256), 0, st,
+                       V, Np, z, ctx->dpart, Np, ctx->bstride);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((Np + 255) / 256), 1, bn), dim3(256), 0, st, ctx->dpart, Np,
+                       nchunk, alpha, ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
 // out[0] = sum_i log L_ii (i < n_real), out[1] = sum_i z_i^2   (single workgroup)
-__global__ __launch_bounds__(1024) void logdet_quad_kernel(const double* __restrict__ L, int64_t ld,
-                                                           const double* __restrict__ z,
-                                                           int64_t n_real, double* __restrict__ out,
-                                                           const int* __restrict__ info, double* __restrict__ host_res,
-                                                           int info_at) {
+__global__ __launch_bounds__(1024) void logdet_quad_kernel(const double* __restrict__ L_, int64_t ld,
+                                                           const double* __restrict__ z_,
+                                                           int64_t n_real, double* __restrict__ out_,
+                                                           const int* __restrict__ info_, double* __restrict__ host_res,
+                                                           int info_at, int64_t bstride) {
     __shared__ double r0[1024], r1[1024];
+    const int tb = (int)blockIdx.z;             // theta of a batched launch: its results go to their own row of host_res
+    const double* __restrict__ L = bset(L_, tb, bstride);
+    const double* __restrict__ z = bset(z_, tb, bstride);
+    double* __restrict__ out = bset(out_, tb, bstride);
+    const int* __restrict__ info = bset(info_, tb, bstride);
+    if (host_res) host_res += (int64_t)tb * GPRY_BRES_STRIDE;
     const int t = threadIdx.x;
     double a = 0.0, b = 0.0;
     for (int64_t i = t; i < n_real; i += 1024) { a += log(L[i * ld + i]); b = fma(z[i], z[i], b); }
@@ -703,8 +762,8 @@ __global__ __launch_bounds__(1024) void logdet_quad_kernel(const double* __restr
 int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np, double* out2_dev, double* host_res,
                     int info_at) {
     (void)Np;
-    hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(1024), 0, ctx->stream, L, ctx->Np, z, ctx->N, out2_dev,
-                       ctx->dinfo, host_res, info_at);
+    hipLaunchKernelGGL(logdet_quad_kernel, dim3(1, 1, (unsigned)ctx->bn), dim3(1024), 0, ctx->stream, L, ctx->Np, z, ctx->N, out2_dev,
+                       ctx->dinfo, host_res, info_at, ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -215,13 +215,16 @@ __device__ __forceinline__ void tile_store_t(double* T, v4d v, int lane) {      
 #pragma unroll
     for (int q = 0; q < 4; q++) T[r * PLD + g + 4 * q] = v[q];
 }
-__global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restrict__ L, double* __restrict__ V,
-                                                           int64_t ld, const int* info, int clear_right) {
+__global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restrict__ L_, double* __restrict__ V_,
+                                                           int64_t ld, const int* info, int clear_right, int64_t bstride) {
     __shared__ __attribute__((aligned(16))) double sL[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sV[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sVt[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sTt[64 * PLD];
-    if (*info != 0) return;
+    const int tb = (int)blockIdx.z;             // theta of a batched launch (gpry_ctx::bn)
+    if (*bset(info, tb, bstride) != 0) return;
+    const double* __restrict__ L = bset(L_, tb, bstride);
+    double* __restrict__ V = bset(V_, tb, bstride);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     if (clear_right) {      // rows of this block, columns right of it (ld = the matrix dimension): stands in for a memset of V
@@ -286,14 +289,16 @@ __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restr
     }
 }
 int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right) {
-    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)(Np / 64)), dim3(256), 0, st, L, V, Np, ctx->dinfo, clear_right ? 1 : 0);
+    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)(Np / 64), 1, (unsigned)ctx->bn), dim3(256), 0, st, L, V, Np, ctx->dinfo,
+                       clear_right ? 1 : 0, ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 // diagonal blocks blk0 .. blk0 + nblk - 1 only (pipelined factor chain, chol.hip)
 int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st) {
     const int64_t off = (int64_t)blk0 * 64 * (Np + 1);
-    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)nblk), dim3(256), 0, st, L + off, V + off, Np, ctx->dinfo, 0);
+    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)nblk, 1, (unsigned)ctx->bn), dim3(256), 0, st, L + off, V + off, Np, ctx->dinfo, 0,
+                       ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -470,6 +475,7 @@ struct PanelArgs {
     double* A; int64_t ld, j0, K0, Kfar, n_real;
     int* info; int* arrive; int target;
     unsigned long long* dbg; int dbg_block;
+    int64_t bstride;        // batched launch (gpry_ctx::bn): A, info and arrive of theta blockIdx.z lie this many doubles further on
 };
 #define PANEL_SMEM_DOUBLES (4 * 64 * PLD + 64 + 8)
 
@@ -479,10 +485,10 @@ struct PanelArgs {
 // accumulated from zero over all 128 k and then subtracted, exactly what the trailing update's SYRK tile
 // does (same MFMA sequence, same single rounding of C - acc), so the factor stays bit-identical.
 template <bool FAR>
-__device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* smem, const int bx) {
-    double* __restrict__ A = pa.A;
+__device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* smem, const int bx, const int tb) {
+    double* __restrict__ A = bset(pa.A, tb, pa.bstride);
     const int64_t ld = pa.ld, j0 = pa.j0, K0 = pa.K0, n_real = pa.n_real;
-    int* info = pa.info; int* arrive = pa.arrive; const int target = pa.target;
+    int* info = bset(pa.info, tb, pa.bstride); int* arrive = bset(pa.arrive, tb, pa.bstride); const int target = pa.target;
     unsigned long long* dbg = pa.dbg; const int dbg_block = pa.dbg_block;
     double* sD = smem;
     double* sB = sD + 64 * PLD;
@@ -939,13 +945,14 @@ __device__ __forceinline__ void syrk128x64_tile_body(double* __restrict__ A, int
 __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const TileItem* __restrict__ items, int P) {
     __shared__ __attribute__((aligned(16))) double smem[PANEL_SMEM_DOUBLES];
     const int bx = (int)blockIdx.x;
+    const int tb = (int)blockIdx.z;             // theta of a batched launch (gpry_ctx::bn)
     if (bx < P) {
-        if (pa.Kfar < pa.K0) panel_step_body<true>(pa, smem, bx);
-        else panel_step_body<false>(pa, smem, bx);
+        if (pa.Kfar < pa.K0) panel_step_body<true>(pa, smem, bx, tb);
+        else panel_step_body<false>(pa, smem, bx, tb);
     } else {
         const TileItem it = items[bx - P];
-        if (it.pair) syrk128x64_tile_body(pa.A, pa.ld, it, smem, pa.info);
-        else syrk64_tile_body(pa.A, pa.ld, it, smem, pa.info);
+        if (it.pair) syrk128x64_tile_body(bset(pa.A, tb, pa.bstride), pa.ld, it, smem, bset(pa.info, tb, pa.bstride));
+        else syrk64_tile_body(bset(pa.A, tb, pa.bstride), pa.ld, it, smem, bset(pa.info, tb, pa.bstride));
     }
 }
 
@@ -1085,9 +1092,10 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
 }
 
 int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
-    if (Np > (ctx->opt_chol_overlap_max > 0 ? ctx->opt_chol_overlap_max : 7168)) return potrf_lower_fused(ctx, A, Np);
     OverlapPlan* pl = nullptr;
-    const int prc = overlap_plan_get(ctx, Np, &pl);
+    const bool too_large = Np > (ctx->opt_chol_overlap_max > 0 ? ctx->opt_chol_overlap_max : 7168);
+    const int prc = too_large ? 1 : overlap_plan_get(ctx, Np, &pl);
+    if (prc == 1 && ctx->bn > 1) return gpry_fail(ctx, -1, "batched chain: no fused Cholesky schedule for Np = %lld", (long long)Np);
     if (prc == 1) return potrf_lower_fused(ctx, A, Np);
     if (prc) return prc;
     hipStream_t st = ctx->stream;
@@ -1103,8 +1111,8 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
             const int P = (int)((Np - j0) / 64);
             arrivals += P;
             PanelArgs pa = {A, Np, j0, K0, (K0 > 0 && s == 0) ? K0 - 128 : K0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals,
-                            dbg, ctx->opt_chol_dbg - 1};
-            hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + pl->count[l])), dim3(256), 0, st, pa,
+                            dbg, ctx->opt_chol_dbg - 1, ctx->bstride};
+            hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + pl->count[l]), 1, (unsigned)ctx->bn), dim3(256), 0, st, pa,
                                pl->d_items + pl->first[l], P);
             GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));
         }

@@ -78,6 +78,19 @@ struct gpry_ctx {
     unsigned long long lml_seq = 0;     // stamp of the last single-launch evaluation
     int opt_lml_small = 1;       // N <= 128, d <= 16: LML + gradient in one launch of one workgroup (lml_small.hip)
 
+    // Batched objective above N = 128 (gpry_lml_batch, api.hip): the B thetas of a call go through ONE chain of launches.
+    // Every kernel of the chain takes the theta index from blockIdx.z; the per-theta buffers (W, W2, W3, scaled
+    // coordinates, vectors, partial sums, split-K slices, [C, l...], status words) are the same layout repeated
+    // `bstride` doubles apart in one arena, so a kernel moves every per-theta pointer by the same number of bytes
+    // (bset below).  Outside a batched evaluation bn = 1, bstride = 0, bpar = NULL and nothing changes.
+    int bn = 1;
+    int64_t bstride = 0;
+    const double* bpar = nullptr;      // device, set 0: [C, l_1 .. l_d] as the host computes them for one evaluation
+    double* barena = nullptr; int64_t barena_cap = 0;     // doubles
+    void* hbres = nullptr; void* hbres_dev = nullptr; int64_t hbres_cap = 0;   // results of a batch (pinned, device-mapped)
+    int64_t opt_lml_batch = 2048;      // largest Np whose gpry_lml_batch runs as one chain (0: thetas one after another)
+    int64_t opt_lml_batch_mb = 16384;  // upper limit of the arena (MiB): longer batches go through in chunks
+
     double* dX = nullptr;      // N x d raw transformed training rows (row-major, ld = d)
     double* dXs = nullptr;     // Np x dpad rows scaled by 1/l (pad rows = 0)
     double* dy = nullptr;      // Np
@@ -197,6 +210,15 @@ int dev_free(gpry_ctx* ctx, void* p);
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// the buffer of theta `tb` in a batched launch (see gpry_ctx::bn): every per-theta pointer moves by tb * bstride doubles
+// (pointer arithmetic, not integer arithmetic: the result keeps the provenance of a kernel argument, i.e. global loads
+// and stores -- through an integer cast it became a flat pointer, and chol_fused_kernel went to scratch memory)
+template <typename T>
+__device__ __forceinline__ T* bset(T* p, int tb, int64_t bstride) {
+    return (T*)((char*)p + (int64_t)tb * bstride * 8);
+}
+#define GPRY_BRES_STRIDE 40     // doubles per theta in the result buffer of a batch: [logdet/2, quad, grad (1 + 32), info0, info1]
+
 // ---- GEMM (gemm_f64.hip) -----------------------------------------------------------
 enum GemmKMode {
     KM_FULL = 0,      // k in [0, K)
@@ -236,7 +258,19 @@ struct GemmArgs {
     int dma_ok;            // batched launches: 1 = every item meets gemm_dma_usable (checked by the caller)
     int skip_reduce;       // split-K: leave the slices in split_buf (the caller reduces them itself)
     int small64;           // 1: every M, N is a multiple of 64 and every K of 32: launches with few tiles may take gemm_small.hip
+    // batched objective (filled in by the launchers from the context): grid.z = bz_div * bn, theta = blockIdx.z / bz_div,
+    // A / B / C / info / split_buf of theta tb lie tb * bstride doubles behind those of theta 0
+    int bn, bz_div;
+    int64_t bstride;
 };
+// theta index and batch item of a GEMM workgroup
+__device__ __forceinline__ void gemm_block_z(const GemmArgs& g, int z, int* tb, int* item) {
+    if (g.bn > 1) { *tb = z / g.bz_div; *item = z - *tb * g.bz_div; }
+    else { *tb = 0; *item = z; }
+}
+static inline void gemm_fill_batch(const gpry_ctx* ctx, GemmArgs* g) {
+    g->bn = ctx->bn; g->bstride = ctx->bstride; g->bz_div = g->batch ? g->n_batch : 1;
+}
 // ---- stream-K launches of the DMA engine (gemm_dma.hip): the (tile, k) space of a launch is cut into segments of
 // equal length, one workgroup per segment; a segment is a list of parts (tile, share of the tile's k-range).
 struct GemmPart { int bz, ti, tj, lo, hi, slice; };     // lo / hi: slab pairs (32 k) within the tile's own k-range
@@ -309,6 +343,7 @@ int trtri_pipeline_finish(gpry_ctx* ctx);
 void trtri_pipeline_abort(gpry_ctx* ctx);   // error path: wait for the side stream, mark the chain inactive
 void trtri_pipe_free(gpry_ctx* ctx);
 int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np);
+int factor_chain_slices(gpry_ctx* ctx, int64_t Np, int* slices);   // split-K slices V = L^-1 and K^-1 = V^T V need at this size
 int solve_alpha(gpry_ctx* ctx, const double* V, const double* y, double* z, double* alpha,
                 int64_t Np);
 int logdet_and_quad(gpry_ctx* ctx, const double* L, const double* z, int64_t Np,

@@ -73,6 +73,9 @@ int ensure_pinned(gpry_ctx* ctx, int64_t bytes) {
     // mapped: the small-batch predict kernels read and write this buffer directly
     HIP_TRY(ctx, hipHostMalloc(&ctx->hpin, (size_t)bytes, hipHostMallocMapped | hipHostMallocPortable));
     HIP_TRY(ctx, hipHostGetDevicePointer(&ctx->hpin_dev, ctx->hpin, 0));
+    // the stamped units of the single-launch objective (lml_small.hip) live in this buffer: a recycled allocation must
+    // not hold words that look like a current stamp
+    memset(ctx->hpin, 0, (size_t)bytes);
     ctx->hpin_cap = bytes;
     return 0;
 }
@@ -200,9 +203,10 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
                     ctx->dsig_all, ctx->dacq_all, ctx->dKst, ctx->dpart, ctx->dkeys, ctx->dhist,
                     ctx->dcand, ctx->dsel, ctx->dU, ctx->dXkb, ctx->dkbout, ctx->pr.dXc, ctx->pr.dmask,
                     ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq, ctx->dsched, ctx->dG,
-                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit, ctx->dbord};
+                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit, ctx->dbord, ctx->barena};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
+    if (ctx->hbres) (void)hipHostFree(ctx->hbres);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (hipEvent_t ev : {ctx->ev_start, ctx->ev_built[0], ctx->ev_built[1], ctx->ev_free[0], ctx->ev_free[1]})
@@ -275,6 +279,14 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "syrk_lds")) { ctx->opt_syrk_lds = (int)value; return 0; }
     if (!strcmp(key, "predict_small")) { ctx->opt_predict_small = (int64_t)value; return 0; }
     if (!strcmp(key, "lml_small")) { ctx->opt_lml_small = (int)value; ctx->lml_cache = false; return 0; }
+    if (!strcmp(key, "lml_batch")) {
+        if (value < 0) return gpry_fail(ctx, -1, "lml_batch must be >= 0");
+        ctx->opt_lml_batch = value; return 0;
+    }
+    if (!strcmp(key, "lml_batch_mb")) {
+        if (value < 1) return gpry_fail(ctx, -1, "lml_batch_mb must be >= 1");
+        ctx->opt_lml_batch_mb = value; return 0;
+    }
     if (!strcmp(key, "lml_cache")) { ctx->opt_lml_cache = (int)value; ctx->lml_cache = false; return 0; }
     if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }
     if (!strcmp(key, "kb_variant")) { ctx->opt_kb_variant = (int)value; ctx->lml_cache = false; return 0; }
@@ -286,6 +298,15 @@ int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 6) return gpry_fail(ctx, -1, "sweep_tilemap must be in 0..6");
         ctx->opt_sweep_tilemap = (int)value; return 0;
     }
+    return gpry_fail(ctx, -1, "unknown option '%s'", key);
+}
+
+int gpry_ctx_get_option(gpry_ctx* ctx, const char* key, int64_t* value) {
+    if (!ctx || !key || !value) return gpry_fail(ctx, -1, "gpry_ctx_get_option: NULL argument");
+    if (!strcmp(key, "lml_batch")) { *value = ctx->opt_lml_batch; return 0; }
+    if (!strcmp(key, "lml_batch_mb")) { *value = ctx->opt_lml_batch_mb; return 0; }
+    if (!strcmp(key, "lml_small")) { *value = ctx->opt_lml_small; return 0; }
+    if (!strcmp(key, "timing")) { *value = ctx->opt_timing; return 0; }
     return gpry_fail(ctx, -1, "unknown option '%s'", key);
 }
 

@@ -25,7 +25,9 @@ template <bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs g) {
     constexpr int A_SZ = !AT ? KC_DOUBLES : MC_DOUBLES, B_SZ = BT ? KC_DOUBLES : MC_DOUBLES;
     __shared__ __attribute__((aligned(16))) double smem[2 * (A_SZ + B_SZ)];
-    gemm_dma_tile_body<AT, BT, EPI>(g, smem, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+    int tb, bz;
+    gemm_block_z(g, (int)blockIdx.z, &tb, &bz);
+    gemm_dma_tile_body<AT, BT, EPI>(g, smem, (int)blockIdx.x, (int)blockIdx.y, bz, nullptr, tb);
 }
 
 // can this product go through the DMA kernel?  (host side; batch items are checked by the caller
@@ -55,6 +57,8 @@ static int gd_launch_epi(gpry_ctx* ctx, const GemmArgs& g, int epi, dim3 grid) {
 // the product only (same grid as gemm_f64_launch); the caller runs the split-K reduce
 int gemm_dma_launch_product(gpry_ctx* ctx, const GemmArgs& g0, bool a_trans, bool b_trans, int epi, dim3 grid) {
     GemmArgs g = g0;
+    gemm_fill_batch(ctx, &g);
+    grid.z = (unsigned)(g.bz_div * g.bn);
     if ((g.tile_map & 15) == TM_ROWMAJOR) {
         g.tile_map = TM_BALANCED;
         const int tm = g.M / BM, tn = g.N / BN;      // batched launches: the largest item
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_parts_kernel(GemmArgs g, cons
     const int p1 = first[blockIdx.x + 1];
     for (int p = first[blockIdx.x]; p < p1; p++) {
         const GemmPart pt = parts[p];
-        gemm_dma_tile_body<AT, BT, EPI>(g, smem, 0, 0, 0, &pt);
+        gemm_dma_tile_body<AT, BT, EPI>(g, smem, 0, 0, 0, &pt, (int)blockIdx.z);      // grid.z = thetas of a batched launch
         // the body counts its own DMA pieces with s_waitcnt: nothing of this part may be in flight, and no wave may
         // still read the LDS images, when the next one starts
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -95,8 +99,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_parts_kernel(GemmArgs g, cons
 
 // C = sign * (slice 0 + slice 1 + ...) for the tiles that were computed in several parts; 8 row slices per tile
 __global__ __launch_bounds__(256) void gemm_parts_reduce_kernel(GemmArgs g, const GemmRedTile* __restrict__ tiles, double sign) {
-    if (g.info != nullptr && *g.info != 0) return;
+    const int tb = (int)blockIdx.z;
+    if (g.info != nullptr && *bset(g.info, tb, g.bstride) != 0) return;
     const GemmRedTile t = tiles[blockIdx.x];
+    const double* split_buf = bset(g.split_buf, tb, g.bstride);
+    double* Cb = bset(g.C, tb, g.bstride);
     int64_t coff = 0;
     if (g.batch != nullptr) coff = g.batch[t.bz].c_off;
     const int row0 = t.ti * BM, col0 = t.tj * BN;
@@ -106,10 +113,10 @@ __global__ __launch_bounds__(256) void gemm_parts_reduce_kernel(GemmArgs g, cons
         const int64_t off = coff + (int64_t)(row0 + rr) * g.ldc + col0 + cc;
         double2 acc = make_double2(0.0, 0.0);
         for (int sidx = 0; sidx < t.nslice; sidx++) {
-            const double2 v = *reinterpret_cast<const double2*>(g.split_buf + (int64_t)sidx * g.split_stride + off);
+            const double2 v = *reinterpret_cast<const double2*>(split_buf + (int64_t)sidx * g.split_stride + off);
             acc.x += v.x; acc.y += v.y;
         }
-        *reinterpret_cast<double2*>(g.C + off) = make_double2(sign * acc.x, sign * acc.y);
+        *reinterpret_cast<double2*>(Cb + off) = make_double2(sign * acc.x, sign * acc.y);
     }
 }
 
@@ -207,7 +214,7 @@ int gemm_parts_plan_build(gpry_ctx* ctx, int kmode, int lower_only, const std::v
 
 template <bool AT, bool BT>
 static int gd_parts_launch_epi(gpry_ctx* ctx, const GemmArgs& g, int epi, const GemmPartsPlan& pl, hipStream_t st) {
-    const dim3 grid((unsigned)pl.nwg);
+    const dim3 grid((unsigned)pl.nwg, 1, (unsigned)(g.bn > 1 ? g.bn : 1));
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL((gemm_dma_parts_kernel<AT, BT, EPI_STORE>), grid, dim3(256), 0, st, g, pl.d_parts, pl.d_first); break;
         case EPI_STORE_NEG: hipLaunchKernelGGL((gemm_dma_parts_kernel<AT, BT, EPI_STORE_NEG>), grid, dim3(256), 0, st, g, pl.d_parts, pl.d_first); break;
@@ -223,6 +230,7 @@ int gemm_dma_parts_launch(gpry_ctx* ctx, const GemmArgs& g0, bool a_trans, bool 
                           int64_t slice_stride) {
     if (pl.nwg == 0) return 0;
     GemmArgs g = g0;
+    gemm_fill_batch(ctx, &g);
     g.nsplit = 1; g.split_buf = nullptr; g.split_stride = slice_stride;
     if (pl.max_slices > 0) GPRY_TRY(gemm_split_scratch(ctx, pl.max_slices, slice_stride, &g.split_buf));
     hipStream_t st = g.stream ? g.stream : ctx->stream;
@@ -232,7 +240,7 @@ int gemm_dma_parts_launch(gpry_ctx* ctx, const GemmArgs& g0, bool a_trans, bool 
     else if (a_trans && !b_trans) rc = gd_parts_launch_epi<true, false>(ctx, g, epi, pl, st);
     else return gpry_fail(ctx, -1, "gemm parts: the TT layout is not built");
     if (rc || pl.nred == 0) return rc;
-    hipLaunchKernelGGL(gemm_parts_reduce_kernel, dim3((unsigned)pl.nred, 8), dim3(256), 0, st, g, pl.d_red,
+    hipLaunchKernelGGL(gemm_parts_reduce_kernel, dim3((unsigned)pl.nred, 8, (unsigned)(g.bn > 1 ? g.bn : 1)), dim3(256), 0, st, g, pl.d_red,
                        epi == EPI_STORE_NEG ? -1.0 : 1.0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;

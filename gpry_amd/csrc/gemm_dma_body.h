@@ -78,16 +78,19 @@ __device__ __forceinline__ void gd_mma_row(v4d (&acc)[4][4], const GdFrag& f, in
 // `part` (nullable): stream-K launch (gemm_dma_parts_kernel) -- the tile, the share of its k-range (in slab pairs,
 // relative to the tile's own range) and the slice of g.split_buf the partial product goes to (slice < 0: the whole
 // range, final epilogue straight into C) come from the part instead of from the block coordinates.
+// `tb`: theta index of a batched launch (gpry_ctx::bn; 0 otherwise), bz_: the batch item
 template <bool AT, bool BT, int EPI>
 __device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* smem, const int bx, const int by, const int bz_,
-                                                   const GemmPart* part = nullptr) {
+                                                   const GemmPart* part = nullptr, const int tb = 0) {
     const int bz = part ? part->bz : bz_;
     constexpr bool AKC = !AT, BKC = BT;
     constexpr int A_SZ = AKC ? KC_DOUBLES : MC_DOUBLES, B_SZ = BKC ? KC_DOUBLES : MC_DOUBLES;
     constexpr int BUF_SZ = A_SZ + B_SZ;
-    if (g.info != nullptr && *g.info != 0) return;
+    if (g.info != nullptr && *bset(g.info, tb, g.bstride) != 0) return;
 
-    const double* A = g.A; const double* B = g.B; double* C = g.C;
+    double* const C0 = bset(g.C, tb, g.bstride);
+    double* const split0 = bset(g.split_buf, tb, g.bstride);
+    const double* A = bset(g.A, tb, g.bstride); const double* B = bset(g.B, tb, g.bstride); double* C = C0;
     int M = g.M, N = g.N, K = g.K;
     if (g.batch != nullptr) {
         GemmBatchItem it = g.batch[bz];
@@ -146,14 +149,14 @@ __device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* sm
         kend = kbeg + part->hi * 2 * BK;
         kbeg = kbeg + part->lo * 2 * BK;
         partial = part->slice >= 0;
-        if (partial) C = g.split_buf + (int64_t)part->slice * g.split_stride + (C - g.C);
+        if (partial) C = split0 + (int64_t)part->slice * g.split_stride + (C - C0);
     } else if (g.nsplit > 1) {      // split-K over grid.y, in units of slab pairs
         const int all = (kend - kbeg) / (2 * BK);
         const int per = (all + g.nsplit - 1) / g.nsplit;
         const int lo = min(all, by * per), hi = min(all, lo + per);
         kend = kbeg + hi * 2 * BK;
         kbeg = kbeg + lo * 2 * BK;
-        C = g.split_buf + (int64_t)by * g.split_stride + (C - g.C);
+        C = split0 + (int64_t)by * g.split_stride + (C - C0);
     }
     const int nslab = (kend - kbeg) / BK;      // even; 0 only for an empty split-K share
 

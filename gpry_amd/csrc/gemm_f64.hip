@@ -92,12 +92,15 @@ __device__ __forceinline__ void store_mc(double* lds, const double (&r)[8]) {
 template <bool AT, bool BT, int EPI, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double smem[4 * TILE_DOUBLES];
-    if (g.info != nullptr && *g.info != 0) return;
+    int tb, bz;
+    gemm_block_z(g, (int)blockIdx.z, &tb, &bz);
+    if (g.info != nullptr && *bset(g.info, tb, g.bstride) != 0) return;
 
-    const double* A = g.A; const double* B = g.B; double* C = g.C;
+    double* const C0 = bset(g.C, tb, g.bstride);
+    const double* A = bset(g.A, tb, g.bstride); const double* B = bset(g.B, tb, g.bstride); double* C = C0;
     int M = g.M, N = g.N, K = g.K;
     if (g.batch != nullptr) {
-        GemmBatchItem it = g.batch[blockIdx.z];
+        GemmBatchItem it = g.batch[bz];
         A += it.a_off; B += it.b_off; C += it.c_off;
         M = it.M; N = it.N; K = it.K;
     }
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const int lo = min(all, (int)blockIdx.y * per), hi = min(all, lo + per);
         kend = min(kend, kbeg + hi * BK);
         kbeg = kbeg + lo * BK;
-        C = g.split_buf + (int64_t)blockIdx.y * g.split_stride + (C - g.C);
+        C = bset(g.split_buf, tb, g.bstride) + (int64_t)blockIdx.y * g.split_stride + (C - C0);
     }
     const int nslab = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
     // Tiles that share a V row-panel or a K* column-panel start at different slabs so that
@@ -276,12 +279,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 // C = sign * sum over the split-K slices, same tile map / batch / lower_only logic as the product
 // kernel (one workgroup per output tile, 256 threads, 16-byte accesses).
 __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(GemmArgs g, double sign) {
-    if (g.info != nullptr && *g.info != 0) return;
-    double* C = g.C;
+    int tb, bz;
+    gemm_block_z(g, (int)blockIdx.z, &tb, &bz);
+    if (g.info != nullptr && *bset(g.info, tb, g.bstride) != 0) return;
+    double* C = bset(g.C, tb, g.bstride);
+    const double* split_buf = bset(g.split_buf, tb, g.bstride);
     int M = g.M, N = g.N;
     int64_t coff = 0;
     if (g.batch != nullptr) {
-        GemmBatchItem it = g.batch[blockIdx.z];
+        GemmBatchItem it = g.batch[bz];
         coff = it.c_off; M = it.M; N = it.N;
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(GemmArgs g, doub
         const int64_t off = coff + (int64_t)row * g.ldc + col;
         double2 acc = make_double2(0.0, 0.0);
         for (int sidx = 0; sidx < g.nsplit; sidx++) {
-            const double2 v = *reinterpret_cast<const double2*>(g.split_buf + (int64_t)sidx * g.split_stride + off);
+            const double2 v = *reinterpret_cast<const double2*>(split_buf + (int64_t)sidx * g.split_stride + off);
             acc.x += v.x; acc.y += v.y;
         }
         *reinterpret_cast<double2*>(C + off) = make_double2(sign * acc.x, sign * acc.y);
@@ -322,7 +328,9 @@ static int launch_epi(gpry_ctx* ctx, const GemmArgs& g, int epi, dim3 grid) {
     return 0;
 }
 
-int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi) {
+int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g0, bool a_trans, bool b_trans, int epi) {
+    GemmArgs g = g0;
+    gemm_fill_batch(ctx, &g);
     int M = g.M, N = g.N;
     if (g.batch == nullptr && (M <= 0 || N <= 0)) return 0;
     int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -339,7 +347,7 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
     if (g.small64 && ctx->opt_gemm_small > 0 && epi != EPI_SUMSQ && g.nsplit <= 1 && (g.tile_map & 15) == TM_ROWMAJOR &&
         !(a_trans && b_trans) && !g.diag && nblk * (g.batch ? g.n_batch : 1) <= ctx->opt_gemm_small)
         return gemm64_launch(ctx, g, a_trans, b_trans, epi);
-    dim3 grid((unsigned)nblk, (unsigned)(g.nsplit > 1 ? g.nsplit : 1), g.batch ? (unsigned)g.n_batch : 1u);
+    dim3 grid((unsigned)nblk, (unsigned)(g.nsplit > 1 ? g.nsplit : 1), (unsigned)(g.bz_div * g.bn));
     if (g.nsplit > 1 && !(epi == EPI_STORE || epi == EPI_STORE_NEG))
         return gpry_fail(ctx, -1, "gemm: split-K only with the store epilogues");
     int rc;
@@ -351,7 +359,7 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
     else if (a_trans && !b_trans) rc = launch_epi<true, false>(ctx, g, epi, grid);
     else rc = launch_epi<true, true>(ctx, g, epi, grid);
     if (rc != 0 || g.nsplit <= 1 || g.skip_reduce) return rc;
-    dim3 rgrid((unsigned)nblk, 8, g.batch ? (unsigned)g.n_batch : 1u);
+    dim3 rgrid((unsigned)nblk, 8, (unsigned)(g.bz_div * g.bn));
     hipLaunchKernelGGL(gemm_split_reduce_kernel, rgrid, dim3(256), 0, g.stream ? g.stream : ctx->stream, g,
                        epi == EPI_STORE_NEG ? -1.0 : 1.0);
     HIP_TRY(ctx, hipGetLastError());
@@ -361,6 +369,8 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
 // scratch for split-K partial products: nsplit slices of `slice` doubles each
 int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf) {
     const int64_t need = (int64_t)nsplit * slice;
+    // a batched evaluation works in the arena: its slices were sized up front and are never re-allocated
+    if (need > ctx->split_cap && ctx->bpar) return gpry_fail(ctx, -1, "batched chain: split-K scratch of %lld doubles exceeds the %lld planned", (long long)need, (long long)ctx->split_cap);
     if (need > ctx->split_cap) {
         if (ctx->dsplit) GPRY_TRY(dev_free(ctx, ctx->dsplit));
         ctx->dsplit = nullptr; ctx->split_cap = 0;

@@ -47,11 +47,13 @@ __device__ __forceinline__ void s64_store_mc(double* lds, const double (&r)[8]) 
 template <bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double smem[4 * OP_DOUBLES];
-    if (g.info != nullptr && *g.info != 0) return;
-    const double* A = g.A; const double* B = g.B; double* C = g.C;
+    int tb, bz;
+    gemm_block_z(g, (int)blockIdx.z, &tb, &bz);
+    if (g.info != nullptr && *bset(g.info, tb, g.bstride) != 0) return;
+    const double* A = bset(g.A, tb, g.bstride); const double* B = bset(g.B, tb, g.bstride); double* C = bset(g.C, tb, g.bstride);
     int M = g.M, N = g.N, K = g.K;
     if (g.batch != nullptr) {
-        const GemmBatchItem it = g.batch[blockIdx.z];
+        const GemmBatchItem it = g.batch[bz];
         A += it.a_off; B += it.b_off; C += it.c_off;
         M = it.M; N = it.N; K = it.K;
     }
@@ -152,11 +154,13 @@ static int launch64(gpry_ctx* ctx, const GemmArgs& g, int epi, dim3 grid) {
 }
 
 // g.M / g.N: the largest item of a batched launch (as for gemm_f64_launch)
-int gemm64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi) {
+int gemm64_launch(gpry_ctx* ctx, const GemmArgs& g0, bool a_trans, bool b_trans, int epi) {
+    GemmArgs g = g0;
+    gemm_fill_batch(ctx, &g);
     if (g.M % SB_T || g.N % SB_T || (g.batch == nullptr && g.K % SB_K))
         return gpry_fail(ctx, -1, "gemm64: M, N must be multiples of 64 and K of 32");
     if (a_trans && b_trans) return gpry_fail(ctx, -1, "gemm64: A^T B^T is not built");
-    const dim3 grid((unsigned)((g.M / SB_T) * (g.N / SB_T)), 1, g.batch ? (unsigned)g.n_batch : 1u);
+    const dim3 grid((unsigned)((g.M / SB_T) * (g.N / SB_T)), 1, (unsigned)(g.bz_div * g.bn));
     if (!a_trans && !b_trans) return launch64<false, false>(ctx, g, epi, grid);
     if (!a_trans && b_trans) return launch64<false, true>(ctx, g, epi, grid);
     return launch64<true, false>(ctx, g, epi, grid);

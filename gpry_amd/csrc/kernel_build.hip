@@ -10,8 +10,14 @@
 #include "kern_math.h"
 
 // ------------------------------------------------------------------------------------
-__global__ void scale_train_kernel(const double* __restrict__ X, double* __restrict__ Xs,
-                                   int64_t N, int64_t Np, int d, int dpad, AffParams ap, int* info) {
+// Batched launch (gpry_ctx::bn): theta blockIdx.z scales into ITS coordinate buffer with ITS length scales (bpar: the
+// [C, l_1 .. l_d] rows the host computed, one per theta, bstride doubles apart like every per-theta buffer).
+__global__ void scale_train_kernel(const double* __restrict__ X, double* __restrict__ Xs_,
+                                   int64_t N, int64_t Np, int d, int dpad, AffParams ap, int* info_,
+                                   const double* __restrict__ bpar, int64_t bstride) {
+    const int tb = (int)blockIdx.z;
+    double* __restrict__ Xs = bset(Xs_, tb, bstride);
+    int* info = bset(info_, tb, bstride);
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // first kernel of every factorisation: it also clears the status / arrival words the panel chain starts from
     // (a memset in front of the first panel step is one more dependent dispatch)
@@ -19,15 +25,15 @@ __global__ void scale_train_kernel(const double* __restrict__ X, double* __restr
     if (idx >= Np * dpad) return;
     int64_t i = idx / dpad; int k = (int)(idx - i * dpad);
     double v = 0.0;
-    if (i < N && k < d) v = X[i * d + k] / ap.ls[k];
+    if (i < N && k < d) v = X[i * d + k] / (bpar ? bset(bpar, tb, bstride)[1 + k] : ap.ls[k]);
     Xs[idx] = v;
 }
 
 int launch_scale_train(gpry_ctx* ctx) {
     AffParams ap = make_ap(ctx, false);
     int64_t n = ctx->Np * ctx->dpad;
-    hipLaunchKernelGGL(scale_train_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       ctx->stream, ctx->dX, ctx->dXs, ctx->N, ctx->Np, ctx->d, ctx->dpad, ap, ctx->dinfo);
+    hipLaunchKernelGGL(scale_train_kernel, dim3((unsigned)((n + 255) / 256), 1, (unsigned)ctx->bn), dim3(256), 0,
+                       ctx->stream, ctx->dX, ctx->dXs, ctx->N, ctx->Np, ctx->d, ctx->dpad, ap, ctx->dinfo, ctx->bpar, ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     ctx->info_cleared = true;
     ctx->xs_foreign = false;
@@ -164,10 +170,14 @@ __global__ __launch_bounds__((TS / 4) * (TS / 4), 5) void kernel_train_kernel(
 // failed with them; the F1 goldens, 1e-13, would not have noticed).
 template <int KID, int TS, bool CHUNKED>
 __global__ __launch_bounds__((TS / 32) * (TS / 32) * 64, 6) void kernel_train_q_kernel(
-    const double* __restrict__ Xs, const double* __restrict__ noise, double* __restrict__ K,
-    int64_t ld, KernParams kp, int add_noise) {
+    const double* __restrict__ Xs_, const double* __restrict__ noise, double* __restrict__ K_,
+    int64_t ld, KernParams kp, int add_noise, const double* __restrict__ bpar, int64_t bstride) {
     constexpr int WPR = TS / 32, NT = WPR * WPR * 64;
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    // batched launch (gpry_ctx::bn): theta blockIdx.z builds its own K from its own scaled coordinates and constant
+    const double* __restrict__ Xs = bset(Xs_, (int)blockIdx.z, bstride);
+    double* __restrict__ K = bset(K_, (int)blockIdx.z, bstride);
+    if (bpar) kp.C = bset(bpar, (int)blockIdx.z, bstride)[0];
     const int dp = kp.dpad;
     double* Xi = sm;             // [dp][TS]
     double* Xj = sm + dp * TS;   // [dp][TS]
@@ -250,18 +260,20 @@ int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
         const bool chunked = ctx->opt_kb_variant == 3;
         const int64_t nbq = ctx->Np / TQ, ntq = nbq * (nbq + 1) / 2;
         const size_t smq = sizeof(double) * (size_t)(2 * ctx->dpad * TQ);
+        const dim3 gq((unsigned)ntq, 1, (unsigned)ctx->bn);
 #define KQ(KID)                                                                                               \
-    if (TQ == 64 && chunked) hipLaunchKernelGGL((kernel_train_q_kernel<KID, 64, true>), dim3((unsigned)ntq), dim3(256), smq, \
-                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise);          \
-    else if (TQ == 64) hipLaunchKernelGGL((kernel_train_q_kernel<KID, 64, false>), dim3((unsigned)ntq), dim3(256), smq,     \
-                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise);          \
-    else hipLaunchKernelGGL((kernel_train_q_kernel<KID, 32, false>), dim3((unsigned)ntq), dim3(64), smq,              \
-                            ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise)
+    if (TQ == 64 && chunked) hipLaunchKernelGGL((kernel_train_q_kernel<KID, 64, true>), gq, dim3(256), smq, \
+                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise, ctx->bpar, ctx->bstride);          \
+    else if (TQ == 64) hipLaunchKernelGGL((kernel_train_q_kernel<KID, 64, false>), gq, dim3(256), smq,     \
+                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise, ctx->bpar, ctx->bstride);          \
+    else hipLaunchKernelGGL((kernel_train_q_kernel<KID, 32, false>), gq, dim3(64), smq,              \
+                            ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise, ctx->bpar, ctx->bstride)
         DISPATCH_KID(ctx->kernel_id, KQ)
 #undef KQ
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     }
+    if (ctx->bn > 1) return gpry_fail(ctx, -1, "batched chain: kb_variant 0 is not batched");
     const int TS = ctx->opt_kb_tile == 64 ? 64 : 32;
     int64_t nb = ctx->Np / TS;
     int64_t ntile = nb * (nb + 1) / 2;
@@ -506,8 +518,15 @@ int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, 
 // part[tile][DP+1]; reduce_traces_kernel sums them in a fixed order (deterministic).
 template <int DP, int KID>
 __global__ __launch_bounds__(256) void lml_traces_kernel(
-    const double* __restrict__ Xs, const double* __restrict__ Kinv, int64_t ld,
-    const double* __restrict__ alpha, double* __restrict__ part, KernParams kp) {
+    const double* __restrict__ Xs_, const double* __restrict__ Kinv_, int64_t ld,
+    const double* __restrict__ alpha_, double* __restrict__ part_, KernParams kp,
+    const double* __restrict__ bpar, int64_t bstride) {
+    // batched launch (gpry_ctx::bn): the buffers and the constant of theta blockIdx.z
+    const double* __restrict__ Xs = bset(Xs_, (int)blockIdx.z, bstride);
+    const double* __restrict__ Kinv = bset(Kinv_, (int)blockIdx.z, bstride);
+    const double* __restrict__ alpha = bset(alpha_, (int)blockIdx.z, bstride);
+    double* __restrict__ part = bset(part_, (int)blockIdx.z, bstride);
+    if (bpar) kp.C = bset(bpar, (int)blockIdx.z, bstride)[0];
     __shared__ __attribute__((aligned(16))) double Xi[DP * 64];
     __shared__ __attribute__((aligned(16))) double Xj[DP * 64];
     __shared__ double ai[64], aj[64];
@@ -600,11 +619,17 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
 }
 
 // one workgroup per hyperparameter: strided partial sums then a fixed LDS tree
-__global__ __launch_bounds__(256) void reduce_traces_kernel(const double* __restrict__ part, int64_t ntile,
-                                                            int stride, double* __restrict__ out,
-                                                            const int* __restrict__ info, const double* __restrict__ lq,
-                                                            double* __restrict__ host_res, int info_at) {
+__global__ __launch_bounds__(256) void reduce_traces_kernel(const double* __restrict__ part_, int64_t ntile,
+                                                            int stride, double* __restrict__ out_,
+                                                            const int* __restrict__ info_, const double* __restrict__ lq_,
+                                                            double* __restrict__ host_res, int info_at, int64_t bstride) {
     __shared__ double red[256];
+    const int tb = (int)blockIdx.z;             // theta of a batched launch: its results go to their own row of host_res
+    const double* __restrict__ part = bset(part_, tb, bstride);
+    double* __restrict__ out = bset(out_, tb, bstride);
+    const int* __restrict__ info = bset(info_, tb, bstride);
+    const double* __restrict__ lq = bset(lq_, tb, bstride);
+    if (host_res) host_res += (int64_t)tb * GPRY_BRES_STRIDE;
     const int k = blockIdx.x, t = threadIdx.x;
     double s = 0.0;
     for (int64_t i = t; i < ntile; i += 256) s += part[i * stride + k];
@@ -636,21 +661,22 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha, do
     if (ctx->d > 32) return gpry_fail(ctx, -1, "d > 32 is not supported");
     int DPsel = ctx->d <= 4 ? 4 : ctx->d <= 8 ? 8 : ctx->d <= 16 ? 16 : ctx->d <= 24 ? 24 : 32;
     int64_t need = ntile * (DPsel + 1);
+    if (need > ctx->part_cap && ctx->bpar) return gpry_fail(ctx, -1, "batched chain: partial sums exceed the arena");
     if (need > ctx->part_cap) {
         if (ctx->dpart) dev_free(ctx, ctx->dpart);
         GPRY_TRY(dev_alloc(ctx, &ctx->dpart, need));
         ctx->part_cap = need;
     }
-#define LT2(DP, KID) hipLaunchKernelGGL((lml_traces_kernel<DP, KID>), dim3((unsigned)ntile), dim3(256), 0, \
-                                        ctx->stream, ctx->dXs, Kinv, ctx->Np, alpha, ctx->dpart, kp)
+#define LT2(DP, KID) hipLaunchKernelGGL((lml_traces_kernel<DP, KID>), dim3((unsigned)ntile, 1, (unsigned)ctx->bn), dim3(256), 0, \
+                                        ctx->stream, ctx->dXs, Kinv, ctx->Np, alpha, ctx->dpart, kp, ctx->bpar, ctx->bstride)
 #define LT4(KID) { if (DPsel == 4) LT2(4, KID); else if (DPsel == 8) LT2(8, KID); \
                    else if (DPsel == 16) LT2(16, KID); else if (DPsel == 24) LT2(24, KID); else LT2(32, KID); }
     DISPATCH_KID(ctx->kernel_id, LT4)
 #undef LT4
 #undef LT2
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(reduce_traces_kernel, dim3((unsigned)(ctx->d + 1)), dim3(256), 0, ctx->stream,
-                       ctx->dpart, ntile, DPsel + 1, grad_out_dev, ctx->dinfo, lq_dev, host_res, info_at);
+    hipLaunchKernelGGL(reduce_traces_kernel, dim3((unsigned)(ctx->d + 1), 1, (unsigned)ctx->bn), dim3(256), 0, ctx->stream,
+                       ctx->dpart, ntile, DPsel + 1, grad_out_dev, ctx->dinfo, lq_dev, host_res, info_at, ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

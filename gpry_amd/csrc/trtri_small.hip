@@ -13,10 +13,13 @@
 #define TS_LD 130
 #define TS_NB 8
 
-__global__ __launch_bounds__(512) void trtri_diag128_kernel(const double* __restrict__ L, double* __restrict__ V,
-                                                            int64_t ld, const int* info, int clear_right) {
+__global__ __launch_bounds__(512) void trtri_diag128_kernel(const double* __restrict__ L_, double* __restrict__ V_,
+                                                            int64_t ld, const int* info, int clear_right, int64_t bstride) {
     __shared__ __attribute__((aligned(16))) double M[TS_NP * TS_LD];
-    if (*info != 0) return;
+    const int tb = (int)blockIdx.z;             // theta of a batched launch (gpry_ctx::bn)
+    if (*bset(info, tb, bstride) != 0) return;
+    const double* __restrict__ L = bset(L_, tb, bstride);
+    double* __restrict__ V = bset(V_, tb, bstride);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * TS_NP;
     if (clear_right) {      // rows of this block, columns right of it: stands in for a memset of V (ld = the matrix dimension)
@@ -97,7 +100,8 @@ __global__ __launch_bounds__(512) void trtri_diag128_kernel(const double* __rest
 }
 
 int launch_trtri_diag128(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right) {
-    hipLaunchKernelGGL(trtri_diag128_kernel, dim3((unsigned)(Np / TS_NP)), dim3(512), 0, st, L, V, Np, ctx->dinfo, clear_right ? 1 : 0);
+    hipLaunchKernelGGL(trtri_diag128_kernel, dim3((unsigned)(Np / TS_NP), 1, (unsigned)ctx->bn), dim3(512), 0, st, L, V, Np, ctx->dinfo,
+                       clear_right ? 1 : 0, ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -15,6 +15,7 @@ There is no CPU path: without the library or without a GPU the methods raise.
 """
 import copy
 import os
+import sys
 import warnings
 from collections.abc import Mapping
 from numbers import Number
@@ -35,14 +36,37 @@ except Exception:  # pragma: no cover
     _BE = _RM = object
 
 
+# One process per GPU is announced differently by every launcher: torchrun sets WORLD_SIZE / LOCAL_RANK; the reference's
+# own parallel mode is mpi4py under mpirun / srun (gpry/mpi.py:18-28, gpry/run.py:1254-1275), which set these instead.
+_WORLD_SIZE_VARS = ("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS")
+_LOCAL_RANK_VARS = ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID")
+
+
+def multi_process_launch():
+    """True if this process is one rank of a multi-process launch (any launcher's world-size variable > 1, or an
+    initialised mpi4py world of more than one rank)."""
+    for var in _WORLD_SIZE_VARS:
+        try:
+            if int(os.environ.get(var, "1")) > 1:
+                return True
+        except ValueError:
+            pass
+    mpi = sys.modules.get("mpi4py.MPI")
+    try:
+        return mpi is not None and mpi.Is_initialized() and mpi.COMM_WORLD.Get_size() > 1
+    except Exception:
+        return False
+
+
 def default_device_index():
-    """GPU of this process: ``GPRY_HIP_DEVICE`` or ``LOCAL_RANK`` (one process per GPU), else 0.
+    """GPU of this process: ``GPRY_HIP_DEVICE`` or the launcher's local rank (``LOCAL_RANK``,
+    ``OMPI_COMM_WORLD_LOCAL_RANK``, ``MPI_LOCALRANKID``, ``SLURM_LOCALID``: one process per GPU), else 0.
 
     An index beyond the visible devices raises: two ranks silently sharing a GPU is what made the
     RCCL bootstrap fail with "invalid usage" (a communicator cannot hold one device twice).
     ``GPRY_HIP_DEVICE_WRAP=1`` restores the wrap-around for development boxes with fewer GPUs
     than ranks (no RCCL communicator can be built there)."""
-    for var in ("GPRY_HIP_DEVICE", "LOCAL_RANK"):
+    for var in ("GPRY_HIP_DEVICE",) + _LOCAL_RANK_VARS:
         if os.environ.get(var, "") != "":
             n, idx = _lib.device_count(), int(os.environ[var])
             if n > 0 and idx >= n:
@@ -73,8 +97,9 @@ def fit_context_devices(own, n_restarts, spec=None):
 
     ``spec`` (``GaussianProcessRegressor.fit_devices``): explicit list, one entry per context, repeats
     allowed.  ``None``: ``GPRY_HIP_DEVICES`` (a list of GPUs, or ``all`` / ``none``), else every visible GPU
-    unless this process is one rank of a multi-process launch (``WORLD_SIZE`` > 1: one process per GPU, the
-    ranks farm the restarts among themselves, ``gpry_amd.parallel``); ``fit_contexts()`` contexts per GPU,
+    unless this process is one rank of a multi-process launch (``multi_process_launch``: torchrun's ``WORLD_SIZE``, or
+    ``OMPI_COMM_WORLD_SIZE`` / ``PMI_SIZE`` / ``SLURM_NTASKS`` of the reference's mpirun / srun mode -- one process per
+    GPU, the ranks farm the restarts among themselves, ``gpry_amd.parallel`` / ``gpry/run.py:1254-1275``); ``fit_contexts()`` contexts per GPU,
     dealt out round-robin so that the first restarts land on distinct GPUs.  An unmodified single-process
     ``gpry.Runner`` on an 8-GPU node (``gpry/run.py:315-325``: without mpi4py there is one rank) thereby
     spreads its 10+2d restarts over all GPUs instead of running them on GPU 0."""
@@ -83,7 +108,7 @@ def fit_context_devices(own, n_restarts, spec=None):
         env = os.environ.get("GPRY_HIP_DEVICES", "").strip().lower()
         if env not in ("", "none", "1", "all"):
             devs = [int(v) for v in env.split(",")]
-        elif env in ("none", "1") or (env == "" and int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        elif env in ("none", "1") or (env == "" and multi_process_launch()):
             devs = [own]
         else:
             n = _lib.device_count()
@@ -673,12 +698,18 @@ class GaussianProcessRegressor(_RM, _BE):
         return self
 
     def _can_step_restarts_together(self):
-        """Small training sets (the single-launch objective: N <= 128, d <= 16; ``gpry_lml_batch``): the optimiser runs
-        of a fit advance together and every round is ONE launch with a workgroup per run."""
+        """Can ``gpry_lml_batch`` evaluate a round's thetas together?  N <= 128, d <= 16: ONE launch with a workgroup per
+        run (the single-launch objective); above that and up to the device's ``lml_batch`` limit (2048): ONE chain of
+        launches whose every kernel carries all runs.  Then the optimiser runs of a fit advance side by side."""
         if (self.optimizer != "fmin_l_bfgs_b" or getattr(self, "fit_lockstep", True) is False
                 or os.environ.get("GPRY_HIP_FIT_LOCKSTEP", "1") == "0"):
             return False
-        if not hasattr(self.device, "lml_batch") or self.n > 128 or self.d > 16:
+        if not hasattr(self.device, "lml_batch"):
+            return False
+        if self.n <= 128:
+            if self.d > 16:
+                return False
+        elif self.n > int(getattr(self.device, "lml_batch_max", 128)):
             return False
         from gpry_amd import lockstep
         return lockstep.available()

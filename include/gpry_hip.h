@@ -87,6 +87,9 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                            (default 16384; 0 = always the device radix select)
  *              "lml_small" = 0/1 gpry_lml of N <= 128, d <= 16 in ONE launch of one workgroup (default 1; the factor of
  *                            such an evaluation is not kept for gpry_factorize)
+ *              "lml_batch" = largest padded training-set size (multiple of 128) at which gpry_lml_batch runs all its thetas
+ *                            through ONE chain of launches (default 2048; 0 = one after another), "lml_batch_mb" = upper limit
+ *                            of the scratch arena of such a batch in MiB (default 16384; longer batches go in chunks)
  *              "predict_gates" = 0/1 gpry_predict applies the gates of gpry_set_gates itself (default 0)
  *              "predict_serve" = 0/1 mean-only gpry_predict of <= 8 points is answered by a RESIDENT kernel (no
  *                                launch per call; default 1), "serve_idle_us" = how long that kernel waits for the
@@ -98,6 +101,9 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  * The environment variable GPRY_HIP_OPTIONS="key=value,key=value" applies options to every context the process
  * creates (gpry_ctx_create fails on an unknown key or a malformed entry). */
 int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value);
+/* current value of an option (the host mirror asks for "lml_batch" to decide whether the restarts of a fit -- gpry/gpr.py:968-984,
+ * one after another there -- can be stepped side by side); unknown keys return -1 */
+int gpry_ctx_get_option(gpry_ctx* ctx, const char* key, int64_t* value);
 
 /* ---- model state ------------------------------------------------------------------ */
 /* X_train_, y_train_, alpha = noise_^2 in the TRANSFORMED space, as assembled by
@@ -145,8 +151,11 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml,
 
 /* B evaluations of the same objective in one call (thetas: B x (1 + d), lml: B, grad: B x (1 + d) or NULL, info: B or NULL,
  * each as gpry_lml).  The optimiser runs of a multi-restart fit (gpry/gpr.py:883-994, one after another there) stepped side
- * by side hand over one theta per run and round.  N <= 128, d <= 16: one launch, one workgroup per theta, every theta with
- * the arithmetic -- and the bits -- of a single gpry_lml call; otherwise the thetas are evaluated one after another. */
+ * by side hand over one theta per run and round.  N <= 128, d <= 16: one launch, one workgroup per theta; larger training
+ * sets up to option "lml_batch" padded rows (default 2048): ONE chain of launches in which every kernel (covariance build,
+ * Cholesky panel steps, V = L^-1 levels, K^-1 = V^T V, traces) carries all thetas, each with its own scratch set; either way
+ * every theta gets the arithmetic -- and the bits -- of a single gpry_lml call, and a theta whose matrix is not positive
+ * definite returns (-inf, 0, info > 0) on its own.  Beyond that size the thetas are evaluated one after another. */
 int gpry_lml_batch(gpry_ctx* ctx, const double* thetas, int64_t B, int want_grad, double* lml, double* grad, int* info);
 
 /* ---- a8-a11: posterior mean / std (gpry/gpr.py:1022-1273, 1275-1352) -------------- */

@@ -90,6 +90,8 @@ class OracleDevice:
             return float(out[0]), np.array(out[1]), int(not np.isfinite(out[0]))
         return float(out), int(not np.isfinite(out))
 
+    lml_batch_max = 2048      # the device's "lml_batch" option: largest training set whose batch is ONE chain of launches
+
     def lml_batch(self, thetas, eval_gradient=True):
         rows = [self.lml(th, eval_gradient) for th in np.atleast_2d(thetas)]
         if eval_gradient:

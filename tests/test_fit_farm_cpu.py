@@ -92,6 +92,28 @@ def test_restarts_stepped_side_by_side_select_the_sequential_optimum(monkeypatch
     np.testing.assert_array_equal(b[3], a[3])
 
 
+def test_side_by_side_gate_follows_the_size_limit_of_the_batched_chain(monkeypatch):
+    """Up to the device's ``lml_batch`` limit the restarts of a fit of more than 128 points are stepped together as well
+    (F6b: the reference's fit of 200 points), above it the thread farm / sequential loop takes over; d > 16 at N <= 128 has
+    no single-launch objective and stays sequential."""
+    g = load_golden("fit_mid")
+    p = "f6b_k3_"
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "1")
+    gpr = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=4, random_state=3)
+    gpr.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=True)
+    assert gpr.fit_stats.get("side_by_side") is True and gpr.n == 200
+    assert abs(gpr.log_marginal_likelihood_value_ - g[p + "lml_full"]) < 1e-5 * abs(float(g[p + "lml_full"]))
+    np.testing.assert_allclose(gpr.kernel_.theta, g[p + "theta_full"], rtol=1e-3, atol=1e-3)
+    assert gpr._can_step_restarts_together()
+    monkeypatch.setattr(type(gpr.device), "lml_batch_max", 128)
+    assert not gpr._can_step_restarts_together()
+    monkeypatch.setattr(type(gpr.device), "lml_batch_max", 2048)
+    monkeypatch.setattr(type(gpr), "n", property(lambda self: 100))
+    monkeypatch.setattr(type(gpr), "d", property(lambda self: 20))
+    assert not gpr._can_step_restarts_together()
+
+
 def test_fit_contexts_are_dealt_out_over_the_devices_of_the_process(monkeypatch):
     """``fit_context_devices``: own device first, GPUs round-robin (the first restarts land on distinct
     GPUs), ``GPRY_HIP_FIT_CONTEXTS`` contexts per GPU, never more contexts than restarts; one rank of a
@@ -116,6 +138,14 @@ def test_fit_contexts_are_dealt_out_over_the_devices_of_the_process(monkeypatch)
     monkeypatch.setenv("WORLD_SIZE", "8")                 # one process per GPU: the ranks farm among themselves
     assert G.fit_context_devices(6, 32) == [6, 6]
     monkeypatch.delenv("WORLD_SIZE")
+    # the reference's own parallel mode is mpi4py under mpirun / srun: no WORLD_SIZE there
+    for var in ("OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"):
+        monkeypatch.setenv(var, "8")
+        assert G.fit_context_devices(6, 32) == [6, 6]
+        monkeypatch.delenv(var)
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "5")
+    assert G.default_device_index() == 5
+    monkeypatch.delenv("OMPI_COMM_WORLD_LOCAL_RANK")
     assert G.fit_context_devices(0, 32, spec=[0, 0, 1, 1, 1]) == [0, 0, 1, 1, 1]
     monkeypatch.setattr(_lib, "device_count", lambda: 1)
     assert G.fit_context_devices(0, 32) == [0, 0]

@@ -171,6 +171,21 @@ def test_f6_fit_full_and_simple(kid, N):
     np.testing.assert_allclose(s, g[p + "std_simple"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("kid", [3, 0])
+def test_f6b_fit_of_a_few_hundred_points(kid):
+    """F6b (tools/make_goldens.py:f6b_fit_mid): the reference's 4-restart fits of 200 / 300 points -- the sizes at which the
+    device steps the restarts side by side on the batched chain (tests/test_lml_batch_gpu.py)."""
+    g = load_golden("fit_mid")
+    p = f"f6b_k{kid}_"
+    gpr = orc.OracleGPR(g[p + "bounds"], kernel_id=kid, n_restarts_optimizer=4, random_state=3)
+    gpr.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=True)
+    assert abs(gpr.log_marginal_likelihood_value_ - g[p + "lml_full"]) < 1e-5 * max(1.0, abs(float(g[p + "lml_full"])))
+    np.testing.assert_allclose(gpr.theta, g[p + "theta_full"], rtol=1e-3, atol=1e-3)
+    m, s = gpr.predict(g[p + "Xc"], return_std=True)
+    np.testing.assert_allclose(m, g[p + "mean_full"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(s, g[p + "std_full"], rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_f7_nora_multi_add(tag):
     g = load_golden("multi_add")

@@ -429,6 +429,28 @@ def f10b_batch_optimizer(out):
     out["f10b_opt_x"], out["f10b_opt_f"] = np.array([x0, x1]), np.array([float(f0), float(f1)])
 
 
+def f6b_fit_mid(out):
+    """F6b: multi-restart fits of a few hundred points -- the sizes at which the device steps the restarts side by side on
+    the batched kernel chain (gpry_lml_batch above N = 128)."""
+    from gpry.gpr import GaussianProcessRegressor
+    from gpry.preprocessing import Normalize_bounds, Normalize_y
+    for kid, N, d in ((3, 200, 3), (0, 300, 4)):
+        bounds, X, y, Xc = gauss_problem(N, d, 32, seed=650 + kid)
+        name, kw = KERNELS[kid]
+        gpr = GaussianProcessRegressor(
+            kernel={name: kw}, bounds=bounds, n_restarts_optimizer=4,
+            preprocessing_X=Normalize_bounds(bounds), preprocessing_y=Normalize_y(),
+            account_for_inf=None, random_state=3)
+        gpr.append_to_data(X, y, fit_gpr=True)
+        p = f"f6b_k{kid}_"
+        out[p + "bounds"], out[p + "X"], out[p + "y"], out[p + "Xc"] = bounds, X, y, Xc
+        out[p + "theta_full"] = gpr.kernel_.theta
+        out[p + "lml_full"] = gpr.log_marginal_likelihood_value_
+        out[p + "neval_full"] = gpr.n_eval_loglike
+        m, s = gpr.predict(Xc, return_std=True)
+        out[p + "mean_full"], out[p + "std_full"] = m, s
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not mounted; nothing to do")
@@ -439,7 +461,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     groups = {"kernels": [f1_kernels], "factor_lml": [f2_f3_factor_lml],
               "predict": [f4_predict, f5_logexp, f8_append], "fit": [f6_fit, f9_config1],
-              "multi_add": [f7_multi_add], "gradients": [f10_gradients, f10b_batch_optimizer]}
+              "multi_add": [f7_multi_add], "gradients": [f10_gradients, f10b_batch_optimizer],
+              "fit_mid": [f6b_fit_mid]}
     for name, fns in groups.items():
         out = {}
         for fn in fns:
