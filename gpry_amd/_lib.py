@@ -160,7 +160,8 @@ def make_affine(x_lo=None, x_span=None, y_mean=0.0, y_std=1.0, clip_hi=np.inf):
 
 
 class Device:
-    """One ``gpry_ctx``: the device-resident GP state of one GPU."""
+    """One ``gpry_ctx``: the device-resident GP state of one GPU.  Like the context it wraps, a ``Device`` is not
+    re-entrant: one thread at a time (distinct ``Device`` objects may be driven from distinct threads)."""
 
     applies_gates_in_predict = True     # option "predict_gates": gpry_predict ORs the gates of set_gates into the mask
 
@@ -342,7 +343,9 @@ class Device:
                 fast = self._small = (xin, out, C.c_void_p(xin.ctypes.data), C.c_void_p(out.ctypes.data))
             xin, out, pin, pout = fast
             M = len(X)
-            xin[:M] = X            # (raises on a shape mismatch; converts dtype / strides)
+            if np.ndim(X) != 2 or np.shape(X)[1] != self.d:      # (an assignment would broadcast a vector or a column)
+                raise ValueError(f"expected an (M, {self.d}) array, got shape {np.shape(X)}")
+            xin[:M] = X            # (converts dtype / strides)
             rc = self._lib.gpry_predict(self._h, pin, M, None, pout, None)
             if rc != 0:
                 self._check(rc, "gpry_predict")

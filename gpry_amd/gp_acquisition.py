@@ -88,7 +88,13 @@ class BatchOptimizer(GenericGPAcquisition):
     runs of a proposal advance side by side, the posterior evaluations of a round in one ``gpry_predict_grad_batch``
     (``lockstep``; one ``gpry_predict_point`` per step with ``lockstep=False``, the reference's one-run-after-another
     form), and each lie extends the factor by a border row (``gpry_append_rows``, O(N^2)) where the reference rebuilds
-    and refactorises the model (gpry/gp_acquisition.py:488-491 -> gpry/gpr.py:1015-1017, O(N^3))."""
+    and refactorises the model (gpry/gp_acquisition.py:488-491 -> gpry/gpr.py:1015-1017, O(N^3)).
+
+    Parity of the side-by-side form with the one-after-another loop is to the tolerance of the posterior (1e-8 of the
+    mean, 1e-9 C of the variance), not to the bit: a round of four or more points goes through the batched kernels, the
+    last runs through the one-point call, and the two sum in different orders -- a run's trajectory can therefore depend in
+    its last digits on how many other runs are still going.  (The hyper-parameter fit's side-by-side form IS bit-identical
+    to its sequential loop: ``gpry_lml_batch`` gives every theta the arithmetic of a single evaluation.)"""
 
     def __init__(self, bounds, preprocessing_X=None, verbose=1, acq_func="LogExp", proposer=None,
                  acq_optimizer="fmin_l_bfgs_b", n_restarts_optimizer="5d", n_repeats_propose=10, lockstep="auto"):
@@ -198,7 +204,8 @@ class BatchOptimizer(GenericGPAcquisition):
     def _optimize_side_by_side(self, gpr, n_runs, use_bounds, rng, proposal_X, acq_X):
         """The ``n_runs`` optimiser runs of one proposal with their posterior evaluations batched: the starting points are
         drawn run by run first (the optimiser itself draws nothing, so the generator is consumed as in the reference), then
-        the runs advance together (same routine, tolerances and stopping rules as ``fmin_l_bfgs_b``)."""
+        the runs advance together (same routine, tolerances and stopping rules as ``fmin_l_bfgs_b``; function values equal
+        to the one-after-another loop's within the posterior tolerance, see the class docstring)."""
         from gpry_amd import lockstep
         self.proposer.update(gpr)
         self.proposer.update_bounds(use_bounds)

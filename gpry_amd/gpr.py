@@ -1048,10 +1048,19 @@ class GaussianProcessRegressor(_RM, _BE):
         self._ensure_factor()
         self._push_affine()
         mask = None
-        if self.infinities_classifier is not None:
-            X_ = self.preprocessing_X.transform(X)
-            finite = self.infinities_classifier.predict(np.ascontiguousarray(X_), validate=validate)
-            mask = np.logical_not(finite).astype(np.uint8) * _lib.MASK_CLASSIFIED_INF
+        on_device = getattr(self.device, "applies_gates_in_predict", False)
+        if on_device and self.infinities_classifier is not None and self._sync_gates(ignore_trust_region=True):
+            pass        # the CURRENT classifier sits on the device (re-pushed if it was refitted since the last push)
+        else:
+            # gpry_predict ORs whatever gates the context holds into the mask: a classifier that was refitted since the
+            # last push (append_to_data) must not vote on this call
+            if on_device and self._dev_gates is not None and self._dev_gates[1]:
+                self.device.set_gates()
+                self._dev_gates = None
+            if self.infinities_classifier is not None:
+                X_ = self.preprocessing_X.transform(X)
+                finite = self.infinities_classifier.predict(np.ascontiguousarray(X_), validate=validate)
+                mask = np.logical_not(finite).astype(np.uint8) * _lib.MASK_CLASSIFIED_INF
         return self.device.predict(X, return_std=True, mask=mask)[1]
 
     # ---- Kriging-believer conditioning (used by RankedPool.cache_model) ---------------------

@@ -9,13 +9,29 @@ V = L^-1 once for all of them instead of twice per point).
 The runs ARE scipy's: this module drives the same compiled routine (``scipy.optimize._lbfgsb.setulb``, reverse
 communication) with the same workspace set-up, tolerances and stopping rules as ``scipy.optimize._lbfgsb_py._minimize_lbfgsb``
 of the scipy this was written against (1.15); given the same function values a run takes the same steps as
-``fmin_l_bfgs_b``.  That entry point is private: ``available()`` checks once per process that it exists and that a run
-through this driver reproduces ``fmin_l_bfgs_b`` bit for bit on a small bounded problem; callers fall back to the
-one-after-another form otherwise.
+``fmin_l_bfgs_b``.  That entry point is private: ``available()`` first refuses every scipy outside ``SCIPY_TESTED`` (the
+work-array sizes are hard-coded: a routine that wants larger ones must never be called), then checks once per process
+that a run through this driver reproduces ``fmin_l_bfgs_b`` bit for bit on a small bounded problem; callers fall back to
+the one-after-another form otherwise.
 """
 import numpy as np
 
 _STATE = {"checked": False, "ok": False, "why": ""}
+
+# scipy releases whose ``_lbfgsb.setulb`` has the argument list and workspace sizes used below (the C translation that
+# replaced the Fortran routine in 1.15: ``wa`` of 2mn + 5n + 11m^2 + 8m doubles, ``iwa`` of 3n, ``isave`` of 44 and
+# ``dsave`` of 29 entries, two-word ``task``).  A routine that expects larger work arrays would write past ours before
+# any self-check could notice, so other versions are refused BEFORE the first call.
+SCIPY_TESTED = ((1, 15), (1, 16))       # [first, one past the last) minor version
+
+
+def _scipy_version_ok():
+    import scipy
+    try:
+        ver = tuple(int(p) for p in scipy.__version__.split(".")[:2])
+    except ValueError:
+        return False, scipy.__version__
+    return SCIPY_TESTED[0] <= ver < SCIPY_TESTED[1], scipy.__version__
 
 
 class _Run:
@@ -105,6 +121,11 @@ def available():
     if _STATE["checked"]:
         return _STATE["ok"]
     _STATE["checked"] = True
+    ok, ver = _scipy_version_ok()
+    if not ok:
+        _STATE["why"] = (f"scipy {ver} is outside the range this driver of its private L-BFGS-B routine was tested with "
+                         f"({SCIPY_TESTED[0][0]}.{SCIPY_TESTED[0][1]} <= version < {SCIPY_TESTED[1][0]}.{SCIPY_TESTED[1][1]})")
+        return False
     try:
         import scipy.optimize
         A = np.array([[3.0, 0.4, 0.1], [0.4, 2.0, -0.3], [0.1, -0.3, 1.5]])

@@ -547,6 +547,22 @@ def test_lockstep_driver_reproduces_fmin_l_bfgs_b():
     assert batches[0] == 9 and min(batches) < 9 and sum(batches) == nfev.sum()
 
 
+def test_lockstep_driver_refuses_a_scipy_it_was_not_tested_with(monkeypatch):
+    """The driver hard-codes the work-array sizes of scipy 1.15's ``setulb``: any other release is refused before the first
+    call into the private routine (VERDICT r03 #8), and the callers run the restarts one after another."""
+    import scipy
+    from gpry_amd import lockstep
+    calls = []
+    from scipy.optimize import _lbfgsb
+    monkeypatch.setattr(_lbfgsb, "setulb", lambda *a, **k: calls.append(1))
+    for ver, ok in (("1.14.1", False), ("1.16.0", False), ("2.0.0", False), ("1.15.0rc1", True), ("weird", False)):
+        monkeypatch.setattr(scipy, "__version__", ver)
+        assert lockstep._scipy_version_ok()[0] is ok
+    monkeypatch.setattr(scipy, "__version__", "1.16.2")
+    monkeypatch.setattr(lockstep, "_STATE", {"checked": False, "ok": False, "why": ""})
+    assert not lockstep.available() and "1.16.2" in lockstep._STATE["why"] and not calls
+
+
 def test_proposers_draw_in_the_reference_order():
     from gpry_amd.proposal import UniformProposer, CentroidsProposer, PartialProposer
     import scipy.stats

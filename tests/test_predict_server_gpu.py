@@ -266,3 +266,41 @@ def test_classifier_and_trust_box_on_the_device_for_every_predict_path():
     b2 = np.array([host_g.predict(x[None, :], validate=False)[0] for x in Xc[100:400]])
     np.testing.assert_array_equal(a2, b2)
     assert not np.array_equal(np.isneginf(a2), np.isneginf(a[100:400]))
+
+
+def test_predict_std_after_a_classifier_refit_does_not_see_the_previous_gates():
+    """every context applies the gates it holds inside ``gpry_predict``; ``predict_std`` (gpry/gpr.py:1275-1352:
+    classifier-masked rows give 0, no trust-region gate) used to pass a host mask without syncing or clearing them, so that
+    between a refit of the classifier (``append_to_data``) and the next ``predict`` the PREVIOUS support vectors still voted.
+    The std of points the current classifier accepts must not be zeroed, with no ``predict`` in between."""
+    from test_host_mirror_gpu import make_gpr
+    bounds, X, y, Xc = orc.synthetic_like_goldens(150, 3, 600, seed=9)
+    y = y.copy()
+    y[X[:, 0] > 1.0] = -np.inf
+    theta = np.log(np.array([4.0, 0.3, 0.3, 0.3]))
+
+    def build(on_device):
+        gpr = make_gpr(bounds, 3, theta=theta, account_for_inf="SVM", inf_threshold="20s", trust_region_factor=1.5, random_state=1)
+        gpr.append_to_data(X, y, fit_gpr=False)
+        if not on_device:
+            gpr.device.applies_gates_in_predict = False
+            gpr.device.set_option("predict_gates", 0)
+        return gpr
+
+    dev_g, host_g = build(True), build(False)
+    s0d, s0h = dev_g.predict_std(Xc), host_g.predict_std(Xc)        # first call: nothing pushed yet
+    np.testing.assert_array_equal(s0d, s0h)
+    dev_g.predict(Xc[:300])                                           # the gates of classifier #1 now sit on the device
+    # classifier #2 accepts the half-space classifier #1 rejected (the new finite points lie at x0 > 1) and rejects x1 > 1
+    Xn = np.concatenate([Xc[Xc[:, 0] > 1.2][:30], Xc[Xc[:, 1] > 1.0][:30]])
+    yn = np.where(Xn[:, 1] > 1.0, -np.inf, -2.0)
+    for g in (dev_g, host_g):
+        g.append_to_data(Xn, yn, fit_gpr=False)
+    s1d, s1h = dev_g.predict_std(Xc), host_g.predict_std(Xc)        # no predict() in between
+    np.testing.assert_array_equal(s1d, s1h)
+    assert ((s0h == 0) != (s1h == 0)).any()                           # the two classifiers do disagree on this pool
+    # a 1-D or mis-shaped X is refused by the fast path as by the general one (ADVICE r03)
+    with pytest.raises(ValueError):
+        dev_g.device.predict(np.zeros(3))
+    with pytest.raises(ValueError):
+        dev_g.device.predict(np.zeros((3, 1)))
