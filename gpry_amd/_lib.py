@@ -99,7 +99,6 @@ SIGNATURES = {
     "gpry_microbench": (C.c_int, [_vp, C.c_int, C.c_int64, _P(C.c_double)]),
     "gpry_debug_gemm": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 9),
     "gpry_debug_logexp": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_double, _vp]),
-    "gpry_debug_read_diag": (C.c_int, [_vp, _vp, C.c_int]),
 }
 
 
@@ -512,10 +511,6 @@ class Device:
                                                 float(baseline), float(sigma_n), _ptr(acq)), "gpry_debug_logexp")
         return acq
 
-    def read_diag(self, reset=True):
-        out = np.zeros(6, dtype=np.uint64)
-        self._check(self._lib.gpry_debug_read_diag(self._h, _ptr(out), int(reset)), "gpry_debug_read_diag")
-        return out
 
     def microbench(self, kind, nbytes=0):
         v = C.c_double(0.0)

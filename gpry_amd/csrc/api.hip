@@ -63,8 +63,7 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
             gpry_ctx* c; bool armed = false;
             ~PipeGuard() { if (armed) trtri_pipeline_abort(c); }
         } guard{ctx};
-        if (ctx->opt_factor_pipeline && ctx->opt_chol == 0 && !ctx->opt_chol_lookahead &&
-            ctx->Np >= ctx->opt_factor_pipeline_min) {
+        if (ctx->opt_factor_pipeline && ctx->opt_chol == 0 && ctx->Np >= ctx->opt_factor_pipeline_min) {
             const int rc = trtri_pipeline_begin(ctx, A, V, T, ctx->Np);
             if (rc < 0) return rc;
             piped = rc == 0;
@@ -72,9 +71,7 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
         }
         {
             StageScope s(ctx, "potrf");
-            const bool overlap = ctx->opt_chol_overlap && !ctx->opt_chol_lookahead && ctx->opt_chol_outer == 0;
-            GPRY_TRY(ctx->opt_chol == 2 ? potrf_lower(ctx, A, ctx->Np)
-                                        : overlap ? potrf_lower_overlap(ctx, A, ctx->Np) : potrf_lower_fused(ctx, A, ctx->Np));
+            GPRY_TRY(ctx->opt_chol_overlap ? potrf_lower_overlap(ctx, A, ctx->Np) : potrf_lower_fused(ctx, A, ctx->Np));
         }
         {
             StageScope s(ctx, "trtri");
@@ -159,12 +156,11 @@ static int ensure_batch_buffers(gpry_ctx* ctx, int64_t arena_doubles, int64_t re
     }
     return 0;
 }
-// is the batched chain built for this context's size and options?  (the experiment switches of the single chain that the
-// batched launches do not carry fall back to one evaluation after another)
+// is the batched chain built for this context's size and options?  (the comparators -- rocSOLVER, separate trailing launches --
+// and the pipelined chain of the large sizes are not batched: one evaluation after another there)
 static bool lml_batch_usable(const gpry_ctx* ctx) {
     return ctx->N > 0 && ctx->Np > 128 && ctx->Np <= ctx->opt_lml_batch && ctx->d <= 32 && ctx->opt_chol == 0 && ctx->opt_chol_overlap &&
-           !ctx->opt_chol_lookahead && ctx->opt_chol_outer == 0 && !ctx->opt_chol_dbg && ctx->opt_kb_variant >= 1 && ctx->opt_kb_variant <= 3 &&
-           ctx->opt_trtri_diag_v1 != 1 && ctx->Np < ctx->opt_factor_pipeline_min;
+           (!ctx->opt_factor_pipeline || ctx->Np < ctx->opt_factor_pipeline_min);
 }
 static int lml_batch_general(gpry_ctx* ctx, const double* thetas, int64_t B, int want_grad, double* lml, double* grad, int* info) {
     const int w = ctx->d + 1;
@@ -600,53 +596,30 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
     const int nt = (int)(Np / 128);
     int64_t chunk = ctx->opt_sweep_chunk;
     if (chunk > round_up(M, 128)) chunk = round_up(M, 128);
-    // Optional (sweep_overlap=1; measured slower: 270 vs 258 ms per 1e6 candidates, the contraction
-    // loses more to the co-running vector work than the 14.6 ms it hides).
-    // Two panel / partial-sum buffers: while chunk c is contracted on the main stream, the
-    // panel of chunk c+1 is built on stream2.  The contraction is matrix-pipe bound with the
-    // vector ALUs idle and leaves 21 KB of LDS and 120 VGPRs per lane on every CU, which is what
-    // a cross_build workgroup needs: the two kernels share the CUs.
-    const bool overlap = ctx->opt_sweep_overlap && want_std && M > chunk;
-    const int nbuf = overlap ? 2 : 1;
-    if (nbuf * Np * chunk > ctx->kst_cap) {
+    if (Np * chunk > ctx->kst_cap) {
         if (ctx->dKst) GPRY_TRY(dev_free(ctx, ctx->dKst));
         ctx->dKst = nullptr; ctx->kst_cap = 0;
-        GPRY_TRY(dev_alloc(ctx, &ctx->dKst, nbuf * Np * chunk));
-        ctx->kst_cap = nbuf * Np * chunk;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dKst, Np * chunk));
+        ctx->kst_cap = Np * chunk;
     }
     // gpry_predict with a few hundred points: the panel comes from the small-batch kernel, which leaves
     // four mean partials per 128 training rows (kernel_build.hip: cross_build_small_kernel)
     const bool small_build = allow_split && M <= 512;
     const int nt_mean = small_build ? 4 * nt : nt;
     const int64_t part_stride = (int64_t)(nt_mean + nt) * chunk;
-    GPRY_TRY(ensure_part(ctx, nbuf * part_stride));
+    GPRY_TRY(ensure_part(ctx, part_stride));
     FinishParams fp;
     fp.C = exp(ctx->theta[0]); fp.y_mean = ctx->tf.y_mean; fp.y_std = ctx->tf.y_std;
     fp.clip_hi = ctx->tf.clip_hi; fp.zeta = zeta; fp.baseline = baseline; fp.sigma_n = sigma_n;
     fp.want_std = want_std; fp.want_acq = want_acq;
     ctx->sw_M = M;
-    if (overlap) {
-        // everything queued so far (candidate upload, factor) happens before the first panel
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_start, 0));
-    }
-    int64_t c = 0;
-    for (int64_t m0 = 0; m0 < M; m0 += chunk, c++) {
+    for (int64_t m0 = 0; m0 < M; m0 += chunk) {
         int64_t mc = (M - m0 < chunk) ? M - m0 : chunk;
         int64_t mcp = round_up(mc, 128);
-        const int b = overlap ? (int)(c & 1) : 0;
-        double* Kst = ctx->dKst + (int64_t)b * Np * chunk;
-        double* mean_part = ctx->dpart + (int64_t)b * part_stride;
+        double* Kst = ctx->dKst;
+        double* mean_part = ctx->dpart;
         double* ss_part = mean_part + (int64_t)nt_mean * chunk;
-        if (overlap) {
-            if (c >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_free[b], 0));
-            {
-                StageScope s(ctx, "cross_build", ctx->stream2);
-                GPRY_TRY(launch_cross_build(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1, ctx->stream2));
-            }
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_built[b], ctx->stream2));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[b], 0));
-        } else if (small_build) {
+        if (small_build) {
             StageScope s(ctx, "cross_build");
             GPRY_TRY(launch_cross_build_small(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
         } else {
@@ -688,11 +661,9 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
             GemmArgs g = {};
             g.A = ctx->dV; g.lda = Np; g.B = Kst; g.ldb = mcp; g.C = ss_part; g.ldc = mcp;
             g.M = (int)Np; g.N = (int)mcp; g.K = (int)Np;
-            g.kmode = KM_A_LOWER; g.lower_only = 0; g.tile_map = TM_SWEEP | (ctx->opt_sweep_tilemap << 4) | (ctx->opt_sweep_colouter << 8) | (ctx->opt_sweep_altwalk << 9); g.stagger = ctx->opt_sweep_stagger; g.extra_lds = ctx->opt_sweep_extra_lds; g.kskew = ctx->opt_sweep_kskew; g.persist = ctx->opt_sweep_persist;
-            if (ctx->opt_sweep_diag) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); g.diag = ctx->dsel + 16; }
-            if (ctx->opt_sweep_dma == 3) GPRY_TRY(sweep_gemm_dma_sp_launch(ctx, g));
-            else if (ctx->opt_sweep_dma == 2 && !ctx->opt_sweep_diag && mcp % 256 == 0) GPRY_TRY(sweep_gemm_dma256_launch(ctx, g));
-            else if (ctx->opt_sweep_dma && !ctx->opt_sweep_diag) GPRY_TRY(sweep_gemm_dma_launch(ctx, g));
+            g.kmode = KM_A_LOWER; g.lower_only = 0; g.tile_map = TM_SWEEP | (3 << 4);     // super-tiles of 8 row tiles x 8 candidate tiles
+            // LDS-DMA staging + software pipeline (sweep_gemm.hip); "gemm_dma" = 0: the register-staged engine (comparator)
+            if (ctx->opt_gemm_dma) GPRY_TRY(sweep_gemm_dma_sp_launch(ctx, g));
             else GPRY_TRY(gemm_f64_launch(ctx, g, false, false, EPI_SUMSQ));
         }
         {
@@ -702,7 +673,6 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
                                ctx->dy_all, ctx->dsig_all, ctx->dacq_all, fp);
             HIP_TRY(ctx, hipGetLastError());
         }
-        if (overlap) HIP_TRY(ctx, hipEventRecord(ctx->ev_free[b], ctx->stream));
     }
     return 0;
 }
@@ -1646,13 +1616,3 @@ extern "C" int gpry_debug_logexp(gpry_ctx* ctx, const double* mu, const double* 
     return 0;
 }
 
-extern "C" int gpry_debug_read_diag(gpry_ctx* ctx, uint64_t out[6], int reset) {
-    if (!ctx) return gpry_fail(nullptr, -1, "gpry_debug_read_diag: ctx is NULL");
-    if (!out) return gpry_fail(ctx, -1, "debug_read_diag: out is NULL");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, ctx->dsel + 16, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(ctx, hipMemset(ctx->dsel + 16, 0, 6 * sizeof(uint64_t)));
-    return 0;
-}

@@ -1,5 +1,5 @@
 // Dense FP64 factorisation kernels for gfx950 (row-major, lower triangular):
-//   potrf_lower : A = L L^T          scipy.linalg.cholesky  at gpry/gpr.py:1456
+//   potrf       : A = L L^T          scipy.linalg.cholesky  at gpry/gpr.py:1456   (chol_panel.hip)
 //   trtri_lower : V = L^-1           solve_triangular(L, I) at gpry/gpr.py:1457
 //   lauum_lower : K^-1 = V^T V       cho_solve(L, I)        at sklearn:_gpr.py:640-642
 //   solve_alpha : alpha_ = V^T (V y) cho_solve(L, y)        at gpry/gpr.py:1465
@@ -9,124 +9,6 @@
 #include "common.h"
 #include <algorithm>
 #include <dlfcn.h>
-
-// ------------------------------------------------------------------------------------
-// 64x64 diagonal block Cholesky in LDS (unblocked right-looking, 256 threads).
-__global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, int64_t ld,
-                                                       int64_t j0, int64_t n_real, int* info) {
-    __shared__ double S[64][65];
-    if (*info != 0) return;
-    const int t = threadIdx.x;
-    double* base = A + j0 * ld + j0;
-    for (int e = t; e < 64 * 64; e += 256) {
-        int i = e >> 6, j = e & 63;
-        S[i][j] = (j <= i) ? base[(int64_t)i * ld + j] : 0.0;
-    }
-    __syncthreads();
-    __shared__ int bad;
-    if (t == 0) bad = 0;
-    for (int j = 0; j < 64; j++) {
-        __syncthreads();
-        double djj = S[j][j];
-        // LAPACK dpotf2: fail on ajj <= 0 or NaN
-        if (!(djj > 0.0)) {
-            if (t == 0) { bad = 1; if (j0 + j < n_real) atomicCAS(info, 0, (int)(j0 + j + 1)); else atomicCAS(info, 0, (int)n_real); }
-            break;
-        }
-        double piv = sqrt(djj);
-        __syncthreads();
-        if (t == 0) S[j][j] = piv;
-        if (t > j && t < 64) S[t][j] = S[t][j] / piv;
-        __syncthreads();
-        // trailing update of the lower triangle: rows i>j, cols j<c<=i
-        const int rem = 63 - j;
-        for (int e = t; e < rem * rem; e += 256) {
-            int ii = e / rem, cc = e - ii * rem;
-            if (cc <= ii) {
-                int i = j + 1 + ii, c = j + 1 + cc;
-                S[i][c] = fma(-S[i][j], S[c][j], S[i][c]);
-            }
-        }
-    }
-    __syncthreads();
-    if (bad) return;
-    for (int e = t; e < 64 * 64; e += 256) {
-        int i = e >> 6, j = e & 63;
-        if (j <= i) base[(int64_t)i * ld + j] = S[i][j];
-    }
-}
-
-// Panel solve X * Lkk^T = A_panel, one lane per row (row kept in registers, Lkk broadcast
-// from LDS).  Same operation as BLAS dtrsm('R','L','T','N').
-__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ A, int64_t ld,
-                                                        int64_t j0, int64_t row_begin,
-                                                        int64_t n_rows, const int* info) {
-    __shared__ double Lk[64 * 64];
-    if (*info != 0) return;
-    const int t = threadIdx.x;
-    for (int e = t; e < 64 * 64; e += 64) {
-        int i = e >> 6, j = e & 63;
-        Lk[e] = A[(j0 + i) * ld + j0 + j];
-    }
-    __syncthreads();
-    int64_t r = (int64_t)blockIdx.x * 64 + t;
-    if (r >= n_rows) return;
-    double* rowp = A + (row_begin + r) * ld + j0;
-    double a[64];
-#pragma unroll
-    for (int c = 0; c < 64; c += 2) {
-        double2 v = *reinterpret_cast<const double2*>(rowp + c);
-        a[c] = v.x; a[c + 1] = v.y;
-    }
-#pragma unroll
-    for (int c = 0; c < 64; c++) {
-        double s = a[c];
-#pragma unroll
-        for (int c2 = 0; c2 < c; c2++) s = fma(-a[c2], Lk[c * 64 + c2], s);
-        a[c] = s / Lk[c * 64 + c];
-    }
-#pragma unroll
-    for (int c = 0; c < 64; c += 2) *reinterpret_cast<double2*>(rowp + c) = make_double2(a[c], a[c + 1]);
-}
-
-int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np) {
-    const int64_t NB = 256;
-    hipStream_t st = ctx->stream;
-    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, sizeof(int), st));
-    ctx->info_cleared = false;
-    for (int64_t K0 = 0; K0 < Np; K0 += NB) {
-        int64_t nbw = (Np - K0 < NB) ? Np - K0 : NB;
-        for (int64_t j0 = K0; j0 < K0 + nbw; j0 += 64) {
-            hipLaunchKernelGGL(potf2_64_kernel, dim3(1), dim3(256), 0, st, A, Np, j0, ctx->N, ctx->dinfo);
-            int64_t below = Np - (j0 + 64);
-            if (below <= 0) continue;
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)((below + 63) / 64)), dim3(64), 0, st,
-                               A, Np, j0, j0 + 64, below, ctx->dinfo);
-            int64_t w = K0 + nbw - (j0 + 64);
-            if (w > 0) {  // update the rest of the current outer panel (K = 64)
-                GemmArgs g = {};
-                g.A = A + (j0 + 64) * Np + j0; g.lda = Np;
-                g.B = A + (j0 + 64) * Np + j0; g.ldb = Np;   // B(k, j) = P[j][k]
-                g.C = A + (j0 + 64) * Np + (j0 + 64); g.ldc = Np;
-                g.M = (int)below; g.N = (int)w; g.K = 64;
-                g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
-                GPRY_TRY(gemm_f64_launch(ctx, g, false, true, EPI_SUB));
-            }
-        }
-        int64_t rest = Np - (K0 + nbw);
-        if (rest > 0) {  // trailing SYRK with K = nbw
-            GemmArgs g = {};
-            g.A = A + (K0 + nbw) * Np + K0; g.lda = Np;
-            g.B = g.A; g.ldb = Np;
-            g.C = A + (K0 + nbw) * Np + (K0 + nbw); g.ldc = Np;
-            g.M = (int)rest; g.N = (int)rest; g.K = (int)nbw;
-            g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
-            GPRY_TRY(gemm_f64_launch(ctx, g, false, true, EPI_SUB));
-        }
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
-}
 
 // ------------------------------------------------------------------------------------
 // Inverse of every 64x64 diagonal block: lane c solves L x = e_c by forward substitution
@@ -221,7 +103,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) slots = 2 * prop.multiProcessorCount; }
     // up to Np = 1024 the leaves are 128 x 128 blocks, inverted in LDS by one workgroup each (trtri_small.hip): the tree
     // is built over 128-row blocks and its coordinates scaled back to the 64-row units everything below works in
-    pl.leaf = (ctx->opt_trtri_diag128 && Np > 128 && Np <= 1024) ? 2 : 1;
+    pl.leaf = (Np > 128 && Np <= 1024) ? 2 : 1;
     std::vector<TriNode> nodes;
     int nlev = build_tree(0, (int)(Np / (64 * pl.leaf)), nodes);
     for (auto& nd : nodes) { nd.lo *= pl.leaf; nd.mid *= pl.leaf; nd.hi *= pl.leaf; }
@@ -289,12 +171,12 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
         std::vector<int> cps = {root.mid, nblk};
         for (auto& nd : nodes)
             if (nd.lo == root.lo && nd.hi == root.mid) cps.push_back(nd.mid);      // first quarter
-        // ... and the split points down the right spine of the tree while a node has at least `spine` blocks:
-        // by default only 3/4.  Going on to 7/8, 15/16, ... leaves less for after the last panel on paper, but the
+        // ... and the split points down the right spine of the tree while a node has at least half of all blocks,
+        // i.e. only 3/4.  Going on to 7/8, 15/16, ... leaves less for after the last panel on paper, but the
         // small phases are chains of 5-20 us launches that start one or two panel steps before the end and are
         // not finished when potrf is (exposed V = L^-1 at N = 4096: 0.49 ms with 3/4, 0.55 with 7/8, 0.62 with
         // 15/16, 0.68 down to the last block; tools/ab_factor_pipeline.py).
-        const int spine = ctx->opt_factor_pipeline_spine > 0 ? ctx->opt_factor_pipeline_spine : nblk / 2;
+        const int spine = nblk / 2;
         for (int lo = root.mid, hi = root.hi; hi - lo >= spine && hi - lo > 1;) {
             int mid = -1;
             for (auto& nd : nodes) if (nd.lo == lo && nd.hi == hi) mid = nd.mid;
@@ -371,10 +253,9 @@ static int trtri_level_nsplit(gpry_ctx* ctx, const TrtriPlan* pl, size_t lev) {
     const int tm = (pl->maxM[lev] + 127) / 128, tn = (pl->maxN[lev] + 127) / 128;
     const int64_t tiles = (int64_t)tm * tn * pl->count[lev];
     int nsplit = 1;
-    if (ctx->opt_split_k && pl->maxN[lev] >= 512) {
+    if (pl->maxN[lev] >= 512) {
         while (nsplit < 4 && tiles * nsplit * 2 <= 1024 && pl->maxN[lev] / (nsplit * 2) >= 128) nsplit *= 2;
     }
-    if (ctx->opt_trtri_split_cap > 0 && nsplit > ctx->opt_trtri_split_cap) nsplit = ctx->opt_trtri_split_cap;
     return nsplit;
 }
 
@@ -434,15 +315,15 @@ __global__ __launch_bounds__(256) void zero_sets_kernel(double2* __restrict__ p_
 // every level is two batched MFMA GEMMs.  T is an Np x Np scratch.
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np) {
     hipStream_t st = ctx->stream;
-    // 0 = auto: the four-wave kernel from Np = 256 on.  Up to Np = 128 the whole inverse IS this stage, and
+    // The four-wave kernels from Np = 256 on.  Up to Np = 128 the whole inverse IS this stage, and
     // the column-by-column substitution of the single-wave kernel is the operation order of the
     // reference's dtrsm: on the cond(K) = 5e15 matrix of BASELINE config 1 (N = 64) any other order moves
     // the posterior mean by 2..4e-5 of its range, beyond the one-ulp noise floor the golden test allows.
-    const bool single_wave = ctx->opt_trtri_diag_v1 == 1 || (ctx->opt_trtri_diag_v1 == 0 && Np <= 128);
+    const bool single_wave = Np <= 128;
     // V above its block diagonal has to be zero (the products walk whole tiles).  Up to Np = 1024 the workgroups of
-    // the diagonal stage clear the blocks to the right of their own (a memset is one more dependent dispatch, 5 us of
-    // an evaluation that takes 200 at N = 256); above, one memset of the matrix is cheaper than their 64-row strips.
-    const bool clear_in_diag = !single_wave && Np <= 1024 && ctx->opt_trtri_clear;
+    // the 128 x 128 diagonal stage clear the blocks to the right of their own (a memset is one more dependent dispatch, 5 us
+    // of an evaluation that takes 200 at N = 256); above, one memset of the matrix is cheaper than their row strips.
+    const bool clear_in_diag = !single_wave && Np <= 1024;
     if (!clear_in_diag && ctx->bn > 1) {
         const int64_t n2 = Np * Np / 2;
         int64_t nb = (n2 + 2047) / 2048;          // 8 double2 per thread
@@ -457,10 +338,10 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
     if (single_wave) {
         hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)(Np / 64)), dim3(64), 0, st, L, V, Np, ctx->dinfo);
         HIP_TRY(ctx, hipGetLastError());
-    } else if (pl->leaf == 2 && clear_in_diag) {
+    } else if (pl->leaf == 2) {         // (128 < Np <= 1024: exactly the sizes that clear in the diagonal stage)
         GPRY_TRY(launch_trtri_diag128(ctx, L, V, Np, st, true));
     } else {
-        GPRY_TRY(launch_trtri_diag(ctx, L, V, Np, st, clear_in_diag));
+        GPRY_TRY(launch_trtri_diag(ctx, L, V, Np, st));
     }
     for (size_t lev = 0; lev < pl->count.size(); lev++)
         GPRY_TRY(trtri_level_products(ctx, L, V, T, Np, trtri_level_nsplit(ctx, pl, lev), pl->aligned[lev],
@@ -607,14 +488,12 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
     // Np = 8192 (2080 tiles) it costs 5 %.
     const int64_t tiles = (Np / 128) * (Np / 128 + 1) / 2;
     int nsplit = 1;
-    if (ctx->opt_split_k) while (nsplit < 4 && tiles * nsplit * 2 <= 1100 && Np / (nsplit * 2) >= 256) nsplit *= 2;
-    if (ctx->opt_lauum_split > 0) nsplit = ctx->opt_lauum_split;
+    while (nsplit < 4 && tiles * nsplit * 2 <= 1100 && Np / (nsplit * 2) >= 256) nsplit *= 2;
     if (nsplit > 1) {
         double* sbuf = nullptr;
         GPRY_TRY(gemm_split_scratch(ctx, nsplit, Np * Np, &sbuf));
         g.nsplit = nsplit; g.split_buf = sbuf; g.split_stride = Np * Np;
     }
-    g.extra_lds = ctx->opt_lauum_lds;
     g.small64 = 1;          // Np is a multiple of 128
     return gemm_f64_launch(ctx, g, true, false, EPI_STORE);
 }
@@ -639,8 +518,7 @@ int factor_chain_slices(gpry_ctx* ctx, int64_t Np, int* slices) {
     } else {
         const int64_t tiles = (Np / 128) * (Np / 128 + 1) / 2;
         int nsplit = 1;
-        if (ctx->opt_split_k) while (nsplit < 4 && tiles * nsplit * 2 <= 1100 && Np / (nsplit * 2) >= 256) nsplit *= 2;
-        if (ctx->opt_lauum_split > 0) nsplit = ctx->opt_lauum_split;
+        while (nsplit < 4 && tiles * nsplit * 2 <= 1100 && Np / (nsplit * 2) >= 256) nsplit *= 2;
         if (nsplit > m) m = nsplit;
     }
     *slices = m > 1 ? m : 0;

@@ -216,7 +216,7 @@ __device__ __forceinline__ void tile_store_t(double* T, v4d v, int lane) {      
     for (int q = 0; q < 4; q++) T[r * PLD + g + 4 * q] = v[q];
 }
 __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restrict__ L_, double* __restrict__ V_,
-                                                           int64_t ld, const int* info, int clear_right, int64_t bstride) {
+                                                           int64_t ld, const int* info, int64_t bstride) {
     __shared__ __attribute__((aligned(16))) double sL[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sV[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sVt[64 * PLD];
@@ -227,14 +227,6 @@ __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restr
     double* __restrict__ V = bset(V_, tb, bstride);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
-    if (clear_right) {      // rows of this block, columns right of it (ld = the matrix dimension): stands in for a memset of V
-        const int64_t ncol = ld - (b0 + 64);
-        const double2 zero2 = make_double2(0.0, 0.0);
-        for (int64_t e = t; e < 64 * (ncol >> 1); e += 256) {
-            const int64_t i = e / (ncol >> 1), j2 = e - i * (ncol >> 1);
-            *reinterpret_cast<double2*>(V + (b0 + i) * ld + b0 + 64 + 2 * j2) = zero2;
-        }
-    }
     for (int e = t; e < 64 * 64; e += 256) {
         const int i = e >> 6, j = e & 63;
         sL[i * PLD + j] = (j <= i) ? L[(b0 + i) * ld + b0 + j] : 0.0;
@@ -288,193 +280,30 @@ __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restr
         V[(b0 + i) * ld + b0 + j] = sV[i * PLD + j];
     }
 }
-int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right) {
+int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st) {
     hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)(Np / 64), 1, (unsigned)ctx->bn), dim3(256), 0, st, L, V, Np, ctx->dinfo,
-                       clear_right ? 1 : 0, ctx->bstride);
+                       ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 // diagonal blocks blk0 .. blk0 + nblk - 1 only (pipelined factor chain, chol.hip)
 int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st) {
     const int64_t off = (int64_t)blk0 * 64 * (Np + 1);
-    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)nblk, 1, (unsigned)ctx->bn), dim3(256), 0, st, L + off, V + off, Np, ctx->dinfo, 0,
+    hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)nblk, 1, (unsigned)ctx->bn), dim3(256), 0, st, L + off, V + off, Np, ctx->dinfo,
                        ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
+// One panel step of the factorisation (the body of the fused launch below).
 // `arrive` / `target`: the diagonal workgroup overwrites D with its factor in place, while every
 // other workgroup of the launch reads D.  Workgroups count in on `arrive` once their loads have
 // landed, and the diagonal workgroup stores only when all of them have (target = arrivals
 // expected up to and including this launch).  Without this the result depends on all workgroups
 // starting before the first one finishes -- not true when another stream shares the GPU.
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int64_t ld, int64_t j0,
-                                                         int64_t K0, int64_t n_real, int* info,
-                                                         int* arrive, int target,
-                                                         unsigned long long* dbg, int dbg_block) {
-    __shared__ __attribute__((aligned(16))) double sD[64 * PLD];
-    __shared__ __attribute__((aligned(16))) double sB[64 * PLD];
-    __shared__ __attribute__((aligned(16))) double sPt[64 * PLD];
-    __shared__ __attribute__((aligned(16))) double sPo[64 * PLD];
-    __shared__ double sRd[64];
-    __shared__ int s_bad;
-    __shared__ int s_flag[8];
-    if (*info != 0) return;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const bool is_diag = blockIdx.x == 0;
-    // optional section stamps of one workgroup (dbg != NULL): loads, update, factor, solve, store
-    const bool stamp = dbg != nullptr && (int)blockIdx.x == dbg_block && t == 0;
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-    if (stamp) ts[0] = __builtin_amdgcn_s_memtime();
-    const int64_t R = j0 + 64 * (int64_t)blockIdx.x;
-    const int kprev = (int)(j0 - K0);          // columns of the outer block already factorised: 0, 64, 128, ...
-    if (t == 0) s_bad = 0;
-    {
-        // all four blocks unconditionally (the diagonal workgroup has R == j0 and the first step of an
-        // outer block K0 == j0: those loads repeat D and land in buffers nobody reads): with the loads
-        // behind branches the 3 x 128-byte register sets went through scratch memory
-        double2 rD[8], rB[8], rPt[8], rPo[8];
-        load_block_issue(A + j0 * ld + j0, ld, t, rD);
-        load_block_issue(A + R * ld + j0, ld, t, rB);
-        load_block_issue(A + j0 * ld + K0, ld, t, rPt);
-        load_block_issue(A + R * ld + K0, ld, t, rPo);
-        load_block_commit(sD, t, rD);
-        load_block_commit(sB, t, rB);
-        load_block_commit(sPt, t, rPt);
-        load_block_commit(sPo, t, rPo);
-    }
-    __syncthreads();
-    if (stamp) ts[1] = __builtin_amdgcn_s_memtime();
-    // ---- left-looking update with the previous columns of the outer block, 64 at a time (the first
-    // chunk came in with the loads above; an outer block of 256 columns has up to three)
-    for (int c0 = 0; c0 < kprev; c0 += 64) {
-        if (c0) {
-            __syncthreads();                       // everybody is done with the previous chunk
-            double2 rPt[8], rPo[8];
-            load_block_issue(A + j0 * ld + K0 + c0, ld, t, rPt);
-            if (!is_diag) load_block_issue(A + R * ld + K0 + c0, ld, t, rPo);
-            load_block_commit(sPt, t, rPt);
-            if (!is_diag) load_block_commit(sPo, t, rPo);
-            __syncthreads();
-        }
-        // D: only the ten 16x16 tiles on and below the diagonal are ever read (the factor works on the
-        // lower triangle); they are dealt round-robin to the waves (3, 3, 2, 2) instead of a full row each
-#pragma unroll 1
-        for (int tl = w; tl < 10; tl += 4) {
-            const int rw = tl < 1 ? 0 : tl < 3 ? 1 : tl < 6 ? 2 : 3;
-            const int n = tl - rw * (rw + 1) / 2;
-            double* T = sD + (rw * 16) * PLD + n * 16;
-            v4d acc = tile_load(T, lane);
-            acc = mfma_nt16<true>(acc, sPt + (rw * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
-            tile_store(T, acc, lane);
-        }
-        if (!is_diag) {
-#pragma unroll
-            for (int n = 0; n < 4; n++) {
-                double* U = sB + (w * 16) * PLD + n * 16;
-                v4d acb = tile_load(U, lane);
-                acb = mfma_nt16<true>(acb, sPo + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
-                tile_store(U, acb, lane);
-            }
-        }
-    }
-    if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (stamp) ts[2] = __builtin_amdgcn_s_memtime();
-    // ---- Cholesky of the 64x64 diagonal block, blocked by 16, as a dataflow between the four waves
-    // (wave w owns block row w) instead of three workgroup barriers per block column:
-    //   for cb < w:  wait chol(cb);  T(w,cb): D[w][cb] <- D[w][cb] L[cb][cb]^-T;  publish;
-    //                for cc in cb+1..w: (cc < w: wait T(cc,cb))  D[w][cc] -= D[w][cb] D[cc][cb]^T
-    //   chol(w); publish;  then (w < 3, off-diagonal workgroups) the own-row solve of column block w.
-    // Wave cb+1 starts chol(cb+1) as soon as ITS row is done, while the rows below still work on block
-    // column cb: the chain is 4 chol16 + 3 (solve + one tile update) = ~35k cycles instead of 44k.
-    // Same operations on every tile in the same order as the barrier version: bit-identical factors.
-    // Flags are LDS words written by lane 0 after a wave fence (LDS requests of a wave retire in order).
-    if (w == 0 && lane < 8) s_flag[lane] = 0;      // [0]: blocks factored, [1 + w]: columns solved by wave w, [5]: own-row blocks solved
-    __syncthreads();
-    {
-        for (int cb = 0; cb < w; cb++) {
-            while (__hip_atomic_load(&s_flag[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(1);
-            trsm16_rows(sD + (w * 16) * PLD + cb * 16, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
-            wave_fence();
-            if (lane == 0) __hip_atomic_store(&s_flag[1 + w], cb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (int cc = cb + 1; cc <= w; cc++) {
-                if (cc < w)
-                    while (__hip_atomic_load(&s_flag[1 + cc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(1);
-                double* T = sD + (w * 16) * PLD + cc * 16;
-                v4d acc = tile_load(T, lane);
-                acc = mfma_nt16<true>(acc, sD + (w * 16) * PLD + cb * 16, sD + (cc * 16) * PLD + cb * 16, 16, lane);
-                tile_store(T, acc, lane);
-            }
-            wave_fence();
-        }
-        // a failed pivot (not positive definite) still publishes: nobody may wait forever; the first
-        // failing column wins (the chol16 calls are ordered by the chain itself)
-        const int bad = chol16_wave(sD + (w * 16) * PLD + w * 16, sRd + w * 16, lane);
-        if (bad && lane == 0 && s_bad == 0) s_bad = w * 16 + bad;
-        wave_fence();
-        if (lane == 0) __hip_atomic_store(&s_flag[0], w + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!is_diag && w < 3) {
-            // this wave has nothing left to do in the factor: it solves the workgroup's own rows against
-            // its block column (needs the own-row blocks 0..w-1, solved by the waves before it)
-            while (__hip_atomic_load(&s_flag[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < w) __builtin_amdgcn_s_sleep(1);
-            solve_block_cols(sB, sD, sRd, w, lane);
-            if (lane == 0) __hip_atomic_store(&s_flag[5], w + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    __syncthreads();
-    if (s_bad) {
-        if (is_diag && t == 0) {
-            int64_t col = j0 + s_bad;                       // 1-based failing column
-            atomicCAS(info, 0, (int)(col <= n_real ? col : n_real));
-        }
-        return;
-    }
-    if (stamp) ts[3] = __builtin_amdgcn_s_memtime();
-    if (is_diag) {
-        if (t == 0)
-            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
-                __builtin_amdgcn_s_sleep(8);
-        __syncthreads();
-        if (stamp) ts[4] = __builtin_amdgcn_s_memtime();
-        store_block(A + j0 * ld + j0, ld, sD, t, true);
-        if (stamp) {
-            ts[5] = __builtin_amdgcn_s_memtime();
-            for (int i = 0; i < 5; i++) atomicAdd(&dbg[i], ts[i + 1] - ts[i]);
-            atomicAdd(&dbg[5], 1ull);
-        }
-        return;
-    }
-    // ---- X = B Lkk^-T: the column blocks 0..2 were solved inside the factor loop (by the waves
-    // idling there); the last one is done here, wave w on its own 16-row strip
-    {
-        const int cb = 3;
-        double* T = sB + (w * 16) * PLD + cb * 16;
-        v4d acc = tile_load(T, lane);
-        acc = mfma_nt16<true>(acc, sB + (w * 16) * PLD, sD + (cb * 16) * PLD, cb * 16, lane);
-        tile_store(T, acc, lane);
-        wave_fence();
-        trsm16_rows(T, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
-        wave_fence();
-    }
-    __syncthreads();
-    if (stamp) ts[4] = __builtin_amdgcn_s_memtime();
-    store_block(A + R * ld + j0, ld, sB, t, false);
-    if (stamp) {
-        ts[5] = __builtin_amdgcn_s_memtime();
-        for (int i = 0; i < 5; i++) atomicAdd(&dbg[i], ts[i + 1] - ts[i]);
-        atomicAdd(&dbg[5], 1ull);
-    }
-}
-
-// The same panel step as a device function (static LDS handed in), used by the fused launch below.  Kept
-// as a second copy on purpose: routed through this function the stand-alone kernel above went from 176
-// VGPRs without scratch to 198 VGPRs + 528 B of scratch per lane, and it is the reference schedule
-// (chol_overlap = 0) that the fused one is compared with bit for bit.
 struct PanelArgs {
     double* A; int64_t ld, j0, K0, Kfar, n_real;
     int* info; int* arrive; int target;
-    unsigned long long* dbg; int dbg_block;
     int64_t bstride;        // batched launch (gpry_ctx::bn): A, info and arrive of theta blockIdx.z lie this many doubles further on
 };
 #define PANEL_SMEM_DOUBLES (4 * 64 * PLD + 64 + 8)
@@ -489,7 +318,6 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     double* __restrict__ A = bset(pa.A, tb, pa.bstride);
     const int64_t ld = pa.ld, j0 = pa.j0, K0 = pa.K0, n_real = pa.n_real;
     int* info = bset(pa.info, tb, pa.bstride); int* arrive = bset(pa.arrive, tb, pa.bstride); const int target = pa.target;
-    unsigned long long* dbg = pa.dbg; const int dbg_block = pa.dbg_block;
     double* sD = smem;
     double* sB = sD + 64 * PLD;
     double* sPt = sB + 64 * PLD;
@@ -501,10 +329,6 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     if (*info != 0) return;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const bool is_diag = bx == 0;
-    // optional section stamps of one workgroup (dbg != NULL): loads, update, factor, solve, store
-    const bool stamp = dbg != nullptr && bx == dbg_block && t == 0;
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-    if (stamp) ts[0] = __builtin_amdgcn_s_memtime();
     const int64_t R = j0 + 64 * (int64_t)bx;
     const int64_t Kfirst = FAR ? pa.Kfar : K0;     // the chunk that comes in with the first loads
     const int kprev = (int)(j0 - K0);          // columns of the outer block already factorised: 0, 64, 128, ...
@@ -524,7 +348,6 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
         load_block_commit(sPo, t, rPo);
     }
     __syncthreads();
-    if (stamp) ts[1] = __builtin_amdgcn_s_memtime();
     // ---- left-looking update with the previous columns of the outer block, 64 at a time (the first
     // chunk came in with the loads above; an outer block of 256 columns has up to three)
     if (FAR) {
@@ -616,7 +439,6 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     }
     if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (stamp) ts[2] = __builtin_amdgcn_s_memtime();
     // ---- Cholesky of the 64x64 diagonal block, blocked by 16, as a dataflow between the four waves
     // (wave w owns block row w) instead of three workgroup barriers per block column:
     //   for cb < w:  wait chol(cb);  T(w,cb): D[w][cb] <- D[w][cb] L[cb][cb]^-T;  publish;
@@ -666,19 +488,12 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
         }
         return;
     }
-    if (stamp) ts[3] = __builtin_amdgcn_s_memtime();
     if (is_diag) {
         if (t == 0)
             while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
                 __builtin_amdgcn_s_sleep(8);
         __syncthreads();
-        if (stamp) ts[4] = __builtin_amdgcn_s_memtime();
         store_block(A + j0 * ld + j0, ld, sD, t, true);
-        if (stamp) {
-            ts[5] = __builtin_amdgcn_s_memtime();
-            for (int i = 0; i < 5; i++) atomicAdd(&dbg[i], ts[i + 1] - ts[i]);
-            atomicAdd(&dbg[5], 1ull);
-        }
         return;
     }
     // ---- X = B Lkk^-T: the column blocks 0..2 were solved inside the factor loop (by the waves
@@ -694,92 +509,7 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
         wave_fence();
     }
     __syncthreads();
-    if (stamp) ts[4] = __builtin_amdgcn_s_memtime();
     store_block(A + R * ld + j0, ld, sB, t, false);
-    if (stamp) {
-        ts[5] = __builtin_amdgcn_s_memtime();
-        for (int i = 0; i < 5; i++) atomicAdd(&dbg[i], ts[i + 1] - ts[i]);
-        atomicAdd(&dbg[5], 1ull);
-    }
-}
-
-// A = L L^T in place (lower; the strict upper triangle is left untouched).  Outer blocks of
-// 128 columns: two fused panel steps, then one MFMA SYRK (K = 128) on the trailing matrix.
-// Trailing update C -= P P^T (lower tiles only) of the rows/cols [r0, Np) x [c0, c0 + nc) with the
-// 128-column panel P = A[:, K0:K0+128].
-static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int64_t r0, int64_t c0,
-                           int64_t nc, hipStream_t st, int kdepth = 128) {
-    if (r0 >= Np || nc <= 0) return 0;
-    GemmArgs g = {};
-    g.A = A + r0 * Np + K0; g.lda = Np;
-    g.B = A + c0 * Np + K0; g.ldb = Np;
-    g.C = A + r0 * Np + c0; g.ldc = Np;
-    g.M = (int)(Np - r0); g.N = (int)nc; g.K = kdepth;
-    g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo; g.stream = st;
-    g.extra_lds = ctx->opt_syrk_lds;
-    return gemm_f64_launch(ctx, g, false, true, EPI_SUB);
-}
-
-int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
-    hipStream_t st = ctx->stream;
-    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
-    ctx->info_cleared = false;
-    int arrivals = 0;
-    // Look-ahead: after panel k only the next panel's 128 columns of the trailing matrix are
-    // updated on the main stream; the rest of the update runs on stream2 underneath panel k+1
-    // (the panel chain is latency-bound and leaves the machine empty).  Every element still
-    // receives its rank-128 updates in the same order from the same kernel: bit-identical.
-    // Outer block: the trailing matrix is read and written once per outer block, and a trailing update
-    // costs >= 40 us however small it is, so wider blocks halve both; the panel steps pay for it with
-    // up to three extra 64-column chunks in their left-looking update.  With the DMA-pipelined
-    // trailing update (36 us for a lone tile) the crossover is at Np ~ 6144 (tools/prof_factor.py N d reps ab:
-    // 128 / 256 columns: 1.16 / 1.23 ms at 2048, 2.61 / 2.71 at 4096, 4.80 / 4.80 at 6144, 8.12 / 7.84 at
-    // 8192); the look-ahead schedule keeps 128.
-    const bool la = ctx->opt_chol_lookahead && ctx->stream2 != nullptr && Np > 512;
-    const int64_t OB = la ? 128 : (ctx->opt_chol_outer > 0 ? ctx->opt_chol_outer : (Np > 6144 ? 256 : 128));
-    bool rest_pending = false;
-    if (la) {
-        const size_t need = 2 * (size_t)(Np / 128);
-        while (ctx->ev_pool.size() < need) {
-            hipEvent_t ev;
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            ctx->ev_pool.push_back(ev);
-        }
-    }
-    int step = 0;
-    hipEvent_t ev_rest_prev = nullptr;
-    for (int64_t K0 = 0; K0 < Np; K0 += OB, step++) {
-        const int64_t ob = (Np - K0 < OB) ? Np - K0 : OB;
-        for (int64_t j0 = K0; j0 < K0 + ob; j0 += 64) {
-            unsigned nblk = (unsigned)((Np - j0) / 64);
-            arrivals += (int)nblk;
-            unsigned long long* dbg = nullptr;
-            if (ctx->opt_chol_dbg) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); dbg = ctx->dsel + 16; }
-            hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), 0, st, A, Np, j0, K0, ctx->N, ctx->dinfo,
-                               ctx->dinfo + 2, arrivals, dbg, ctx->opt_chol_dbg - 1);
-            GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));
-        }
-        const int64_t r0 = K0 + ob;
-        if (r0 >= Np) break;
-        if (!la) {
-            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0, r0, Np - r0, st, (int)ob));
-            continue;
-        }
-        hipEvent_t ev_panel = ctx->ev_pool[2 * step], ev_rest = ctx->ev_pool[2 * step + 1];
-        HIP_TRY(ctx, hipEventRecord(ev_panel, st));                            // panel k done
-        if (rest_pending) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_rest_prev, 0));      // rest(k-1) done
-        GPRY_TRY(trailing_update(ctx, A, Np, K0, r0, r0, 128, st));            // next panel's columns
-        if (r0 + 128 < Np) {
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ev_panel, 0));
-            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0 + 128, r0 + 128, Np - r0 - 128, ctx->stream2));
-            HIP_TRY(ctx, hipEventRecord(ev_rest, ctx->stream2));
-            ev_rest_prev = ev_rest;
-            rest_pending = true;
-        }
-    }
-    if (rest_pending) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_rest_prev, 0));
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -790,7 +520,7 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
 // trailing launches: bit-identical.  Small on purpose: ~10 us, shorter than a panel step, so that tiles
 // riding in a panel launch never set its length (a lone 128 x 128 x 128 tile takes 32-36 us).
 #define S64 130
-struct TileItem { int64_t a_off, b_off, c_off; int32_t n, pair; };   // n consecutive panels (128 columns apart) in one visit; pair: 128 rows
+struct TileItem { int64_t a_off, b_off, c_off; int32_t n, pad; };    // n consecutive panels (128 columns apart) in one visit
 __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
                                                  const int* info) {
     if (*info != 0) return;
@@ -862,82 +592,6 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
             for (int q = 0; q < 4; q++) cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16] = val[mi][ni][q];
 }
 
-// The same for TWO row blocks at once (128 x 64 outputs; option chol_pair, OFF by default): one B image serves
-// both, the read-modify-write and the workgroup's fixed costs are paid once per two tiles.  Costed at +36 % tile
-// throughput per CU; measured 9-11 % SLOWER at N = 4096 ... 8192 (tools/ab_chol_caps.py): the half-wave DMA
-// pieces and the two extra barriers per panel cost more than the shared image saves.  Kept as the A/B switch.  The operands do not fit LDS at full depth (128 x 130 + 64 x 130 doubles),
-// so a panel goes through in two k-halves of 64 (row stride 66), accumulated in ascending k as before:
-// bit-identical to two 64 x 64 visits.  DMA: a 64-k row segment is 512 B = half a wave instruction (lanes 0-31).
-#define S66 66
-__device__ __forceinline__ void syrk128x64_tile_body(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
-                                                     const int* info) {
-    if (*info != 0) return;
-    double* sA = smem;                    // 128 rows x 66
-    double* sB = smem + 128 * S66;        // 64 rows x 66
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
-    double* cbase = A + it.c_off + (int64_t)(wr * 64 + g) * ld + wc * 32 + r;
-    double val[4][2][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) val[mi][ni][q] = cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16];
-#pragma unroll 1
-    for (int u = 0; u < it.n; u++) {
-        v4d acc[4][2];
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++) acc[mi][ni] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int h = 0; h < 2; h++) {
-            const double* Ag = A + it.a_off + (int64_t)u * 128 + h * 64;
-            const double* Bg = A + it.b_off + (int64_t)u * 128 + h * 64;
-            if (u | h) __syncthreads();            // everybody has read the previous images
-            if (lane < 32) {
-#pragma unroll
-                for (int i = 0; i < 32; i++) {      // wave w: rows w*32 .. w*32+31 of A
-                    const int row = w * 32 + i;
-                    gd_dma16(Ag + (int64_t)row * ld + 2 * lane, sA + row * S66);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; i++) {      // rows w*16 .. w*16+15 of B
-                    const int row = w * 16 + i;
-                    gd_dma16(Bg + (int64_t)row * ld + 2 * lane, sB + row * S66);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const double* pa = sA + (wr * 64 + r) * S66 + g;
-            const double* pb = sB + (wc * 32 + r) * S66 + g;
-#pragma unroll 2
-            for (int k0 = 0; k0 < 64; k0 += 4) {
-                const double b0 = pb[k0], b1 = pb[16 * S66 + k0];
-#pragma unroll
-                for (int mi = 0; mi < 4; mi++) {
-                    const double a = pa[mi * 16 * S66 + k0];
-                    acc[mi][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[mi][0], 0, 0, 0);
-                    acc[mi][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[mi][1], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) val[mi][ni][q] = val[mi][ni][q] - acc[mi][ni][q];
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16] = val[mi][ni][q];
-}
-
 // Fused step: the first P workgroups are the panel step, the others each take one 64 x 64 tile of an
 // EARLIER panel's trailing update.  The panel chain is one workgroup's latency and leaves most of the GPU
 // idle; the tiles fill it.  In-order launches on one stream: no cross-stream events, and a panel workgroup
@@ -950,10 +604,49 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
         if (pa.Kfar < pa.K0) panel_step_body<true>(pa, smem, bx, tb);
         else panel_step_body<false>(pa, smem, bx, tb);
     } else {
-        const TileItem it = items[bx - P];
-        if (it.pair) syrk128x64_tile_body(bset(pa.A, tb, pa.bstride), pa.ld, it, smem, bset(pa.info, tb, pa.bstride));
-        else syrk64_tile_body(bset(pa.A, tb, pa.bstride), pa.ld, it, smem, bset(pa.info, tb, pa.bstride));
+        syrk64_tile_body(bset(pa.A, tb, pa.bstride), pa.ld, items[bx - P], smem, bset(pa.info, tb, pa.bstride));
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Schedule with separate trailing launches: A = L L^T in place (lower; the strict upper triangle is left untouched), outer
+// blocks of OB columns = OB / 64 panel steps, then one MFMA SYRK (K = OB) on the trailing matrix.  This is the production
+// path above Np = 7168 (the riding 64 x 64 tiles of the fused schedule below are a latency device, not a throughput one)
+// with OB = 256, and with OB = 128 the comparator of the fused schedule ("chol_overlap" = 0: bit-identical factors).
+// Outer block: the trailing matrix is read and written once per outer block, and a trailing update costs >= 40 us however
+// small it is, so wider blocks halve both; the panel steps pay for it with up to three extra 64-column chunks in their
+// left-looking update (crossover at Np ~ 6144: 128 / 256 columns 4.80 / 4.80 ms there, 8.12 / 7.84 at 8192).
+static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int64_t r0, int kdepth) {
+    if (r0 >= Np) return 0;
+    GemmArgs g = {};
+    g.A = A + r0 * Np + K0; g.lda = Np;
+    g.B = A + r0 * Np + K0; g.ldb = Np;
+    g.C = A + r0 * Np + r0; g.ldc = Np;
+    g.M = (int)(Np - r0); g.N = (int)(Np - r0); g.K = kdepth;
+    g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
+    return gemm_f64_launch(ctx, g, false, true, EPI_SUB);
+}
+
+int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
+    if (ctx->bn > 1) return gpry_fail(ctx, -1, "batched chain: the schedule with separate trailing launches is not batched");
+    hipStream_t st = ctx->stream;
+    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
+    ctx->info_cleared = false;
+    int arrivals = 0;
+    const int64_t OB = Np > 7168 ? 256 : 128;
+    for (int64_t K0 = 0; K0 < Np; K0 += OB) {
+        const int64_t ob = (Np - K0 < OB) ? Np - K0 : OB;
+        for (int64_t j0 = K0; j0 < K0 + ob; j0 += 64) {
+            const int P = (int)((Np - j0) / 64);
+            arrivals += P;
+            PanelArgs pa = {A, Np, j0, K0, K0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals, 0};
+            hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)P), dim3(256), 0, st, pa, (const TileItem*)nullptr, P);
+            GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));
+        }
+        GPRY_TRY(trailing_update(ctx, A, Np, K0, K0 + ob, (int)ob));
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -966,8 +659,8 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
 //     that works on the first 64 columns;
 //   * everything older (p <= bc-2) rides in any launch after panel p and before block bc, most urgent
 //     first (slack = launches left - updates left), two / one rounds of the CUs the panel step leaves free
-//     (chol_caps); a tile far from its deadline waits until two panels are pending and applies both in one
-//     visit (chol_multi), C staying in registers in between.
+//     (first / second launch of a block); a tile far from its deadline waits until two panels are pending and
+//     applies both in one visit, C staying in registers in between.
 // The plan depends on Np only and is cached on the device.  Every element receives the same updates in
 // the same order with the same arithmetic as in potrf_lower_fused with chol_outer = 128: bit-identical
 // factors (tools/ab_chol_overlap.py, tests).  Above Np = 7168 the tiles no longer fit under the panel chain
@@ -998,21 +691,20 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
     std::vector<TileItem> items;
     struct Cand { int slack, c, r, p, n; };
     std::vector<Cand> cand;
-    auto item = [&](int r, int c, int p, int n, int pair) {
+    auto item = [&](int r, int c, int p, int n) {
         TileItem it;
-        it.a_off = (int64_t)r * 64 * Np + (int64_t)p * 128;      // 64 (pair: 128) rows from tile row r, the 128 columns of panel p
+        it.a_off = (int64_t)r * 64 * Np + (int64_t)p * 128;      // 64 rows from tile row r, the 128 columns of panel p
         it.b_off = (int64_t)c * 64 * Np + (int64_t)p * 128;
         it.c_off = (int64_t)r * 64 * Np + (int64_t)c * 64;
-        it.n = n; it.pair = pair;
+        it.n = n; it.pad = 0;
         return it;
     };
-    const bool pairing = ctx->opt_chol_pair != 0;
-    std::vector<int> cidx((size_t)n64 * n64, -1);        // (r, c) -> position in `cand` of this launch
-    const int multi = ctx->opt_chol_multi;       // panels per visit of a lagging tile (1: one visit per update)
+    const int multi = 2;                         // panels per visit of a lagging tile
+    const int rounds_first = 2, rounds_second = 1;       // tile rounds (of the CUs the panel step leaves free) per launch of a block
     for (int l = 0; l < nl; l++) {
         const int b = l / 2;
         const int P = (int)((Np - ((int64_t)b * 128 + 64 * (l & 1))) / 64);
-        const int rounds = (l & 1) ? (ctx->opt_chol_caps & 15) : ((ctx->opt_chol_caps >> 4) & 15);
+        const int rounds = (l & 1) ? rounds_second : rounds_first;
         const int cap = rounds * (ncu > P ? ncu - P : 0);
         cand.clear();
         // columns not yet factored: c >= 2b (+1 in the block's second launch: its first 64 columns are done)
@@ -1039,35 +731,12 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
         });
         pl.first.push_back((int)items.size());
         int n_taken = 0;
-        for (size_t i = 0; i < cand.size(); i++) cidx[(size_t)cand[i].r * n64 + cand[i].c] = (int)i;
-        std::vector<char> used(cand.size(), 0);
-        for (size_t i = 0; i < cand.size(); i++) {
-            if (used[i]) continue;
-            const Cand& q = cand[i];
+        for (const Cand& q : cand) {
             if (n_taken >= cap && q.slack > 1) continue;          // not urgent and the launch is full
-            // the row block below, same column, same pending panels: one 128 x 64 visit for both
-            int partner = -1;
-            if (pairing && q.r + 1 < n64) {
-                const int j = cidx[(size_t)(q.r + 1) * n64 + q.c];
-                if (j >= 0 && !used[j] && cand[j].p == q.p && cand[j].n == q.n) partner = j;
-            }
-            if (partner < 0 && pairing && q.r - 1 >= q.c) {
-                const int j = cidx[(size_t)(q.r - 1) * n64 + q.c];
-                if (j >= 0 && !used[j] && cand[j].p == q.p && cand[j].n == q.n) partner = j;
-            }
-            used[i] = 1;
-            int r0 = q.r;
-            if (partner >= 0) {
-                used[partner] = 1;
-                const Cand& q2 = cand[partner];
-                r0 = q.r < q2.r ? q.r : q2.r;
-                done[(size_t)q2.r * n64 + q2.c] = q2.p + q2.n; last[(size_t)q2.r * n64 + q2.c] = l;
-            }
-            items.push_back(item(r0, q.c, q.p, q.n, partner >= 0 ? 1 : 0));
+            items.push_back(item(q.r, q.c, q.p, q.n));
             done[(size_t)q.r * n64 + q.c] = q.p + q.n; last[(size_t)q.r * n64 + q.c] = l;
             n_taken++;
         }
-        for (size_t i = 0; i < cand.size(); i++) cidx[(size_t)cand[i].r * n64 + cand[i].c] = -1;
         pl.count.push_back(n_taken);
         // what the NEXT launch's panel step reads must be complete now
         const int cnext = (l & 1) ? 2 * (b + 1) : 2 * b + 1;     // the 64-column strip factored next
@@ -1102,8 +771,6 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
     ctx->info_cleared = false;
     int arrivals = 0;
-    unsigned long long* dbg = nullptr;
-    if (ctx->opt_chol_dbg) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); dbg = ctx->dsel + 16; }
     int l = 0;
     for (int64_t K0 = 0; K0 < Np; K0 += 128) {
         for (int s = 0; s < 2; s++, l++) {
@@ -1111,7 +778,7 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
             const int P = (int)((Np - j0) / 64);
             arrivals += P;
             PanelArgs pa = {A, Np, j0, K0, (K0 > 0 && s == 0) ? K0 - 128 : K0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals,
-                            dbg, ctx->opt_chol_dbg - 1, ctx->bstride};
+                            ctx->bstride};
             hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + pl->count[l]), 1, (unsigned)ctx->bn), dim3(256), 0, st, pa,
                                pl->d_items + pl->first[l], P);
             GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));

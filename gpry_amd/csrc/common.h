@@ -25,8 +25,7 @@ struct StageTimer {
 struct gpry_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;          // cross-kernel panels of the sweep are built here (overlap)
-    hipEvent_t ev_start = nullptr, ev_built[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    hipStream_t stream2 = nullptr;          // V = L^-1 phases of the pipelined factor chain run here, underneath potrf
     std::vector<hipEvent_t> ev_pool;        // one pair per Cholesky look-ahead step (never re-recorded within a call)
     char err[1024] = {0};
 
@@ -34,34 +33,12 @@ struct gpry_ctx {
     int opt_chol = 0;
     int64_t opt_sweep_chunk = 32768;
     int opt_timing = 0;          // per-stage HIP-event timers: off until gpry_timing_reset (or "timing" = 1) asks for them
-    int opt_sweep_colouter = 0;  // 1: super-tiles ordered candidate super-column outermost
     bool xs_foreign = false;     // dXs holds coordinates scaled for an LML evaluation's theta, not the prediction factor's (ensure_pred_xs)
     bool info_cleared = false;   // dinfo[0..3] were zeroed by launch_scale_train and nothing has touched them since
-    int opt_trtri_clear = 1;     // 1: up to Np = 1024 the diagonal stage of V = L^-1 clears V above the block diagonal itself (0: memset)
-    int opt_trtri_diag128 = 1;   // 1 (default): up to Np = 1024 the diagonal stage of V = L^-1 works on 128 x 128 blocks
     int opt_gemm_small = 32;     // launches of at most this many 128 x 128 tiles run with 64 x 64 tiles (0: never)
-    int opt_sweep_altwalk = 1;   // 1 (default): super-tiles of an XCD alternate the direction of their k walk (sweep_dma=3, grid launch)
-    int opt_sweep_tilemap = 3;   // log2 of V row-tiles per 64-tile super-tile
-    int opt_sweep_stagger = 0;
-    int opt_sweep_extra_lds = 0;
-    int opt_sweep_diag = 0;
-    int opt_sweep_dma = 3;       // 3: LDS-DMA + explicit software pipeline (default); 1: LDS-DMA; 2: 128x256 ring; 0: register-staged
-    int opt_kb_tile = 64;        // kernel-build tile size (32 or 64; 64 measured faster)
-    int opt_kb_variant = 1;      // 1 (default): register-mirrored 64 x 64 tiles; 0: round-2 kernel (LDS transpose); 2: 32 x 32 single-wave
-                                 // tiles; 3: distances per row pair (measured at N = 4096: 37.2 / 41.5 / 49.2 / 41.0 us back to back, tools/ab_kernel_build.py)
-    int opt_sweep_kskew = 0;
-    int opt_sweep_overlap = 0;   // 1: build the panel of chunk c+1 on a second stream while chunk c is contracted (measured: slower, the co-running cross_build costs the contraction +10 %)
-    int opt_sweep_persist = 0;   // 1: persistent workgroups + per-XCD tile tickets (sweep_dma=3 only)
     int64_t opt_predict_small = 2048;  // mean-only gpry_predict of at most this many points: one fused launch
-    int opt_chol_outer = 0;      // outer block of the fused Cholesky (0: automatic, else 128 / 256 / ...)
-    int opt_chol_dbg = 0;        // k > 0: section stamps of workgroup k-1 of every panel step (read_diag)
     int opt_chol_overlap = 1;    // 1: trailing-update tiles ride in the panel launches (potrf_lower_overlap)
     int64_t opt_chol_overlap_max = 0;   // largest Np for that schedule (0: 7168; measured: -10 % at 6144, -1 % at 7168, +3 % at 8192)
-    int opt_chol_pair = 0;              // 1: two row blocks of a column in one 128 x 64 visit (measured 9-11 % SLOWER: off)
-    int opt_chol_multi = 2;             // panels a lagging trailing tile applies per visit
-    int opt_chol_caps = 0x21;           // tile rounds per launch: high nibble = first step of a block, low = second
-    int opt_chol_lookahead = 0;  // 1: trailing update of the next panel's columns first, the rest on stream2
-                                 // (bit-identical; 4.50 vs 4.14 ms at N=4096: cross-stream events cost more than the overlap saves)
 
     // training set (transformed space)
     int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
@@ -103,7 +80,6 @@ struct gpry_ctx {
     double* dalpha_ = nullptr; // Np
     double* dvec = nullptr;    // small vectors / reductions (8 * Np + 4096 doubles)
     int* dinfo = nullptr;      // device status word(s)
-    int* dsched = nullptr;     // tile ticket counters of the persistent sweep GEMM (8 used)
     double* dparams = nullptr; // device copy of [C, 1/l..., lo..., span...] etc.
 
     // gates evaluated on the device inside gpry_sweep_logexp (gpry_set_gates)
@@ -129,13 +105,7 @@ struct gpry_ctx {
     int64_t g_cap = 0;
     double* dsplit = nullptr;  // split-K partial products of the factor GEMMs
     int64_t split_cap = 0;
-    int opt_split_k = 1;       // split-K for launches with fewer tiles than slots (trtri top levels, lauum)
     int opt_predict_split = 1; // split-K contraction for predict / sweeps of a few thousand points (one chunk)
-    int opt_syrk_lds = 0;         // extra dynamic LDS of the trailing update (32768: one workgroup per CU)
-    int opt_lauum_lds = 0;        // extra dynamic LDS of K^-1 = V^T V (32768: one workgroup per CU)
-    int opt_trtri_diag_v1 = 0;    // 0 auto, 1: single-wave inverse of the 64x64 diagonal blocks, 2: four-wave kernel
-    int opt_trtri_split_cap = 0;  // > 0: upper limit of the split-K factor of the V = L^-1 levels (A/B)
-    int opt_lauum_split = 0;      // > 0: force the split-K factor of K^-1 = V^T V (A/B)
     int opt_gemm_dma = 1;         // 128-aligned factor-chain products through gemm_dma_kernel
     double* dpart = nullptr;   // partial sums (sumsq per i-tile, mean per j-chunk)
     int64_t part_cap = 0;
@@ -158,7 +128,6 @@ struct gpry_ctx {
 
     void* trtri_plan = nullptr;
     void* trtri_pipe = nullptr;   // state of a pipelined factor chain in flight (chol.hip)
-    int opt_factor_pipeline_spine = 0;    // > 0: checkpoints down the right spine of the tree while a node has >= this many blocks (0: half of all)
     int64_t opt_gemm_streamk = 5632;   // up to this Np the V = L^-1 levels >= 512 and K^-1 = V^T V are stream-K launches
                                        // (gemm_dma.hip; a gain up to 5120, neutral at 6144, a loss at 8192); 0 = off
     int64_t opt_topk_host = 16384;    // pools up to this size are selected on the host (gpry_sweep_topk)
@@ -246,12 +215,6 @@ struct GemmArgs {
     const GemmBatchItem* batch;  // nullable; grid.z = n_batch
     int n_batch;
     const int* info;       // nullable: if *info != 0 the kernel exits immediately
-    int stagger;           // >0: odd wave-slot workgroups sleep stagger*32*64 cycles first
-    int extra_lds;         // bytes of unused dynamic LDS (occupancy experiments)
-    int kskew;             // >0: rotate the slab order of tile (ti,tj) by ((ti+tj)&7)*kskew slabs
-    unsigned long long* diag;  // non-null: run the stamped diagnostic build, sums land here
-    int* sched;            // persistent sweep kernel: one ticket counter per XCD
-    int persist;           // sweep_gemm_dma_sp: resident workgroups pulling tiles from g.sched
     hipStream_t stream;    // null: ctx->stream
     int nsplit;            // > 1: split-K over grid.y into split_buf (store epilogues only), then reduced
     double* split_buf; int64_t split_stride;
@@ -294,7 +257,7 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
 int gemm64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
 int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
 // gemm_dma.hip: LDS-DMA staged, software-pipelined variant for 128-aligned products (NN, NT, TN)
-int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right = false);   // chol_panel.hip
+int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st);   // chol_panel.hip
 // re-scales the training coordinates for the prediction factor if the last LML evaluation left its own in dXs
 int ensure_pred_xs(gpry_ctx* ctx);   // kernel_build.hip
 int launch_point_full(gpry_ctx* ctx, const double* x, int want_kinv, double* kstar, double* G, double* u, double* part,
@@ -303,9 +266,7 @@ int launch_trtri_diag128(gpry_ctx* ctx, const double* L, double* V, int64_t Np, 
 int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st);
 bool gemm_dma_usable(const GemmArgs& g, int M, int N, int K);
 int gemm_dma_launch_product(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi, dim3 grid);
-int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g);   // sweep_gemm.hip (LDS-DMA staging)
-int sweep_gemm_dma256_launch(gpry_ctx* ctx, const GemmArgs& g);  // 128x256 tile, 8 waves, 3-stage ring
-int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g);  // variant 1 + explicit software pipeline
+int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g);  // sweep_gemm.hip: LDS-DMA staging + explicit software pipeline
 
 // ---- kernel_build.hip --------------------------------------------------------------
 int upload_params(gpry_ctx* ctx, const double* theta);
@@ -332,8 +293,7 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
 // host_res (nullable, mapped host memory): [logdet/2, quad, grad...] and dinfo[0..1] as doubles at info_at, status last
 
 // ---- chol.hip ----------------------------------------------------------------------
-int potrf_lower(gpry_ctx* ctx, double* A, int64_t Np);             // info -> ctx->dinfo (unfused v1)
-int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // fused panel steps, trailing update as its own launches
+int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // panel steps, trailing update as its own launches (Np > 7168; comparator)
 int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);     // panel step + previous trailing tiles in ONE launch (default)
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
 // V = L^-1 queued phase by phase underneath potrf (chol.hip); begin returns 1 when the size is not cut

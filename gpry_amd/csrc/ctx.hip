@@ -158,9 +158,6 @@ int gpry_ctx_create(int device, gpry_ctx** out) {
     if (e != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipStreamCreate: %s", hipGetErrorString(e)); }
     e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipStreamCreate: %s", hipGetErrorString(e)); }
-    hipEvent_t* evs[] = {&ctx->ev_start, &ctx->ev_built[0], &ctx->ev_built[1], &ctx->ev_free[0], &ctx->ev_free[1]};
-    for (hipEvent_t* ev : evs)
-        if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipEventCreate"); }
     if (hipMalloc((void**)&ctx->dinfo, 16 * sizeof(int)) != hipSuccess) { delete ctx; return gpry_fail(nullptr, -2, "hipMalloc info"); }
     (void)hipMemset(ctx->dinfo, 0, 16 * sizeof(int));
     // GPRY_HIP_OPTIONS="key=value,key=value": options for every context of the process (A/B runs of
@@ -202,15 +199,13 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
                     ctx->dalpha_, ctx->dvec, ctx->dinfo, ctx->dparams, ctx->dXc, ctx->dmask, ctx->dy_all,
                     ctx->dsig_all, ctx->dacq_all, ctx->dKst, ctx->dpart, ctx->dkeys, ctx->dhist,
                     ctx->dcand, ctx->dsel, ctx->dU, ctx->dXkb, ctx->dkbout, ctx->pr.dXc, ctx->pr.dmask,
-                    ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq, ctx->dsched, ctx->dG,
+                    ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq, ctx->dG,
                     ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit, ctx->dbord, ctx->barena};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->hbres) (void)hipHostFree(ctx->hbres);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    for (hipEvent_t ev : {ctx->ev_start, ctx->ev_built[0], ctx->ev_built[1], ctx->ev_free[0], ctx->ev_free[1]})
-        if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     delete ctx;
     return 0;
@@ -224,90 +219,64 @@ int gpry_ctx_sync(gpry_ctx* ctx) {
     return 0;
 }
 
+// ---- options: ONE table (include/gpry_hip.h documents every key) -------------------------------------------------
+namespace {
+struct OptionSpec {
+    const char* key;
+    int64_t lo, hi;                         // accepted range
+    int64_t (*get)(const gpry_ctx*);
+    void (*set)(gpry_ctx*, int64_t);
+};
+#define OPT_INT(KEY, FIELD, LO, HI, AFTER)                                                         \
+    {KEY, LO, HI, [](const gpry_ctx* c) -> int64_t { return (int64_t)c->FIELD; },                  \
+     [](gpry_ctx* c, int64_t v) { c->FIELD = (decltype(c->FIELD))v; AFTER; }}
+const int64_t BIG = (int64_t)1 << 40;
+const OptionSpec OPTIONS[] = {
+    OPT_INT("timing", opt_timing, 0, 1, (void)0),
+    OPT_INT("chol", opt_chol, 0, 1, c->lml_cache = false),
+    OPT_INT("chol_overlap", opt_chol_overlap, 0, 1, (void)0),
+    OPT_INT("chol_overlap_max", opt_chol_overlap_max, 0, BIG, (void)0),
+    OPT_INT("factor_pipeline", opt_factor_pipeline, 0, 1, (void)0),
+    OPT_INT("factor_pipeline_min", opt_factor_pipeline_min, 0, BIG, (void)0),
+    OPT_INT("gemm_dma", opt_gemm_dma, 0, 1, (void)0),
+    OPT_INT("gemm_streamk", opt_gemm_streamk, 0, BIG, trtri_plan_free(c)),       // the plan holds the stream-K parts
+    OPT_INT("gemm_small", opt_gemm_small, 0, BIG, c->lml_cache = false),
+    OPT_INT("sweep_chunk", opt_sweep_chunk, 128, BIG, c->opt_sweep_chunk = round_up(c->opt_sweep_chunk, 1024)),
+    OPT_INT("topk_host", opt_topk_host, 0, BIG, (void)0),
+    OPT_INT("lml_small", opt_lml_small, 0, 1, c->lml_cache = false),
+    OPT_INT("lml_cache", opt_lml_cache, 0, 1, c->lml_cache = false),
+    OPT_INT("lml_batch", opt_lml_batch, 0, BIG, (void)0),
+    OPT_INT("lml_batch_mb", opt_lml_batch_mb, 1, BIG, (void)0),
+    OPT_INT("predict_small", opt_predict_small, 0, BIG, (void)0),
+    OPT_INT("predict_split", opt_predict_split, 0, 1, (void)0),
+    OPT_INT("predict_gates", opt_predict_gates, 0, 1, (void)0),
+    OPT_INT("predict_serve", opt_predict_serve, 0, 1, (void)0),
+    OPT_INT("serve_idle_us", opt_serve_idle_us, 10, 1000000, (void)0),
+};
+#undef OPT_INT
+const OptionSpec* find_option(const char* key) {
+    for (const OptionSpec& o : OPTIONS) if (!strcmp(o.key, key)) return &o;
+    return nullptr;
+}
+}  // namespace
+
 int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value) {
-    if (!ctx) return gpry_fail(nullptr, -1, "gpry_ctx_set_option: ctx is NULL");
+    if (!ctx || !key) return gpry_fail(ctx, -1, "gpry_ctx_set_option: NULL argument");
     GPRY_TRY(serve_stop(ctx));
-    if (!strcmp(key, "predict_serve")) { ctx->opt_predict_serve = (int)value; return 0; }
-    if (!strcmp(key, "predict_gates")) { ctx->opt_predict_gates = (int)value; return 0; }
-    if (!strcmp(key, "serve_idle_us")) {
-        if (value < 10 || value > 1000000) return gpry_fail(ctx, -1, "serve_idle_us must be in 10..1000000");
-        ctx->opt_serve_idle_us = value; return 0;
-    }
-    if (!strcmp(key, "chol")) { ctx->opt_chol = (int)value; return 0; }
-    if (!strcmp(key, "sweep_chunk")) {
-        if (value < 128) return gpry_fail(ctx, -1, "sweep_chunk must be >= 128");
-        ctx->opt_sweep_chunk = round_up(value, 1024); return 0;
-    }
-    if (!strcmp(key, "timing")) { ctx->opt_timing = (int)value; return 0; }
-    if (!strcmp(key, "sweep_dma")) { ctx->opt_sweep_dma = (int)value; return 0; }
-    if (!strcmp(key, "sweep_persist")) { ctx->opt_sweep_persist = (int)value; return 0; }
-    if (!strcmp(key, "sweep_overlap")) { ctx->opt_sweep_overlap = (int)value; return 0; }
-    if (!strcmp(key, "chol_overlap")) { ctx->opt_chol_overlap = (int)value; return 0; }
-    if (!strcmp(key, "chol_overlap_max")) { ctx->opt_chol_overlap_max = value; return 0; }
-    if (!strcmp(key, "chol_pair")) { ctx->opt_chol_pair = (int)value; overlap_plan_free(ctx); return 0; }
-    if (!strcmp(key, "chol_multi")) {
-        if (value < 1 || value > 4) return gpry_fail(ctx, -1, "chol_multi must be in 1..4");
-        ctx->opt_chol_multi = (int)value; overlap_plan_free(ctx); return 0;
-    }
-    if (!strcmp(key, "chol_caps")) { ctx->opt_chol_caps = (int)value; overlap_plan_free(ctx); return 0; }
-    if (!strcmp(key, "chol_lookahead")) { ctx->opt_chol_lookahead = (int)value; return 0; }
-    if (!strcmp(key, "chol_dbg")) { ctx->opt_chol_dbg = (int)value; return 0; }
-    if (!strcmp(key, "chol_outer")) {
-        if (value != 0 && (value < 128 || ((int)value % 64))) return gpry_fail(ctx, -1, "chol_outer must be 0 or a multiple of 64 >= 128");
-        ctx->opt_chol_outer = (int)value; return 0;
-    }
-    if (!strcmp(key, "split_k")) { ctx->opt_split_k = (int)value; return 0; }
-    if (!strcmp(key, "predict_split")) { ctx->opt_predict_split = (int)value; return 0; }
-    if (!strcmp(key, "gemm_dma")) { ctx->opt_gemm_dma = (int)value; return 0; }
-    if (!strcmp(key, "trtri_clear")) { ctx->opt_trtri_clear = value != 0; ctx->lml_cache = false; return 0; }
-    if (!strcmp(key, "trtri_diag128")) { ctx->opt_trtri_diag128 = value != 0; trtri_plan_free(ctx); ctx->lml_cache = false; return 0; }
-    if (!strcmp(key, "gemm_small")) { ctx->opt_gemm_small = (int)value; ctx->lml_cache = false; return 0; }
-    if (!strcmp(key, "sweep_altwalk")) { ctx->opt_sweep_altwalk = (int)value & 3; return 0; }   // bit 1: experiment, full-K row tiles
-    if (!strcmp(key, "sweep_colouter")) { ctx->opt_sweep_colouter = (int)value; return 0; }
-    if (!strcmp(key, "lauum_split")) { ctx->opt_lauum_split = (int)value; return 0; }
-    if (!strcmp(key, "trtri_split_cap")) { ctx->opt_trtri_split_cap = (int)value; return 0; }
-    if (!strcmp(key, "trtri_diag_v1")) { ctx->opt_trtri_diag_v1 = (int)value; return 0; }
-    if (!strcmp(key, "topk_host")) { ctx->opt_topk_host = value; return 0; }
-    if (!strcmp(key, "gemm_streamk")) { ctx->opt_gemm_streamk = value; trtri_plan_free(ctx); return 0; }   // the plan holds the stream-K parts
-    if (!strcmp(key, "factor_pipeline")) { ctx->opt_factor_pipeline = (int)value; return 0; }
-    if (!strcmp(key, "factor_pipeline_spine")) {
-        if (value < 0) return gpry_fail(ctx, -1, "factor_pipeline_spine must be >= 0");
-        ctx->opt_factor_pipeline_spine = (int)value; trtri_plan_free(ctx); return 0;
-    }
-    if (!strcmp(key, "factor_pipeline_min")) { ctx->opt_factor_pipeline_min = (int)value; return 0; }
-    if (!strcmp(key, "lauum_lds")) { ctx->opt_lauum_lds = (int)value; return 0; }
-    if (!strcmp(key, "syrk_lds")) { ctx->opt_syrk_lds = (int)value; return 0; }
-    if (!strcmp(key, "predict_small")) { ctx->opt_predict_small = (int64_t)value; return 0; }
-    if (!strcmp(key, "lml_small")) { ctx->opt_lml_small = (int)value; ctx->lml_cache = false; return 0; }
-    if (!strcmp(key, "lml_batch")) {
-        if (value < 0) return gpry_fail(ctx, -1, "lml_batch must be >= 0");
-        ctx->opt_lml_batch = value; return 0;
-    }
-    if (!strcmp(key, "lml_batch_mb")) {
-        if (value < 1) return gpry_fail(ctx, -1, "lml_batch_mb must be >= 1");
-        ctx->opt_lml_batch_mb = value; return 0;
-    }
-    if (!strcmp(key, "lml_cache")) { ctx->opt_lml_cache = (int)value; ctx->lml_cache = false; return 0; }
-    if (!strcmp(key, "kb_tile")) { ctx->opt_kb_tile = (int)value; return 0; }
-    if (!strcmp(key, "kb_variant")) { ctx->opt_kb_variant = (int)value; ctx->lml_cache = false; return 0; }
-    if (!strcmp(key, "sweep_kskew")) { ctx->opt_sweep_kskew = (int)value; return 0; }
-    if (!strcmp(key, "sweep_diag")) { ctx->opt_sweep_diag = (int)value; return 0; }
-    if (!strcmp(key, "sweep_extra_lds")) { ctx->opt_sweep_extra_lds = (int)value; return 0; }
-    if (!strcmp(key, "sweep_stagger")) { ctx->opt_sweep_stagger = (int)value; return 0; }
-    if (!strcmp(key, "sweep_tilemap")) {
-        if (value < 0 || value > 6) return gpry_fail(ctx, -1, "sweep_tilemap must be in 0..6");
-        ctx->opt_sweep_tilemap = (int)value; return 0;
-    }
-    return gpry_fail(ctx, -1, "unknown option '%s'", key);
+    const OptionSpec* o = find_option(key);
+    if (!o) return gpry_fail(ctx, -1, "unknown option '%s'", key);
+    if (value < o->lo || value > o->hi)
+        return gpry_fail(ctx, -1, "%s must be in %lld..%lld (got %lld)", key, (long long)o->lo, (long long)o->hi, (long long)value);
+    o->set(ctx, value);
+    return 0;
 }
 
 int gpry_ctx_get_option(gpry_ctx* ctx, const char* key, int64_t* value) {
     if (!ctx || !key || !value) return gpry_fail(ctx, -1, "gpry_ctx_get_option: NULL argument");
-    if (!strcmp(key, "lml_batch")) { *value = ctx->opt_lml_batch; return 0; }
-    if (!strcmp(key, "lml_batch_mb")) { *value = ctx->opt_lml_batch_mb; return 0; }
-    if (!strcmp(key, "lml_small")) { *value = ctx->opt_lml_small; return 0; }
-    if (!strcmp(key, "timing")) { *value = ctx->opt_timing; return 0; }
-    return gpry_fail(ctx, -1, "unknown option '%s'", key);
+    const OptionSpec* o = find_option(key);
+    if (!o) return gpry_fail(ctx, -1, "unknown option '%s'", key);
+    *value = o->get(ctx);
+    return 0;
 }
 
 int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const double* alpha,

@@ -36,7 +36,6 @@ bool gemm_dma_usable(const GemmArgs& g, int M, int N, int K) {
     if (M <= 0 || N <= 0 || K < 32) return false;
     if (M % BM || N % BN || K % 32) return false;
     if ((g.lda | g.ldb | g.ldc) & 1) return false;
-    if (g.kskew || g.stagger || g.diag) return false;
     // triangular k-ranges start / end on tile boundaries (multiples of 128); split-K works on slab pairs
     return true;
 }
@@ -45,9 +44,9 @@ template <bool AT, bool BT>
 static int gd_launch_epi(gpry_ctx* ctx, const GemmArgs& g, int epi, dim3 grid) {
     hipStream_t st = g.stream ? g.stream : ctx->stream;
     switch (epi) {
-        case EPI_STORE: hipLaunchKernelGGL((gemm_dma_kernel<AT, BT, EPI_STORE>), grid, dim3(256), (size_t)g.extra_lds, st, g); break;
-        case EPI_STORE_NEG: hipLaunchKernelGGL((gemm_dma_kernel<AT, BT, EPI_STORE_NEG>), grid, dim3(256), (size_t)g.extra_lds, st, g); break;
-        case EPI_SUB: hipLaunchKernelGGL((gemm_dma_kernel<AT, BT, EPI_SUB>), grid, dim3(256), (size_t)g.extra_lds, st, g); break;
+        case EPI_STORE: hipLaunchKernelGGL((gemm_dma_kernel<AT, BT, EPI_STORE>), grid, dim3(256), 0, st, g); break;
+        case EPI_STORE_NEG: hipLaunchKernelGGL((gemm_dma_kernel<AT, BT, EPI_STORE_NEG>), grid, dim3(256), 0, st, g); break;
+        case EPI_SUB: hipLaunchKernelGGL((gemm_dma_kernel<AT, BT, EPI_SUB>), grid, dim3(256), 0, st, g); break;
         default: return gpry_fail(ctx, -1, "gemm_dma: bad epilogue %d", epi);
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -89,7 +89,7 @@ __device__ __forceinline__ void store_mc(double* lds, const double (&r)[8]) {
     p[2] = make_double2(r[4], r[5]); p[3] = make_double2(r[6], r[7]);
 }
 
-template <bool AT, bool BT, int EPI, bool DIAG = false>
+template <bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double smem[4 * TILE_DOUBLES];
     int tb, bz;
@@ -128,9 +128,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         C = bset(g.split_buf, tb, g.bstride) + (int64_t)blockIdx.y * g.split_stride + (C - C0);
     }
     const int nslab = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-    // Tiles that share a V row-panel or a K* column-panel start at different slabs so that
-    // one of them fetches a line and the others find it in L2 (simultaneous misses are not merged).
-    const int krot = (g.kskew > 0 && nslab > 0) ? (((tc.ti + tc.tj) & 7) * g.kskew) % nslab : 0;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -144,8 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
     double ra[8], rb[8];
     auto load_slab = [&](int s) {
-        int sk = s + krot; if (sk >= nslab) sk -= nslab;   // rotated slab order (L2 skew)
-        int k0 = kbeg + sk * BK;
+        int k0 = kbeg + s * BK;
         if (AT) load_mc(A, g.lda, row0, M, k0, ra); else load_kc(A, g.lda, row0, M, k0, ra);
         if (BT) load_kc(B, g.ldb, col0, N, k0, rb); else load_mc(B, g.ldb, col0, N, k0, rb);
     };
@@ -160,26 +156,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         load_slab(0);
         store_slab(0);
     }
-    if (g.stagger) {
-        // Two workgroups share every SIMD's matrix pipe and, started together, reach their
-        // per-slab barrier phase together (pipe idle).  Delay the one sitting in the odd
-        // wave slot by about half a slab so that one partner always has MFMAs queued.
-        __shared__ int s_slot;
-        if (threadIdx.x == 0) s_slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11)) & 1;  // HW_ID.WAVE_ID
-        __syncthreads();
-        if (s_slot) { for (int i = 0; i < g.stagger; i++) __builtin_amdgcn_s_sleep(32); }
-    }
     __syncthreads();
 
-    // DIAG build only: s_memtime stamps around the phases of a slab step, summed per wave
-    // and added to g.diag[0..5] (shares, not absolute times; the stamps serialise the step)
-    unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0};
-#define STAMP(v) unsigned long long v = 0; if (DIAG) { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
     for (int s = 0; s < nslab; s++) {
         const int buf = s & 1;
-        STAMP(t0)
         if (s + 1 < nslab) load_slab(s + 1);
-        STAMP(t1)
         const double* As = smem + buf * 2 * TILE_DOUBLES;
         const double* Bs = As + TILE_DOUBLES;
 #pragma unroll
@@ -199,22 +180,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 for (int ni = 0; ni < 4; ni++)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
-        STAMP(t2)
-        if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        STAMP(t3)
         if (s + 1 < nslab) store_slab(buf ^ 1);
-        if (DIAG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-        STAMP(t4)
         __syncthreads();
-        STAMP(t5)
-        if (DIAG) {
-            dsum[0] += t1 - t0; dsum[1] += t2 - t1; dsum[2] += t3 - t2; dsum[3] += t4 - t3; dsum[4] += t5 - t4;
-            dsum[5] += 1;
-        }
-    }
-#undef STAMP
-    if (DIAG && g.diag != nullptr && lane == 0) {
-        for (int i = 0; i < 6; i++) atomicAdd(&g.diag[i], dsum[i]);
     }
 
     // ---- epilogue.  f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4*reg.
@@ -315,13 +282,10 @@ template <bool AT, bool BT>
 static int launch_epi(gpry_ctx* ctx, const GemmArgs& g, int epi, dim3 grid) {
     hipStream_t st = g.stream ? g.stream : ctx->stream;
     switch (epi) {
-        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_STORE>), grid, dim3(256), (size_t)g.extra_lds, st, g); break;
-        case EPI_STORE_NEG: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_STORE_NEG>), grid, dim3(256), (size_t)g.extra_lds, st, g); break;
-        case EPI_SUB: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_SUB>), grid, dim3(256), (size_t)g.extra_lds, st, g); break;
-        case EPI_SUMSQ:
-            if (g.diag) hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_SUMSQ, true>), grid, dim3(256), (size_t)g.extra_lds, st, g);
-            else hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_SUMSQ>), grid, dim3(256), (size_t)g.extra_lds, st, g);
-            break;
+        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_STORE>), grid, dim3(256), 0, st, g); break;
+        case EPI_STORE_NEG: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_STORE_NEG>), grid, dim3(256), 0, st, g); break;
+        case EPI_SUB: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_SUB>), grid, dim3(256), 0, st, g); break;
+        case EPI_SUMSQ: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, EPI_SUMSQ>), grid, dim3(256), 0, st, g); break;
         default: return gpry_fail(ctx, -1, "gemm: bad epilogue %d", epi);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -345,7 +309,7 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g0, bool a_trans, bool b_tran
     }
     // a handful of tiles: four times as many workgroups with 64 x 64 tiles (gemm_small.hip)
     if (g.small64 && ctx->opt_gemm_small > 0 && epi != EPI_SUMSQ && g.nsplit <= 1 && (g.tile_map & 15) == TM_ROWMAJOR &&
-        !(a_trans && b_trans) && !g.diag && nblk * (g.batch ? g.n_batch : 1) <= ctx->opt_gemm_small)
+        !(a_trans && b_trans) && nblk * (g.batch ? g.n_batch : 1) <= ctx->opt_gemm_small)
         return gemm64_launch(ctx, g, a_trans, b_trans, epi);
     dim3 grid((unsigned)nblk, (unsigned)(g.nsplit > 1 ? g.nsplit : 1), (unsigned)(g.bz_div * g.bn));
     if (g.nsplit > 1 && !(epi == EPI_STORE || epi == EPI_STORE_NEG))

@@ -59,12 +59,6 @@ __device__ __forceinline__ void tri_decode(int64_t t, int* bi, int* bj) {
     *bi = i; *bj = (int)(t - (int64_t)i * (i + 1) / 2);
 }
 
-// One TS x TS tile of K per workgroup (lower block triangle), (TS/4)^2 threads, each
-// thread owns a 4x4 patch.  Off-diagonal tiles are mirrored through an LDS transpose so that
-// both the (bi,bj) and (bj,bi) images are written as full row segments with 16-byte stores.
-// TS = 32 (one wave per tile) keeps ~8000 tiles in flight at N = 4096, so that the launch is
-// not quantised into a few long rounds.  Algorithmic traffic: read X once (8 N d), write K
-// once (8 N^2).
 typedef double nt_v2d __attribute__((ext_vector_type(2)));
 // streaming 16-byte store: K is written once and read next by another kernel
 __device__ __forceinline__ void nt_store2(double2* p, double a, double b) {
@@ -72,90 +66,8 @@ __device__ __forceinline__ void nt_store2(double2* p, double a, double b) {
     __builtin_nontemporal_store(v, reinterpret_cast<nt_v2d*>(p));
 }
 
-template <int KID, int TS>
-__global__ __launch_bounds__((TS / 4) * (TS / 4), 5) void kernel_train_kernel(
-    const double* __restrict__ Xs, const double* __restrict__ noise, double* __restrict__ K,
-    int64_t ld, KernParams kp, int add_noise) {
-    constexpr int NT = (TS / 4) * (TS / 4), TQ = TS / 4, TP = TS + 2;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int dp = kp.dpad;
-    double* Xi = sm;             // [dp][TS]
-    double* Xj = sm + dp * TS;   // [dp][TS]
-    int bi, bj; tri_decode(blockIdx.x, &bi, &bj);
-    const int t = threadIdx.x, tx = t % TQ, ty = t / TQ;
-    for (int e = t; e < TS * dp; e += NT) {
-        int row = e / dp, k = e - row * dp;
-        Xi[k * TS + row] = Xs[((int64_t)bi * TS + row) * dp + k];
-        Xj[k * TS + row] = Xs[((int64_t)bj * TS + row) * dp + k];
-    }
-    __syncthreads();
-    double r2[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) r2[a][b] = 0.0;
-    for (int k = 0; k < dp; k++) {
-        // columns of this thread: {2tx, 2tx+1, TS/2+2tx, TS/2+2tx+1} -- the 16 lanes of a row then
-        // store 256 contiguous bytes per instruction (whole cache lines) instead of 16-byte pieces
-        // of every other 32 bytes
-        const double2* pi = reinterpret_cast<const double2*>(Xi + k * TS + ty * 4);
-        const double2* pj = reinterpret_cast<const double2*>(Xj + k * TS + tx * 2);
-        double2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[TS / 4];
-        double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) { double df = xi[a] - xj[b]; r2[a][b] = fma(df, df, r2[a][b]); }
-    }
-    double val[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            int64_t i = (int64_t)bi * TS + ty * 4 + a;
-            int64_t j = (int64_t)bj * TS + (b >> 1) * (TS / 2) + tx * 2 + (b & 1);
-            double v = kp.C * corr_r2<KID>(r2[a][b]);
-            if (i == j) v = kp.C + (add_noise ? noise[i < kp.N ? i : 0] : 0.0);
-            if (i >= kp.N || j >= kp.N) v = (i == j) ? 1.0 : 0.0;   // identity padding
-            val[a][b] = v;
-        }
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        int64_t i = (int64_t)bi * TS + ty * 4 + a;
-        double2* p = reinterpret_cast<double2*>(K + i * ld + (int64_t)bj * TS + tx * 2);
-        nt_store2(p, val[a][0], val[a][1]);
-        nt_store2(p + TS / 4, val[a][2], val[a][3]);
-    }
-    if (bi == bj) return;
-    // Mirror image through an LDS transpose, one half of the tile's columns at a time: the pad is
-    // [TS/2][TS+2] doubles (16.9 KB at TS = 64 instead of 33.8 KB), so that five workgroups fit a CU
-    // and the 2080 tiles of N = 4096 run in two rounds instead of two and a bit.
-    double* T = sm;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        __syncthreads();        // X tiles (h = 0) / the previous half (h = 1) are no longer needed
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            T[(tx * 2 + 0) * TP + ty * 4 + a] = val[a][2 * h + 0];
-            T[(tx * 2 + 1) * TP + ty * 4 + a] = val[a][2 * h + 1];
-        }
-        __syncthreads();
-        // mirrored rows jr = h*TS/2 + 0..TS/2-1 of TS values: every store instruction writes whole
-        // rows (TS/2 lanes x 16 B contiguous), RPI rows per instruction
-        constexpr int LPR = TS / 2;                  // lanes per row (32 at TS = 64)
-        constexpr int RPI = NT / LPR;                // rows per instruction (8 at TS = 64)
-        const int c0 = (t % LPR) * 2;
-#pragma unroll
-        for (int v = 0; v < (TS / 2) / RPI; v++) {
-            const int jl = v * RPI + t / LPR;
-            double2* p = reinterpret_cast<double2*>(K + ((int64_t)bj * TS + h * (TS / 2) + jl) * ld + (int64_t)bi * TS + c0);
-            const double2 q = *reinterpret_cast<const double2*>(T + jl * TP + c0);
-            nt_store2(p, q.x, q.y);
-        }
-    }
-}
-
-// Round 3 mapping ("kb_variant" = 1: 64 x 64 tile per workgroup, = 2: 32 x 32 tile per single-wave workgroup).
+// One 64 x 64 tile of K per workgroup (lower block triangle; off-diagonal tiles write both images), 256 threads = 4 waves.
+// Algorithmic traffic: read X once (8 N d), write K once (8 N^2).
 // Every wave owns a 32 x 32 quadrant; lane = (ly, lx) in an 8 x 8 grid; the thread's 4 x 4 patch has rows
 // {16 a' + 2 ly + a''} and columns {16 b' + 2 lx + b''} of the quadrant.  With that shape BOTH images of an entry
 // are stored straight from registers in whole 128-byte lines: the direct one as double2 over b'' (8 lx lanes = 16
@@ -168,11 +80,11 @@ __global__ __launch_bounds__((TS / 4) * (TS / 4), 5) void kernel_train_kernel(
 // differ from numpy's in the last bit of a few entries, and on the cond(K) = 5e15 matrix of BASELINE config 1 one ulp
 // of K moves the posterior mean by 2e-5 of its range (tests/test_host_mirror_gpu.py::test_f9_config1_curved_degeneracy
 // failed with them; the F1 goldens, 1e-13, would not have noticed).
-template <int KID, int TS, bool CHUNKED>
-__global__ __launch_bounds__((TS / 32) * (TS / 32) * 64, 6) void kernel_train_q_kernel(
+template <int KID>
+__global__ __launch_bounds__(256, 6) void kernel_train_q_kernel(
     const double* __restrict__ Xs_, const double* __restrict__ noise, double* __restrict__ K_,
     int64_t ld, KernParams kp, int add_noise, const double* __restrict__ bpar, int64_t bstride) {
-    constexpr int WPR = TS / 32, NT = WPR * WPR * 64;
+    constexpr int TS = 64, WPR = TS / 32, NT = WPR * WPR * 64;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     // batched launch (gpry_ctx::bn): theta blockIdx.z builds its own K from its own scaled coordinates and constant
     const double* __restrict__ Xs = bset(Xs_, (int)blockIdx.z, bstride);
@@ -195,34 +107,19 @@ __global__ __launch_bounds__((TS / 32) * (TS / 32) * 64, 6) void kernel_train_q_
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) r2[a][b] = 0.0;
-    if (!CHUNKED) {
-        for (int k = 0; k < dp; k++) {
-            const double2 i0 = *reinterpret_cast<const double2*>(Xi + k * TS + r0);
-            const double2 i1 = *reinterpret_cast<const double2*>(Xi + k * TS + r0 + 16);
-            const double2 j0 = *reinterpret_cast<const double2*>(Xj + k * TS + c0);
-            const double2 j1 = *reinterpret_cast<const double2*>(Xj + k * TS + c0 + 16);
-            const double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
+    for (int k = 0; k < dp; k++) {
+        const double2 i0 = *reinterpret_cast<const double2*>(Xi + k * TS + r0);
+        const double2 i1 = *reinterpret_cast<const double2*>(Xi + k * TS + r0 + 16);
+        const double2 j0 = *reinterpret_cast<const double2*>(Xj + k * TS + c0);
+        const double2 j1 = *reinterpret_cast<const double2*>(Xj + k * TS + c0 + 16);
+        const double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
-            for (int a = 0; a < 4; a++)
+        for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) { const double df = xi[a] - xj[b]; r2[a][b] = fma(df, df, r2[a][b]); }
-        }
+            for (int b = 0; b < 4; b++) { const double df = xi[a] - xj[b]; r2[a][b] = fma(df, df, r2[a][b]); }
     }
 #pragma unroll
     for (int ap = 0; ap < 2; ap++) {
-        if (CHUNKED) {
-            // the distances of this row pair only: its stores leave before the other pair's arithmetic starts
-            for (int k = 0; k < dp; k++) {
-                const double2 i0 = *reinterpret_cast<const double2*>(Xi + k * TS + r0 + 16 * ap);
-                const double2 j0 = *reinterpret_cast<const double2*>(Xj + k * TS + c0);
-                const double2 j1 = *reinterpret_cast<const double2*>(Xj + k * TS + c0 + 16);
-                const double xi[2] = {i0.x, i0.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
-#pragma unroll
-                for (int a2 = 0; a2 < 2; a2++)
-#pragma unroll
-                    for (int b = 0; b < 4; b++) { const double df = xi[a2] - xj[b]; r2[2 * ap + a2][b] = fma(df, df, r2[2 * ap + a2][b]); }
-            }
-        }
         double v[2][4];
 #pragma unroll
         for (int a2 = 0; a2 < 2; a2++)
@@ -255,37 +152,13 @@ __global__ __launch_bounds__((TS / 32) * (TS / 32) * 64, 6) void kernel_train_q_
 
 int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
     KernParams kp = make_kp(ctx);
-    if (ctx->opt_kb_variant >= 1 && ctx->opt_kb_variant <= 3) {
-        const int TQ = ctx->opt_kb_variant == 2 ? 32 : 64;
-        const bool chunked = ctx->opt_kb_variant == 3;
-        const int64_t nbq = ctx->Np / TQ, ntq = nbq * (nbq + 1) / 2;
-        const size_t smq = sizeof(double) * (size_t)(2 * ctx->dpad * TQ);
-        const dim3 gq((unsigned)ntq, 1, (unsigned)ctx->bn);
-#define KQ(KID)                                                                                               \
-    if (TQ == 64 && chunked) hipLaunchKernelGGL((kernel_train_q_kernel<KID, 64, true>), gq, dim3(256), smq, \
-                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise, ctx->bpar, ctx->bstride);          \
-    else if (TQ == 64) hipLaunchKernelGGL((kernel_train_q_kernel<KID, 64, false>), gq, dim3(256), smq,     \
-                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise, ctx->bpar, ctx->bstride);          \
-    else hipLaunchKernelGGL((kernel_train_q_kernel<KID, 32, false>), gq, dim3(64), smq,              \
-                            ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise, ctx->bpar, ctx->bstride)
-        DISPATCH_KID(ctx->kernel_id, KQ)
+    const int64_t nbq = ctx->Np / 64, ntq = nbq * (nbq + 1) / 2;
+    const size_t smq = sizeof(double) * (size_t)(2 * ctx->dpad * 64);
+    const dim3 gq((unsigned)ntq, 1, (unsigned)ctx->bn);
+#define KQ(KID) hipLaunchKernelGGL((kernel_train_q_kernel<KID>), gq, dim3(256), smq, ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, \
+                                   add_noise, ctx->bpar, ctx->bstride)
+    DISPATCH_KID(ctx->kernel_id, KQ)
 #undef KQ
-        HIP_TRY(ctx, hipGetLastError());
-        return 0;
-    }
-    if (ctx->bn > 1) return gpry_fail(ctx, -1, "batched chain: kb_variant 0 is not batched");
-    const int TS = ctx->opt_kb_tile == 64 ? 64 : 32;
-    int64_t nb = ctx->Np / TS;
-    int64_t ntile = nb * (nb + 1) / 2;
-    const int pad = (TS / 2) * (TS + 2);
-    size_t smem = sizeof(double) * (size_t)((2 * ctx->dpad * TS > pad) ? 2 * ctx->dpad * TS : pad);
-#define KT(KID)                                                                                        \
-    if (TS == 64) hipLaunchKernelGGL((kernel_train_kernel<KID, 64>), dim3((unsigned)ntile), dim3(256), smem, \
-                                     ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise);  \
-    else hipLaunchKernelGGL((kernel_train_kernel<KID, 32>), dim3((unsigned)ntile), dim3(64), smem,    \
-                            ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, add_noise)
-    DISPATCH_KID(ctx->kernel_id, KT)
-#undef KT
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -51,7 +51,6 @@ struct LmlSmallArgs {
                             // [LS_INFO_UNIT] factorisation status (0 or the 1-based failing column, as a double)
     unsigned long long seq; // stamp of this evaluation
     int want_grad;
-    unsigned long long* dbg;   // nullable: cycles per phase (B, C, E, F, G, H) of the launch, added up (gpry_debug_read_diag)
     const double* batch;       // nullable: several thetas in ONE launch, workgroup b evaluates [C, l_1 .. l_16] = batch[17 b ..] (the values
                                // the host computes for a single evaluation: same bits) and reports into host_res + LS_UNITS * b
 };
@@ -77,9 +76,6 @@ __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernPa
         a.host_res += LS_UNITS * (int64_t)blockIdx.x;
     }
     const int nb = (N + 15) >> 4;            // 16-row blocks that hold training rows (the others are identity padding)
-    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
-    const bool stamp = a.dbg != nullptr && t == 0;
-#define LS_STAMP(I) if (stamp) ts[I] = __builtin_readcyclecounter()
 
     // ---- A: scaled coordinates, targets
 #pragma unroll
@@ -94,7 +90,6 @@ __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernPa
     if (t < 16) s_flag[t] = 0;
     if (t == 0) s_bad = 0;
     __syncthreads();
-    LS_STAMP(0);
 
     // ---- B: covariance matrix, lower tiles (tile list: (bi, bj), bj <= bi), MFMA C-layout per wave:
     // lane (g, r) owns rows 16 bi + g + 4q (q = 0..3), column 16 bj + r
@@ -122,7 +117,6 @@ __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernPa
         }
     }
     __syncthreads();
-    LS_STAMP(1);
 
     // ---- C: Cholesky, blocked by 16, as a dataflow between the waves (wave w owns block row w).  A wave that has
     // factored its diagonal block is done with the chain: it inverts that block (E) into registers while the chain
@@ -174,14 +168,12 @@ __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernPa
         }
         return;
     }
-    LS_STAMP(2);
     if (w < nb && lane < 16) {
         double* Lw = M + (w * 16) * LS_LD + w * 16;
 #pragma unroll
         for (int i = 0; i < 16; i++) Lw[i * LS_LD + lane] = winv[i];
     }
     __syncthreads();
-    LS_STAMP(3);
 
     // ---- F: V = L^-1 in place by recursive doubling over the 16 x 16 tiles: [[L11, 0], [L21, L22]]^-1 =
     // [[V11, 0], [-V22 (L21 V11), V22]].  Per level (block size h = 1, 2, 4 tiles) and node (lo, mid, hi): first
@@ -221,7 +213,6 @@ __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernPa
             __syncthreads();
         }
     }
-    LS_STAMP(4);
 
     // ---- G: z = V y, alpha = V^T z, quad = z.z, log-determinant
     {   // z: four threads per row, 32 terms each (walking a row with the 64 lanes and a butterfly sum per row was
@@ -271,7 +262,6 @@ __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernPa
         return;
     }
 
-    LS_STAMP(5);
     // ---- H: traces 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_k) over the lower tiles, off-diagonal tiles twice
     double gacc[DP + 1];
 #pragma unroll
@@ -324,8 +314,6 @@ __global__ __launch_bounds__(LS_NT) void lml_small_kernel(LmlSmallArgs a, KernPa
         if (lane == 0) red[w][k] = v;
     }
     __syncthreads();
-    LS_STAMP(6);
-    if (stamp) for (int q = 0; q < 6; q++) atomicAdd(&a.dbg[q], ts[q + 1] - ts[q]);
     // ---- I: results
     if (t <= kp.d) {
         double s = 0.0;
@@ -365,13 +353,11 @@ int launch_lml_small_batch(gpry_ctx* ctx, int B, const double* params, int want_
     a.host_res = reinterpret_cast<LsUnit*>(static_cast<char*>(ctx->hpin_dev) + 1024);
     a.seq = ++ctx->lml_seq;
     a.want_grad = want_grad;
-    a.dbg = nullptr;
     a.batch = nullptr;
     if (params) {
         memcpy(static_cast<char*>(ctx->hpin) + par_off, params, sizeof(double) * 17 * B);
         a.batch = reinterpret_cast<const double*>(static_cast<char*>(ctx->hpin_dev) + par_off);
     }
-    if (ctx->opt_chol_dbg && B == 1) { if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64)); a.dbg = ctx->dsel + 16; }
 #define LS2(DP, KID) hipLaunchKernelGGL((lml_small_kernel<DP, KID>), dim3((unsigned)B), dim3(LS_NT), 0, ctx->stream, a, kp, ap)
 #define LS4(KID) { if (ctx->d <= 4) LS2(4, KID); else if (ctx->d <= 8) LS2(8, KID); else LS2(16, KID); }
     DISPATCH_KID(ctx->kernel_id, LS4)

@@ -1,14 +1,18 @@
-// Sweep contraction with direct global->LDS staging (LDS-DMA, global_load_lds_dwordx4):
-//   per 128x128 tile:  S[ti][m] = sum_i ( sum_{k<=i} V[i][k] * Kst[k][m] )^2
-// Same tiling, MFMA schedule and SUMSQ epilogue as gemm_f64_kernel<NN,SUMSQ>; what changes
-// is the staging: no VGPR round trip and no ds_write pass -- each wave issues eight 1-KiB
-// DMA pieces per slab straight into the other LDS buffer and then only waits (vmcnt(0))
-// before the slab barrier.  The DMA destination is linear (wave base + lane*16 B), so
-//   * the K*^T slab keeps the padded [16][144] image (one piece = one 1-KiB k-row), and
-//   * the V slab is an UNPADDED [128 rows][8 pieces of 16 B] image whose bank conflicts are
-//     removed by an XOR swizzle applied on the SOURCE side: LDS piece p' of row r holds
-//     global piece p = p' ^ ((r >> 1) & 7); the fragment read applies the same involution.
-// Requires M, N multiples of 128 (true for the sweep: Np and the padded chunk).
+// Sweep contraction of the NORA acquisition (gpry/gpr.py:1204 dtrmm + :1208 einsum, fused), per 128 x 128 tile:
+//     S[ti][m] = sum_{i in tile ti} ( sum_{k <= i} V[i][k] * Kst[k][m] )^2
+// FP64 MFMA (v_mfma_f64_16x16x4_f64), 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA tiles; the N x M product
+// is never stored (SUMSQ epilogue: per-tile column sums of squares, reduced registers -> shuffles -> LDS in a fixed order).
+// Staging is direct global -> LDS (LDS-DMA, global_load_lds_dwordx4): no VGPR round trip, no ds_write pass -- each wave issues
+// eight 1-KiB DMA pieces per slab of 16 k straight into the other LDS buffer.  The DMA destination is linear (wave base +
+// lane * 16 B), so
+//   * the K*^T slab keeps a padded [16][144] image (one piece = one 1-KiB k-row), and
+//   * the V slab is an UNPADDED [128 rows][8 pieces of 16 B] image whose bank conflicts are removed by an XOR swizzle applied
+//     on the SOURCE side: LDS piece p' of row r holds global piece p = p' ^ ((r >> 1) & 7); the fragment read applies the
+//     same involution.
+// Requires M, N multiples of 128 (true for the sweep: Np and the padded chunk).  The register-staged engine of gemm_f64.hip
+// (option "gemm_dma" = 0) is the comparator; the measured history of the variants that lost (plain LDS-DMA without the software
+// pipeline, a 128 x 256 / 8-wave ring, persistent workgroups with per-XCD tickets, k-skewed and staggered starts) is in
+// profiles/HISTORY.md.
 #include "common.h"
 
 #define BM 128
@@ -26,276 +30,8 @@ __device__ __forceinline__ void dma16(const double* g, double* l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void sweep_gemm_dma_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) double smem[2 * BUF_DOUBLES];
-    const int M = g.M, N = g.N, K = g.K;
-    const int tiles_m = M / BM, tiles_n = N / BN;
-    // XCD-aware super-tile map (see gemm_f64.hip)
-    int ti, tj;
-    {
-        const int b = blockIdx.x;
-        const int a = (g.tile_map >> 4) & 15, c = 6 - a;
-        const int nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
-        const int xcd = b & 7, q = b >> 3;
-        const int s = (q >> 6) * 8 + xcd, within = q & 63;
-        if (s >= nsi * nsj) return;
-        const int si = nsi - 1 - s / nsj, sj = s % nsj;
-        ti = (si << a) + (within >> c);
-        tj = (sj << c) + (within & ((1 << c) - 1));
-        if (ti >= tiles_m || tj >= tiles_n) return;
-    }
-    const int row0 = ti * BM, col0 = tj * BN;
-    const int kend = min(K, row0 + BM);          // V is lower triangular
-    const int nslab = kend / BK;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int r = lane & 15, gq = lane >> 4;
-
-    // per-lane source addresses of this wave's 4 + 4 DMA pieces of a slab (k0 added per slab)
-    const double* srcA[4];
-    int dstA[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int q = wave * 4 + j;                       // piece index: rows q*8 .. q*8+7
-        const int row = q * 8 + (lane >> 3), pp = lane & 7;
-        const int p = pp ^ ((row >> 1) & 7);              // swizzle on the source side
-        srcA[j] = g.A + (int64_t)(row0 + row) * g.lda + 2 * p;
-        dstA[j] = q * 128;                                // doubles, wave-uniform
-    }
-    const double* srcB = g.B + (int64_t)(wave * 4) * g.ldb + col0 + 2 * lane;
-
-    auto issue = [&](int s, int buf) {
-        double* As = smem + buf * BUF_DOUBLES;
-        double* Bs = As + A_DOUBLES;
-        const int k0 = s * BK;
-#pragma unroll
-        for (int j = 0; j < 4; j++) dma16(srcA[j] + k0, As + dstA[j]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) dma16(srcB + (int64_t)(k0 + j) * g.ldb, Bs + (wave * 4 + j) * SMC);
-    };
-
-    v4d acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-    // fragment offsets of the swizzled A image that do not depend on the slab
-    int aoff[4][2];   // [mi][k parity pair]: row*16 ; swizzle key
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++) {
-        const int row = wr * 64 + mi * 16 + r;
-        aoff[mi][0] = row * 16;
-        aoff[mi][1] = (row >> 1) & 7;
-    }
-
-    issue(0, 0);
-    __syncthreads();   // emits s_waitcnt vmcnt(0): the DMA pieces of slab 0 have landed
-
-    for (int s = 0; s < nslab; s++) {
-        const int buf = s & 1;
-        if (s + 1 < nslab) issue(s + 1, buf ^ 1);
-        const double* As = smem + buf * BUF_DOUBLES;
-        const double* Bs = As + A_DOUBLES;
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; kk++) {
-            const int k = kk * 4 + gq;
-            double a[4], b[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; mi++)
-                a[mi] = As[aoff[mi][0] + 2 * ((k >> 1) ^ aoff[mi][1]) + (k & 1)];
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) b[ni] = Bs[k * SMC + wc * 64 + ni * 16 + r];
-#pragma unroll
-            for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-                for (int ni = 0; ni < 4; ni++)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        }
-        __syncthreads();   // vmcnt(0) + barrier: slab s+1 landed, everybody done with slab s
-    }
-
-    // column sums of squares over the 128 rows of the tile (C/D: col = lane&15, row = (lane>>4)+4q)
-    double cs[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ni++) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) sacc = fma(acc[mi][ni][q], acc[mi][ni][q], sacc);
-        sacc += __shfl_xor(sacc, 16);
-        sacc += __shfl_xor(sacc, 32);
-        cs[ni] = sacc;
-    }
-    double* red = smem;
-    if (gq == 0) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++) red[wr * 128 + wc * 64 + ni * 16 + r] = cs[ni];
-    }
-    __syncthreads();
-    if (threadIdx.x < 128)
-        g.C[(int64_t)ti * g.ldc + col0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
-}
-
-int sweep_gemm_dma_launch(gpry_ctx* ctx, const GemmArgs& g) {
-    if (g.M % BM || g.N % BN || g.K % BK) return gpry_fail(ctx, -1, "sweep_gemm_dma: dims must be multiples of 128");
-    const int tiles_m = g.M / BM, tiles_n = g.N / BN;
-    const int a = (g.tile_map >> 4) & 15, c = 6 - a;
-    int64_t nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
-    int64_t ns = (nsi * nsj + 7) / 8 * 8;
-    hipLaunchKernelGGL(sweep_gemm_dma_kernel, dim3((unsigned)(ns * 64)), dim3(256), (size_t)g.extra_lds, ctx->stream, g);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
-}
-
 // ---------------------------------------------------------------------------------------
-// Variant 2: 128 x 256 tile, 8 waves (2 x 4), one workgroup per CU, three-stage LDS ring.
-// A slab of V (128 x 16) now serves 256 candidates, i.e. 25 % fewer staged bytes per MFMA
-// than the 128 x 128 tile, and a DMA piece has two slab times to land: at step s the wave
-// waits only for its own pieces of slab s (s_waitcnt vmcnt(6) leaves slab s+1 in flight),
-// crosses a raw s_barrier, issues slab s+2 into the buffer that was read in step s-1, and
-// multiplies slab s.
-#define BN2 256
-#define SB2 272
-#define B2_DOUBLES (16 * SB2)
-#define STAGE2 (A_DOUBLES + B2_DOUBLES)
-
-__global__ __launch_bounds__(512, 2) void sweep_gemm_dma256_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) double smem[3 * STAGE2];
-    const int M = g.M, N = g.N, K = g.K;
-    const int tiles_m = M / BM, tiles_n = N / BN2;
-    int ti, tj;
-    {
-        const int b = blockIdx.x;
-        const int a = (g.tile_map >> 4) & 15, c = 5 - a;      // 32 tiles per XCD wave of workgroups
-        const int nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
-        const int xcd = b & 7, q = b >> 3;
-        const int s = (q >> 5) * 8 + xcd, within = q & 31;
-        if (s >= nsi * nsj) return;
-        const int si = nsi - 1 - s / nsj, sj = s % nsj;
-        ti = (si << a) + (within >> c);
-        tj = (sj << c) + (within & ((1 << c) - 1));
-        if (ti >= tiles_m || tj >= tiles_n) return;
-    }
-    const int row0 = ti * BM, col0 = tj * BN2;
-    const int kend = min(K, row0 + BM);
-    const int nslab = kend / BK;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int r = lane & 15, gq = lane >> 4;
-
-    const double* srcA[2];
-    int dstA[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int q = wave * 2 + j;
-        const int row = q * 8 + (lane >> 3), pp = lane & 7;
-        const int p = pp ^ ((row >> 1) & 7);
-        srcA[j] = g.A + (int64_t)(row0 + row) * g.lda + 2 * p;
-        dstA[j] = q * 128;
-    }
-    const double* srcB[4];
-    int dstB[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int idx = wave * 4 + j, krow = idx >> 1, half = idx & 1;
-        srcB[j] = g.B + (int64_t)krow * g.ldb + col0 + half * 128 + 2 * lane;
-        dstB[j] = krow * SB2 + half * 128;
-    }
-    auto issue = [&](int s, int buf) {
-        double* As = smem + buf * STAGE2;
-        double* Bs = As + A_DOUBLES;
-        const int k0 = s * BK;
-#pragma unroll
-        for (int j = 0; j < 2; j++) dma16(srcA[j] + k0, As + dstA[j]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) dma16(srcB[j] + (int64_t)k0 * g.ldb, Bs + dstB[j]);
-    };
-
-    v4d acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-    int aoff[4][2];
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++) {
-        const int row = wr * 64 + mi * 16 + r;
-        aoff[mi][0] = row * 16;
-        aoff[mi][1] = (row >> 1) & 7;
-    }
-
-    issue(0, 0);
-    if (nslab > 1) issue(1, 1);
-    int buf = 0;
-    for (int s = 0; s < nslab; s++) {
-        // own pieces of slab s have landed (the newest six, slab s+1, may still be in flight)
-        if (s + 1 < nslab) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        int nb = buf + 2; if (nb >= 3) nb -= 3;
-        if (s + 2 < nslab) issue(s + 2, nb);
-        const double* As = smem + buf * STAGE2;
-        const double* Bs = As + A_DOUBLES;
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; kk++) {
-            const int k = kk * 4 + gq;
-            double a[4], b[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; mi++)
-                a[mi] = As[aoff[mi][0] + 2 * ((k >> 1) ^ aoff[mi][1]) + (k & 1)];
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) b[ni] = Bs[k * SB2 + wc * 64 + ni * 16 + r];
-#pragma unroll
-            for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-                for (int ni = 0; ni < 4; ni++)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of slab s are done
-        buf = buf + 1; if (buf >= 3) buf = 0;
-    }
-    __syncthreads();
-    double cs[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ni++) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) sacc = fma(acc[mi][ni][q], acc[mi][ni][q], sacc);
-        sacc += __shfl_xor(sacc, 16);
-        sacc += __shfl_xor(sacc, 32);
-        cs[ni] = sacc;
-    }
-    double* red = smem;
-    if (gq == 0) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++) red[wr * 256 + wc * 64 + ni * 16 + r] = cs[ni];
-    }
-    __syncthreads();
-    if (threadIdx.x < 256)
-        g.C[(int64_t)ti * g.ldc + col0 + threadIdx.x] = red[threadIdx.x] + red[256 + threadIdx.x];
-}
-
-int sweep_gemm_dma256_launch(gpry_ctx* ctx, const GemmArgs& g) {
-    if (g.M % BM || g.N % BN2 || g.K % BK) return gpry_fail(ctx, -1, "sweep_gemm_dma256: bad dims");
-    const int tiles_m = g.M / BM, tiles_n = g.N / BN2;
-    const int a = (g.tile_map >> 4) & 15, c = 5 - a;
-    if (c < 0) return gpry_fail(ctx, -1, "sweep_gemm_dma256: tile map exponent must be <= 5");
-    int64_t nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
-    int64_t ns = (nsi * nsj + 7) / 8 * 8;
-    hipLaunchKernelGGL(sweep_gemm_dma256_kernel, dim3((unsigned)(ns * 32)), dim3(512), 0, ctx->stream, g);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------
-// Variant 3: the 128 x 128 / 4-wave tile of variant 1 with an explicit software pipeline.
+// The 128 x 128 / 4-wave tile with an explicit software pipeline.
 // The compiler treats a pending LDS-DMA as a "flat" access and therefore turns every wait on
 // a fragment read into s_waitcnt lgkmcnt(0), placed right behind the newest ds_read: the
 // MFMA pipe drains while the wave sits out the LDS latency, once per k-step.  Here the
@@ -360,62 +96,30 @@ __device__ __forceinline__ void mma_row(v4d (&acc)[4][4], const Frag& f, int mi)
     acc[mi][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f.b3, acc[mi][3], 0, 0, 0);
 }
 
-// DIAG build: s_memtime stamps around the slab synchronisation (they cost an extra
-// lgkmcnt(0) each, so the run is slower; the shares are what matters): g.diag[0] += cycles in
-// the vmcnt/lgkmcnt wait, [1] += cycles in s_barrier, [2] += cycles of the whole slab step,
-// [3] += wave lifetime in 100-MHz ticks, [5] += wave-slabs, [4] += wave-tiles.
-template <bool DIAG, bool PERSIST>
+// One workgroup per tile.  XCD-aware block map: blocks b, b + 8, ... share an XCD (round-robin dispatch), 64 consecutive
+// slots of an XCD form one (2^ta x 64 / 2^ta) super-tile (ta = bits 4..7 of g.tile_map: 8 row tiles of V x 8 candidate tiles)
+// so that the V row panels and K*^T column panels of a super-tile are served by that XCD's L2; super-tiles are ordered by
+// descending row index (longest k first).
 __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double smem[2 * BUF_DOUBLES];
-    __shared__ int s_next;
     const int M = g.M, N = g.N, K = g.K;
     const int tiles_m = M / BM, tiles_n = N / BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 15, gq = lane >> 4;
-    unsigned long long dsum0 = 0, dsum1 = 0, dsum2 = 0, tprev = 0, nslab_sum = 0, ntile = 0;
-    unsigned long long rstart = 0;
-    if (DIAG) rstart = __builtin_amdgcn_s_memrealtime();
 
-    // Persistent workgroups: the grid is exactly the number of resident slots (8 XCDs x
-    // slots per XCD); a workgroup takes its first tile from its block index and every further
-    // one from its XCD's ticket counter g.sched[xcd] (fetched at the start of the current
-    // tile, so the atomic's latency is hidden).  The hardware dispatcher hands out workgroups
-    // in order and round-robin over the shader engines, which left 5 % of the wave slots empty
-    // when every tile was its own workgroup (tiles differ 32x in length).
-    const int xcd = blockIdx.x & 7;
+    const int vx = blockIdx.x & 7;                       // XCD
     const int ta = (g.tile_map >> 4) & 15, tc = 6 - ta;
     const int nsi = (tiles_m + (1 << ta) - 1) >> ta, nsj = (tiles_n + (1 << tc) - 1) >> tc;
-    const int q_end = ((nsi * nsj + 7) / 8) * 64;       // tickets per XCD
-    int q = blockIdx.x >> 3;
-    int vx = xcd, hop = 0;      // queue being served: the own XCD's first, the others' leftovers last
-  while (true) {
-    if (q >= q_end) {
-        // this queue is exhausted: help the next XCD with its tail (synchronous fetch, tail only)
-        if (!PERSIST || ++hop == 8) break;
-        vx = (xcd + hop) & 7;
-        if (threadIdx.x == 0) s_next = atomicAdd(&g.sched[vx], 1);
-        __syncthreads();
-        q = s_next;
-        __syncthreads();
-        continue;
-    }
-    int q_next = 0;
-    if (PERSIST && threadIdx.x == 0) q_next = atomicAdd(&g.sched[vx], 1);
+    const int q = blockIdx.x >> 3;                       // position in the XCD's queue
     int ti, tj;
     bool valid, desc;
     {
         const int s = (q >> 6) * 8 + vx, within = q & 63;
-        // tile_map bit 8: candidate super-column outermost (the K*^T columns of a super-column stay in
-        // the Infinity Cache while the nsi row super-tiles that need them run back to back)
-        // (needs nsi | 8: a round of 8 super-tiles, one per XCD, then covers 8/nsi super-columns; the row
-        // index rotates with the round so that every XCD sees every row length)
-        const bool col_outer = ((g.tile_map >> 8) & 1) && nsi <= 8 && 8 % nsi == 0;
-        const int rnd = s >> 3;
-        int si = col_outer ? nsi - 1 - ((vx % nsi + rnd) % nsi) : nsi - 1 - s / nsj;
-        int sj = col_outer ? rnd * (8 / nsi) + vx / nsi : s % nsj;
+        int si = nsi - 1 - s / nsj;
+        int sj = s % nsj;
         int rowin = within >> tc;
-        // tile_map bit 9: alternating k walk.  The 64 tiles of a super-tile fill the 64 slots of an XCD, and the
+        // Alternating k walk.  The 64 tiles of a super-tile fill the 64 slots of an XCD, and the
         // eight tiles of a row tile run in lockstep (equal length), so the V panel is fetched once per XCD; the K*^T
         // panel is shared across the eight ROW tiles only while these sit at the same k, and row tiles differ by
         // eight slabs in length.  A super-tile whose tiles start together and walk k upwards is aligned and frees its
@@ -425,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
         // XCD alternate between two adjacent super-rows: odd positions walk down with their rows reversed.  The
         // direction is a function of the row tile alone, so a candidate's bits do not depend on where its
         // column falls in a launch (sharded = unsharded).
-        const bool alt = (g.tile_map >> 9) & 1;
-        if (alt && !col_outer && !(nsi & 1) && (nsj & 7) == 0) {
+        const bool alt = true;
+        if (!(nsi & 1) && (nsj & 7) == 0) {
             const int n = q >> 6, per_pair = nsj >> 2;        // 2 super-rows x nsj/8 super-tiles per XCD
             const int pair = n / per_pair, n2 = n - pair * per_pair, odd = n2 & 1;
             si = nsi - 1 - 2 * pair - odd;
@@ -440,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
     }
     if (valid) {
     const int row0 = ti * BM, col0 = tj * BN;
-    const int kend = ((g.tile_map >> 10) & 1) ? K : min(K, row0 + BM);   // bit 10 (experiments only): every row tile walks all of K
+    const int kend = min(K, row0 + BM);   // V is lower triangular
     const int nslab = kend / BK;          // multiple of 8
     const int kfirst = desc ? (nslab - 1) * BK : 0, kstep = desc ? -BK : BK;
 
@@ -498,11 +202,6 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
 
     Frag f0, f1;
     load_frag<0, 0>(f0, addrA[0], addrB);
-    if (DIAG) {
-        wait_frag<0>(f0);
-        tprev = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
 
 #define SLAB_STEP(BUF, S)                                                                    \
     {                                                                                        \
@@ -522,21 +221,9 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
         mma_frag(acc, f0);                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                   \
         /* every wave holds its last fragments of slab S; slab S+1 has landed everywhere */  \
-        if (DIAG) {                                                                          \
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();                      \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 \
-            wait_frag<0>(f1);                                                                \
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();                      \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
-            __builtin_amdgcn_s_barrier();                                                    \
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();                      \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
-            dsum0 += t1 - t0; dsum1 += t2 - t1; dsum2 += t0 - tprev; tprev = t0;             \
-        } else {                                                                             \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 \
-            wait_frag<0>(f1);                                                                \
-            __builtin_amdgcn_s_barrier();                                                    \
-        }                                                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+        wait_frag<0>(f1);                                                                    \
+        __builtin_amdgcn_s_barrier();                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                   \
         /* branch-free tail: the last slabs re-fetch slab nslab-1 into the (dead) buffer and  \
            read fragments nobody uses, so that the DMA issue and the fragment reads of the    \
@@ -578,7 +265,6 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
         cs[ni] = sacc;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // trailing DMA / fragment reads
-    if (DIAG) { nslab_sum += nslab; ntile += 1; }
     __syncthreads();
     double* red = smem;
     if (gq == 0) {
@@ -589,44 +275,15 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
     if (threadIdx.x < 128)
         g.C[(int64_t)ti * g.ldc + col0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
     }  // valid
-    if (!PERSIST) break;
-    if (threadIdx.x == 0) s_next = q_next;
-    __syncthreads();      // also: everybody is done with `red` before the next tile's DMA
-    q = s_next;
-  }  // ticket loop
-    if (DIAG && g.diag != nullptr && lane == 0) {
-        atomicAdd(&g.diag[0], dsum0); atomicAdd(&g.diag[1], dsum1); atomicAdd(&g.diag[2], dsum2);
-        // [3]: lifetime of the wave in 100-MHz ticks (slot occupancy = sum / (slots * kernel time))
-        atomicAdd(&g.diag[3], __builtin_amdgcn_s_memrealtime() - rstart); atomicAdd(&g.diag[4], ntile);
-        atomicAdd(&g.diag[5], nslab_sum);
-    }
 }
 
-int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g0) {
-    GemmArgs g = g0;
+int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g) {
     if (g.M % BM || g.N % BN || g.K % BM) return gpry_fail(ctx, -1, "sweep_gemm_dma_sp: dims must be multiples of 128");
-    if (!ctx->dsched) GPRY_TRY(dev_alloc(ctx, &ctx->dsched, 64));
-    // resident slots: two 69.6-KB workgroups per CU (one if extra LDS is requested), 32 CUs per XCD
-    const int per_cu = (2 * (int)sizeof(double) * BUF_DOUBLES + g.extra_lds) * 2 <= 160 * 1024 ? 2 : 1;
-    const int slots = 32 * per_cu;
-    if (g.persist) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->dsched, slots, 8, ctx->stream));
-    g.sched = ctx->dsched;
-    const dim3 grid((unsigned)(8 * slots));
     const int tiles_m = g.M / BM, tiles_n = g.N / BN;
     const int a = (g.tile_map >> 4) & 15, c = 6 - a;
     const int64_t nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
-    const dim3 grid_all((unsigned)(((nsi * nsj + 7) / 8 * 8) * 64));
-    // default: one workgroup per tile (grid launch); persist=1: resident workgroups + tickets
-    // (keeps 97 % instead of 95 % of the wave slots filled but is ~1 % slower end to end: a lone
-    // workgroup already keeps the matrix pipe 90 % busy, and the chip is power-limited)
-    const size_t xl = (size_t)g.extra_lds;
-    if (g.persist) {
-        if (g.diag) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<true, true>), grid, dim3(256), xl, ctx->stream, g);
-        else hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, true>), grid, dim3(256), xl, ctx->stream, g);
-    } else {
-        if (g.diag) hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<true, false>), grid_all, dim3(256), xl, ctx->stream, g);
-        else hipLaunchKernelGGL((sweep_gemm_dma_sp_kernel<false, false>), grid_all, dim3(256), xl, ctx->stream, g);
-    }
+    const dim3 grid((unsigned)(((nsi * nsj + 7) / 8 * 8) * 64));
+    hipLaunchKernelGGL(sweep_gemm_dma_sp_kernel, grid, dim3(256), 0, ctx->stream, g);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

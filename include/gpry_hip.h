@@ -73,31 +73,41 @@ int gpry_ctx_create(int device, gpry_ctx** out);
 int gpry_ctx_destroy(gpry_ctx* ctx);
 const char* gpry_last_error(gpry_ctx* ctx); /* ctx may be NULL: last global error */
 int gpry_ctx_sync(gpry_ctx* ctx);
-/* option keys: "chol" = 0 hand-written MFMA Cholesky (default), 1 rocSOLVER dpotrf/dtrtri
- *              "sweep_chunk" = candidates per sweep chunk (default 32768)
- *              "timing" = 0/1 per-stage HIP-event timers (gpry_timing_get); off by default, switched on by
- *                         gpry_timing_reset
- *              "predict_split" = 0/1 split-K contraction for gpry_predict batches of 5 ... a few thousand points
- *              "chol_overlap" = 0/1 trailing-update tiles ride in the Cholesky panel launches (default 1, Np <= 7168)
- *              "factor_pipeline" = 0/1 V = L^-1 is queued phase by phase on a second stream underneath the
- *                                  Cholesky panel chain (default 1, from "factor_pipeline_min" = 4096 on; bit-identical)
- *              "gemm_streamk" = largest Np at which the top levels of V = L^-1 and K^-1 = V^T V run as stream-K
- *                               launches (default 5632; 0 = off)
- *              "topk_host" = largest pool that gpry_sweep_topk selects on the host from one kernel's records
- *                            (default 16384; 0 = always the device radix select)
- *              "lml_small" = 0/1 gpry_lml of N <= 128, d <= 16 in ONE launch of one workgroup (default 1; the factor of
- *                            such an evaluation is not kept for gpry_factorize)
- *              "lml_batch" = largest padded training-set size (multiple of 128) at which gpry_lml_batch runs all its thetas
- *                            through ONE chain of launches (default 2048; 0 = one after another), "lml_batch_mb" = upper limit
- *                            of the scratch arena of such a batch in MiB (default 16384; longer batches go in chunks)
- *              "predict_gates" = 0/1 gpry_predict applies the gates of gpry_set_gates itself (default 0)
- *              "predict_serve" = 0/1 mean-only gpry_predict of <= 8 points is answered by a RESIDENT kernel (no
- *                                launch per call; default 1), "serve_idle_us" = how long that kernel waits for the
- *                                next request before it leaves (default 2000)
- * Everything else is an A/B switch of the measurements quoted in DESIGN.md (defaults are the
- * measured best): "sweep_dma" 0..3, "sweep_persist", "sweep_overlap", "sweep_tilemap", "sweep_altwalk", "sweep_colouter", "gemm_small", "trtri_diag128", "trtri_clear", "chol_outer",
- * "chol_lookahead", "chol_overlap_max", "chol_caps", "split_k", "gemm_dma", "syrk_lds", "lauum_lds", "lauum_split",
- * "trtri_split_cap", "kb_tile", "predict_small", "lml_cache", "factor_pipeline_spine".  Unknown keys return -1.
+/* Options (all of them; unknown keys and values outside the stated range return -1).  One comparator is kept per stage --
+ * rocSOLVER for the factorisation ("chol"), the schedule with separate trailing launches for the fused Cholesky
+ * ("chol_overlap"), the register-staged GEMM engine for the LDS-DMA one ("gemm_dma") --, the variants that lost their A/B
+ * runs in earlier rounds are gone (profiles/HISTORY.md keeps their numbers).
+ *   measurement
+ *     "timing" 0/1            per-stage HIP-event timers (gpry_timing_get); off by default, switched on by gpry_timing_reset
+ *   factorisation (gpry/gpr.py:1453-1465)
+ *     "chol" 0/1              0 (default): hand-written MFMA Cholesky + V = L^-1; 1: rocSOLVER dpotrf / dtrtri (comparator)
+ *     "chol_overlap" 0/1      1 (default): trailing-update tiles ride in the Cholesky panel launches; 0: separate trailing
+ *                             launches (the production schedule above "chol_overlap_max"; bit-identical factors below it)
+ *     "chol_overlap_max"      largest padded size for the riding tiles (0 = default 7168)
+ *     "factor_pipeline" 0/1   V = L^-1 is queued phase by phase on a second stream underneath the Cholesky panel chain
+ *                             (default 1; bit-identical), from "factor_pipeline_min" padded rows on (default 4096)
+ *     "gemm_dma" 0/1          1 (default): LDS-DMA staged, software-pipelined GEMM engine for the sweep contraction and the
+ *                             128-aligned products of the factor chain; 0: register-staged engine (comparator)
+ *     "gemm_streamk"          largest padded size at which the top levels of V = L^-1 and K^-1 = V^T V run as stream-K
+ *                             launches (default 5632; 0 = off)
+ *     "gemm_small"            launches of at most this many 128 x 128 tiles use 64 x 64 tiles instead (default 32; 0 = never)
+ *   objective (sklearn:_gpr.py:574-652)
+ *     "lml_small" 0/1         gpry_lml of N <= 128, d <= 16 in ONE launch of one workgroup (default 1; the factor of such an
+ *                             evaluation is not kept for gpry_factorize)
+ *     "lml_cache" 0/1         gpry_factorize adopts the factor of the last gpry_lml when theta is the same (default 1)
+ *     "lml_batch"             largest padded size at which gpry_lml_batch runs all its thetas through ONE chain of launches
+ *                             (default 2048; 0 = one after another)
+ *     "lml_batch_mb"          upper limit of the scratch arena of such a batch in MiB (default 16384; longer batches go in chunks)
+ *   predict / sweep (gpry/gpr.py:1022-1273, gpry/gp_acquisition.py:971-1108)
+ *     "sweep_chunk"           candidates per sweep chunk (default 32768, rounded up to a multiple of 1024)
+ *     "topk_host"             largest pool that gpry_sweep_topk selects on the host from one kernel's records
+ *                             (default 16384; 0 = always the device radix select)
+ *     "predict_small"         mean-only gpry_predict of at most this many points is one fused launch (default 2048)
+ *     "predict_split" 0/1     split-K contraction for gpry_predict batches of 5 ... a few thousand points (default 1)
+ *     "predict_gates" 0/1     gpry_predict applies the gates of gpry_set_gates itself (default 0; the Python mirror sets 1)
+ *     "predict_serve" 0/1     mean-only gpry_predict of <= 8 points is answered by a RESIDENT kernel (no launch per call;
+ *                             default 1); "serve_idle_us" = how long that kernel waits for the next request before it
+ *                             leaves (10 ... 1000000, default 2000)
  * The environment variable GPRY_HIP_OPTIONS="key=value,key=value" applies options to every context the process
  * creates (gpry_ctx_create fails on an unknown key or a malformed entry). */
 int gpry_ctx_set_option(gpry_ctx* ctx, const char* key, int64_t value);
@@ -346,10 +356,6 @@ int gpry_debug_gemm(gpry_ctx* ctx, const double* A, const double* B, double* C, 
  * incl. the edge cases sigma <= sigma_n and mu = -inf (-> -inf). */
 int gpry_debug_logexp(gpry_ctx* ctx, const double* mu, const double* sigma, int64_t n, double zeta,
                       double baseline, double sigma_n, double* acq);
-
-/* Diagnostic build of the sweep GEMM (option "sweep_diag"=1): per-phase s_memtime sums
- * [issue loads, mfma block, vmcnt wait, lds store, barrier, slab count]; reset != 0 zeroes them. */
-int gpry_debug_read_diag(gpry_ctx* ctx, uint64_t out[6], int reset);
 
 #ifdef __cplusplus
 }

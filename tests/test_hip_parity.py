@@ -437,31 +437,6 @@ def test_rccl_communicator_single_rank(dev):
     comm.close()
 
 
-def test_cholesky_with_concurrent_trailing_update_is_bit_identical(dev):
-    """The look-ahead schedule (trailing update on a second stream underneath the next panel)
-    must reproduce the in-order factor bit for bit.  Regression test for a race it exposed:
-    the diagonal workgroup of a panel step used to overwrite D with its factor while late
-    workgroups of the same launch were still reading D."""
-    N, d = 8192, 20
-    rng = np.random.default_rng(5)
-    X = rng.uniform(0, 1, (N, d))
-    dev.set_train(X, rng.standard_normal(N), np.full(N, 1e-4))
-    dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
-    try:
-        dev.set_option("chol_outer", 128)          # same blocking on both sides (the default is 256 here)
-        dev.set_option("chol_lookahead", 0)
-        assert dev.factorize() == 0
-        L0 = np.tril(dev.get_factor(want_V=False, want_alpha=False)[0])
-        dev.set_option("chol_lookahead", 1)
-        for _ in range(2):
-            assert dev.factorize() == 0
-            L1 = np.tril(dev.get_factor(want_V=False, want_alpha=False)[0])
-            assert np.array_equal(L0, L1)
-    finally:
-        dev.set_option("chol_lookahead", 0)
-        dev.set_option("chol_outer", 0)
-
-
 @pytest.mark.parametrize("N,d,kid", [(60, 2, 0), (300, 5, 3), (1100, 7, 1), (2500, 3, 2)])
 def test_one_point_call_equals_predict_plus_predict_grad(N, d, kid):
     """gpry_predict_point (mean, std and both x-gradient contractions of ONE point in one call: the acquisition
@@ -827,12 +802,12 @@ def test_split_k_contraction_of_small_batches_equals_the_one_pass_contraction(de
 
 
 @pytest.mark.parametrize("N", [2048, 2300, 4096])
-def test_sweep_with_alternating_k_walk_is_chunking_independent_and_matches_the_upward_walk(dev, N):
+def test_sweep_with_alternating_k_walk_is_chunking_independent(dev, N):
     """The super-tiles of an XCD alternate the direction of their k walk so that the row tiles of a super-tile sit at
     the same k and share the K*^T panel in L2.  The direction is a function of the row tile
     alone: the bits of a candidate's sigma must not depend on the chunking (which moves its column inside a launch and
-    switches between the paired and the plain super-tile order), the mean is untouched, and against the upward walk the
-    variance moves by rounding only; both agree with the oracle."""
+    switches between the paired and the plain super-tile order), the mean is untouched, and against the register-staged
+    engine (``gemm_dma`` = 0: every tile walks k upwards) the variance moves by rounding only; both agree with the oracle."""
     d, M = 6, 21000
     bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M, seed=41)
     m = orc.OracleGPR(bounds, kernel_id=3)
@@ -843,19 +818,19 @@ def test_sweep_with_alternating_k_walk_is_chunking_independent_and_matches_the_u
     C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
     res = {}
     try:
-        for alt in (1, 0):
+        for dma in (1, 0):
             for chunk in (8192, 5120, 1024):
-                dev.set_option("sweep_altwalk", alt)
+                dev.set_option("gemm_dma", dma)
                 dev.set_option("sweep_chunk", chunk)
                 out = dev.sweep_logexp(Xc, 0.1, 0.0, 1e-2, want=("y", "sigma"))
-                res[alt, chunk] = (out["y"].copy(), out["sigma"].copy())
+                res[dma, chunk] = (out["y"].copy(), out["sigma"].copy())
     finally:
-        dev.set_option("sweep_altwalk", 1)
+        dev.set_option("gemm_dma", 1)
         dev.set_option("sweep_chunk", 32768)
-    for alt in (1, 0):
+    for dma in (1, 0):
         for chunk in (5120, 1024):
-            np.testing.assert_array_equal(res[alt, chunk][1], res[alt, 8192][1])
-            np.testing.assert_array_equal(res[alt, chunk][0], res[alt, 8192][0])
+            np.testing.assert_array_equal(res[dma, chunk][1], res[dma, 8192][1])
+            np.testing.assert_array_equal(res[dma, chunk][0], res[dma, 8192][0])
     np.testing.assert_array_equal(res[1, 8192][0], res[0, 8192][0])
     assert np.max(np.abs(res[1, 8192][1] ** 2 - res[0, 8192][1] ** 2)) <= 1e-13 * C
     rm, rs = m.predict(Xc[:3000], return_std=True)
@@ -967,12 +942,10 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
     theta = np.log(np.array([3.0, 0.4, 0.5, 0.6, 0.7]))
     dev.set_theta(3, theta)
     try:
-        dev.set_option("chol_overlap", 0)
-        dev.set_option("chol_outer", 128)
+        dev.set_option("chol_overlap", 0)           # separate trailing launches, outer block 128 (up to Np = 7168)
         assert dev.factorize() == 0
         L0, V0, a0 = dev.get_factor()
         lml0 = dev.lml(theta, True)
-        dev.set_option("chol_outer", 0)
         dev.set_option("chol_overlap", 1)
         for _ in range(2):
             assert dev.factorize() == 0
@@ -989,15 +962,13 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
             alpha = np.full(N, 1e-5)
             alpha[N - 7] = alpha[N // 3] = -1e-3
             infos = []
-            for ov, outer in ((0, 128), (1, 0)):
+            for ov in (0, 1):
                 dev.set_option("chol_overlap", ov)
-                dev.set_option("chol_outer", outer)
                 dev.set_train(Xb, y, alpha)
                 dev.set_theta(3, theta)
                 infos.append(dev.factorize())
             assert infos[0] == infos[1] and infos[0] > 0
     finally:
-        dev.set_option("chol_outer", 0)
         dev.set_option("chol_overlap", 1)
 
 

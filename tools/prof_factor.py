@@ -18,14 +18,15 @@ theta = np.log(np.array([4.0] + [0.3] * d))
 dev.set_theta(3, theta)
 dev.factorize()
 L0 = dev.get_factor()[0]
-for la in ((128, 256, 512) if len(sys.argv) > 4 else (0,)):
-    dev.set_option("chol_outer", la)
+for ov in ((1, 0) if len(sys.argv) > 4 else (1,)):      # 4th argument: also the schedule with separate trailing launches
+    dev.set_option("chol_overlap", ov)
     dev.timing_reset()
     for _ in range(reps):
         assert dev.factorize() == 0
         lml = dev.lml(theta, True)
     same = np.array_equal(np.tril(dev.get_factor()[0]), np.tril(L0))
-    print(f"chol_outer={la}: factor bit-identical to the first one: {same}; lml {lml[0]:.12g}")
+    print(f"chol_overlap={ov}: factor bit-identical to the first one: {same}; lml {lml[0]:.12g}")
     for k in ("kernel_build", "potrf", "trtri", "lauum", "lml_traces"):
         ms, n = dev.timing(k)
         print(f"  {k}: {ms / max(n, 1) * 1e3:.1f} us avg over {n}")
+dev.set_option("chol_overlap", 1)

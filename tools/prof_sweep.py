@@ -10,21 +10,14 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 131072
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 32768
-tilemap = int(sys.argv[5]) if len(sys.argv) > 5 else 3
-dma = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-kskew = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+dma = int(sys.argv[5]) if len(sys.argv) > 5 else 1       # 0: the register-staged comparator ("gemm_dma" = 0)
 rng = np.random.default_rng(0)
 X = rng.uniform(0, 1, (N, d))
 y = rng.standard_normal(N)
 Xc = rng.uniform(0, 1, (M, d))
 dev = _lib.Device(0)
 dev.set_option("sweep_chunk", chunk)
-dev.set_option("sweep_tilemap", tilemap)
-dev.set_option("sweep_dma", dma)
-dev.set_option("sweep_kskew", kskew)
-dev.set_option("sweep_persist", int(os.environ.get("GPRY_SWEEP_PERSIST", "0")))
-dev.set_option("sweep_altwalk", int(os.environ.get("GPRY_SWEEP_ALTWALK", "0")))
-dev.set_option("sweep_colouter", int(os.environ.get("GPRY_SWEEP_COLOUTER", "0")))
+dev.set_option("gemm_dma", dma)
 dev.set_train(X, y, np.full(N, 1e-4))
 dev.set_theta(3, np.log(np.array([4.0] + [0.3] * d)))
 assert dev.factorize() == 0
