@@ -99,6 +99,8 @@ struct gpry_ctx {
         double* dXc = nullptr; uint8_t* dmask = nullptr;
         double *dy = nullptr, *dsig = nullptr, *dacq = nullptr;
     } pr;
+    double* dXcs = nullptr;    // dsel x chunk: the candidates of the current chunk, scaled, coordinate-major (launch_cross_build)
+    int64_t xcs_cap = 0;
     double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
     int64_t kst_cap = 0;       // doubles allocated
     double* dG = nullptr;      // Np x dpad: d k(x, X_j)/dx of the last gpry_predict_grad

@@ -200,7 +200,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
                     ctx->dsig_all, ctx->dacq_all, ctx->dKst, ctx->dpart, ctx->dkeys, ctx->dhist,
                     ctx->dcand, ctx->dsel, ctx->dU, ctx->dXkb, ctx->dkbout, ctx->pr.dXc, ctx->pr.dmask,
                     ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq, ctx->dG,
-                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit, ctx->dbord, ctx->barena};
+                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit, ctx->dbord, ctx->barena, ctx->dXcs};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->hbres) (void)hipHostFree(ctx->hbres);

@@ -90,15 +90,21 @@ __global__ __launch_bounds__(256, 6) void kernel_train_q_kernel(
     const double* __restrict__ Xs = bset(Xs_, (int)blockIdx.z, bstride);
     double* __restrict__ K = bset(K_, (int)blockIdx.z, bstride);
     if (bpar) kp.C = bset(bpar, (int)blockIdx.z, bstride)[0];
-    const int dp = kp.dpad;
-    double* Xi = sm;             // [dp][TS]
-    double* Xj = sm + dp * TS;   // [dp][TS]
+    // Coordinates of the 64 rows and the 64 columns, row-major as they lie in memory, row stride dp + 2 doubles: staged with
+    // 16-byte loads and stores (whole 128-byte lines in, no bank conflicts), read back as double2 over k -- the rows of the
+    // eight `ly` (columns of the eight `lx`) are 288 bytes apart = 8 banks, a conflict-free ds_read_b128.  (Round 3 staged
+    // them transposed, [k][row], with 8-byte loads and a 16-way bank conflict on every LDS write: with all 2080 tiles of
+    // N = 4096 resident at once, every workgroup sits in this prologue at the same time and nothing hides it -- 13 of the
+    // 38 us of a launch, tools/r04/time_kernel_build.py with the arithmetic and the stores switched off.)
+    const int dp = kp.dpad, ldx = dp + 2, dp2 = dp >> 1;
+    double* Xi = sm;              // [TS][ldx]
+    double* Xj = sm + TS * ldx;   // [TS][ldx]
     int bi, bj; tri_decode(blockIdx.x, &bi, &bj);
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, lx = lane & 7, ly = lane >> 3;
-    for (int e = t; e < TS * dp; e += NT) {
-        int row = e / dp, k = e - row * dp;
-        Xi[k * TS + row] = Xs[((int64_t)bi * TS + row) * dp + k];
-        Xj[k * TS + row] = Xs[((int64_t)bj * TS + row) * dp + k];
+    for (int e = t; e < TS * dp2; e += NT) {
+        const int row = e / dp2, k2 = (e - row * dp2) * 2;
+        *reinterpret_cast<double2*>(Xi + row * ldx + k2) = *reinterpret_cast<const double2*>(Xs + ((int64_t)bi * TS + row) * dp + k2);
+        *reinterpret_cast<double2*>(Xj + row * ldx + k2) = *reinterpret_cast<const double2*>(Xs + ((int64_t)bj * TS + row) * dp + k2);
     }
     __syncthreads();
     const int r0 = 32 * (w / WPR) + 2 * ly, c0 = 32 * (w % WPR) + 2 * lx;
@@ -107,17 +113,26 @@ __global__ __launch_bounds__(256, 6) void kernel_train_q_kernel(
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) r2[a][b] = 0.0;
-    for (int k = 0; k < dp; k++) {
-        const double2 i0 = *reinterpret_cast<const double2*>(Xi + k * TS + r0);
-        const double2 i1 = *reinterpret_cast<const double2*>(Xi + k * TS + r0 + 16);
-        const double2 j0 = *reinterpret_cast<const double2*>(Xj + k * TS + c0);
-        const double2 j1 = *reinterpret_cast<const double2*>(Xj + k * TS + c0 + 16);
-        const double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
+    const double* pi = Xi + r0 * ldx;
+    const double* pj = Xj + c0 * ldx;
+    for (int k = 0; k < dp; k += 2) {       // k ascending, one multiply-add per coordinate: the sums of the transposed staging, bit for bit
+        double2 xi[4], xj[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            xi[a] = *reinterpret_cast<const double2*>(pi + ((a >> 1) * 16 + (a & 1)) * ldx + k);
+            xj[a] = *reinterpret_cast<const double2*>(pj + ((a >> 1) * 16 + (a & 1)) * ldx + k);
+        }
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) { const double df = xi[a] - xj[b]; r2[a][b] = fma(df, df, r2[a][b]); }
+            for (int b = 0; b < 4; b++) { const double df = xi[a].x - xj[b].x; r2[a][b] = fma(df, df, r2[a][b]); }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) { const double df = xi[a].y - xj[b].y; r2[a][b] = fma(df, df, r2[a][b]); }
     }
+    // only the tiles on the diagonal and on the padded edge have entries that are not C k(r)
+    const bool special = bi == bj || ((int64_t)bi + 1) * TS > kp.N;
 #pragma unroll
     for (int ap = 0; ap < 2; ap++) {
         double v[2][4];
@@ -125,11 +140,13 @@ __global__ __launch_bounds__(256, 6) void kernel_train_q_kernel(
         for (int a2 = 0; a2 < 2; a2++)
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                const int64_t i = (int64_t)bi * TS + r0 + 16 * ap + a2;
-                const int64_t j = (int64_t)bj * TS + c0 + 16 * (b >> 1) + (b & 1);
-                double x = kp.C * corr_r2<KID>(r2[2 * ap + a2][b]);     // libm exp / sqrt: see below
-                if (i == j) x = kp.C + (add_noise ? noise[i < kp.N ? i : 0] : 0.0);
-                if (i >= kp.N || j >= kp.N) x = (i == j) ? 1.0 : 0.0;   // identity padding
+                double x = kp.C * corr_r2<KID>(r2[2 * ap + a2][b]);     // libm exp / sqrt: see above
+                if (special) {
+                    const int64_t i = (int64_t)bi * TS + r0 + 16 * ap + a2;
+                    const int64_t j = (int64_t)bj * TS + c0 + 16 * (b >> 1) + (b & 1);
+                    if (i == j) x = kp.C + (add_noise ? noise[i < kp.N ? i : 0] : 0.0);
+                    if (i >= kp.N || j >= kp.N) x = (i == j) ? 1.0 : 0.0;   // identity padding
+                }
                 v[a2][b] = x;
             }
 #pragma unroll
@@ -153,7 +170,7 @@ __global__ __launch_bounds__(256, 6) void kernel_train_q_kernel(
 int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
     KernParams kp = make_kp(ctx);
     const int64_t nbq = ctx->Np / 64, ntq = nbq * (nbq + 1) / 2;
-    const size_t smq = sizeof(double) * (size_t)(2 * ctx->dpad * 64);
+    const size_t smq = sizeof(double) * (size_t)(2 * 64 * (ctx->dpad + 2));
     const dim3 gq((unsigned)ntq, 1, (unsigned)ctx->bn);
 #define KQ(KID) hipLaunchKernelGGL((kernel_train_q_kernel<KID>), gq, dim3(256), smq, ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, \
                                    add_noise, ctx->bpar, ctx->bstride)
@@ -208,17 +225,36 @@ int launch_kernel_rows(gpry_ctx* ctx, int64_t row0, int k, int64_t ldk, double* 
 // registers, the training chunk sits in LDS and is read wave-uniformly (broadcast).
 // Output Kst[j*ldk + m] = C k(x*_m, x_j) (rows j >= N are zero) and the per-chunk mean
 // partial  mean_part[jc*mc + m] = sum_{j in chunk} alpha_[j] * Kst[j][m].
+// The candidates of a chunk, mapped to the unit cube and divided by the length scales ONCE, coordinate-major:
+// Xcs[k * ldm + ml] = ((x_k - lo_k) / span_k) / l_k (true divisions, in this order, as sklearn and the preprocessor do;
+// zeros beyond the pool and beyond d).  Every one of the Np / 128 row-chunk workgroups of cross_build_kernel used to redo
+// these 2 d FP64 divisions per candidate from row-major coordinates (one 128-byte line per lane and load).
+__global__ __launch_bounds__(256) void scale_cand_kernel(const double* __restrict__ Xc, int64_t M, int64_t m0, int64_t mc, int d, int dsel,
+                                                         int has_aff, AffParams ap, double* __restrict__ Xcs, int64_t ldm) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (ml, k): k fastest -> the loads are whole lines
+    if (idx >= mc * dsel) return;
+    const int64_t ml = idx / dsel;
+    const int k = (int)(idx - ml * dsel);
+    const int64_t m = m0 + ml;
+    double v = 0.0;
+    if (k < d && m < M) {
+        v = Xc[m * d + k];
+        if (has_aff) v = (v - ap.lo[k]) / ap.span[k];
+        v = v / ap.ls[k];
+    }
+    Xcs[(int64_t)k * ldm + ml] = v;
+}
+
 template <int DP, int KID>
 __global__ __launch_bounds__(256) void cross_build_kernel(
-    const double* __restrict__ Xc, int64_t M, int64_t m0, int64_t mc,
+    const double* __restrict__ Xcs, int64_t ldm, int64_t mc,
     const double* __restrict__ Xs, const double* __restrict__ alpha_,
     double* __restrict__ Kst, int64_t ldk, double* __restrict__ mean_part,
-    KernParams kp, AffParams ap) {
+    KernParams kp) {
     __shared__ double Xl[128 * DP];
     __shared__ double al[128];
     const int t = threadIdx.x;
     const int64_t ml = (int64_t)blockIdx.x * 256 + t;   // local candidate index in the chunk
-    const int64_t m = m0 + ml;
     const int jc = blockIdx.y;
     for (int e = t; e < 128 * DP; e += 256) {
         int row = e / DP, k = e - row * DP;
@@ -227,15 +263,7 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
     if (t < 128) al[t] = alpha_ ? alpha_[jc * 128 + t] : 0.0;
     double xs[DP];
 #pragma unroll
-    for (int k = 0; k < DP; k++) {
-        double v = 0.0;
-        if (k < kp.d && m < M) {
-            v = Xc[m * kp.d + k];
-            if (kp.has_aff) v = (v - ap.lo[k]) / ap.span[k];
-            v = v / ap.ls[k];
-        }
-        xs[k] = v;
-    }
+    for (int k = 0; k < DP; k++) xs[k] = Xcs[(int64_t)k * ldm + ml];       // (the buffer covers the padded chunk)
     __syncthreads();
     double macc = 0.0;
     const bool in_chunk = ml < mc;
@@ -372,8 +400,18 @@ int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, 
     dim3 grid((unsigned)((mc + 255) / 256), (unsigned)(ctx->Np / 128));
     int64_t M = ctx->sw_M;
     if (ctx->d > 32) return gpry_fail(ctx, -1, "d > 32 is not supported");
-#define CB2(DP, KID) hipLaunchKernelGGL((cross_build_kernel<DP, KID>), grid, dim3(256), 0, st, Xc, M, \
-                                        m0, mc, ctx->dXs, ctx->dalpha_, Kst, ldk, mean_part, kp, ap)
+    const int dsel = ctx->d <= 4 ? 4 : ctx->d <= 8 ? 8 : ctx->d <= 16 ? 16 : ctx->d <= 24 ? 24 : 32;
+    const int64_t ldm = round_up(mc, 256);
+    if (dsel * ldm > ctx->xcs_cap) {
+        if (ctx->dXcs) GPRY_TRY(dev_free(ctx, ctx->dXcs));
+        ctx->dXcs = nullptr; ctx->xcs_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dXcs, dsel * ldm));
+        ctx->xcs_cap = dsel * ldm;
+    }
+    hipLaunchKernelGGL(scale_cand_kernel, dim3((unsigned)((ldm * dsel + 255) / 256)), dim3(256), 0, st, Xc, M, m0, ldm, ctx->d, dsel,
+                       kp.has_aff, ap, ctx->dXcs, ldm);
+#define CB2(DP, KID) hipLaunchKernelGGL((cross_build_kernel<DP, KID>), grid, dim3(256), 0, st, ctx->dXcs, ldm, \
+                                        mc, ctx->dXs, ctx->dalpha_, Kst, ldk, mean_part, kp)
 #define CB4(KID) { if (ctx->d <= 4) CB2(4, KID); else if (ctx->d <= 8) CB2(8, KID); \
                    else if (ctx->d <= 16) CB2(16, KID); else if (ctx->d <= 24) CB2(24, KID); else CB2(32, KID); }
     DISPATCH_KID(ctx->kernel_id, CB4)
