@@ -613,6 +613,9 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
     fp.clip_hi = ctx->tf.clip_hi; fp.zeta = zeta; fp.baseline = baseline; fp.sigma_n = sigma_n;
     fp.want_std = want_std; fp.want_acq = want_acq;
     ctx->sw_M = M;
+    // distances of the panel from the matrix pipe (cross_build_mfma_kernel; "cross_mfma" = 0: the difference form)
+    const bool fast_panel = ctx->opt_cross_mfma && !small_build;
+    if (fast_panel) GPRY_TRY(launch_cross_prepare(ctx));
     for (int64_t m0 = 0; m0 < M; m0 += chunk) {
         int64_t mc = (M - m0 < chunk) ? M - m0 : chunk;
         int64_t mcp = round_up(mc, 128);
@@ -622,6 +625,9 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
         if (small_build) {
             StageScope s(ctx, "cross_build");
             GPRY_TRY(launch_cross_build_small(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
+        } else if (fast_panel) {
+            StageScope s(ctx, "cross_build");
+            GPRY_TRY(launch_cross_build_mfma(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
         } else {
             StageScope s(ctx, "cross_build");
             GPRY_TRY(launch_cross_build(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));

@@ -101,6 +101,10 @@ struct gpry_ctx {
     } pr;
     double* dXcs = nullptr;    // dsel x chunk: the candidates of the current chunk, scaled, coordinate-major (launch_cross_build)
     int64_t xcs_cap = 0;
+    double* dYcs = nullptr;    // Np x dsel: centred scaled training rows of the MFMA panel build (launch_cross_prepare)
+    int64_t ycs_cap = 0;
+    double xcenter[GPRY_MAX_DIM] = {0};    // mean of the training rows per dimension (set_train): the centre both sides are shifted by
+    int opt_cross_mfma = 1;    // 1 (default): the sweep's cross-kernel panel takes its distances from the matrix pipe
     double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
     int64_t kst_cap = 0;       // doubles allocated
     double* dG = nullptr;      // Np x dpad: d k(x, X_j)/dx of the last gpry_predict_grad
@@ -278,6 +282,9 @@ int launch_kernel_rows(gpry_ctx* ctx, int64_t row0, int k, int64_t ldk, double* 
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
                        int64_t ldk, double* Kst, double* mean_part, int raw_affine,
                        hipStream_t st = nullptr);
+int launch_cross_prepare(gpry_ctx* ctx);               // centred scaled training rows for ...
+int launch_cross_build_mfma(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk, double* Kst, double* mean_part,
+                            int raw_affine);           // ... the panel with MFMA distances (sweep, large predict batches)
 int launch_cross_build_small(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk,
                              double* Kst, double* mean_part, int raw_affine);     // 4 x (Np/128) mean partials
 int launch_predict_mean_small(gpry_ctx* ctx, const double* Xc, int64_t M, int nsplit, double* part_out);

@@ -200,7 +200,7 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
                     ctx->dsig_all, ctx->dacq_all, ctx->dKst, ctx->dpart, ctx->dkeys, ctx->dhist,
                     ctx->dcand, ctx->dsel, ctx->dU, ctx->dXkb, ctx->dkbout, ctx->pr.dXc, ctx->pr.dmask,
                     ctx->pr.dy, ctx->pr.dsig, ctx->pr.dacq, ctx->dG,
-                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit, ctx->dbord, ctx->barena, ctx->dXcs};
+                    ctx->gate_sv, ctx->gate_coef, ctx->gate_trust, ctx->dsplit, ctx->dbord, ctx->barena, ctx->dXcs, ctx->dYcs};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->hbres) (void)hipHostFree(ctx->hbres);
@@ -241,6 +241,7 @@ const OptionSpec OPTIONS[] = {
     OPT_INT("gemm_dma", opt_gemm_dma, 0, 1, (void)0),
     OPT_INT("gemm_streamk", opt_gemm_streamk, 0, BIG, trtri_plan_free(c)),       // the plan holds the stream-K parts
     OPT_INT("gemm_small", opt_gemm_small, 0, BIG, c->lml_cache = false),
+    OPT_INT("cross_mfma", opt_cross_mfma, 0, 1, (void)0),
     OPT_INT("sweep_chunk", opt_sweep_chunk, 128, BIG, c->opt_sweep_chunk = round_up(c->opt_sweep_chunk, 1024)),
     OPT_INT("topk_host", opt_topk_host, 0, BIG, (void)0),
     OPT_INT("lml_small", opt_lml_small, 0, 1, c->lml_cache = false),
@@ -289,6 +290,11 @@ int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const doub
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     GPRY_TRY(ensure_capacity(ctx, N, d));
     hipStream_t st = ctx->stream;
+    for (int k = 0; k < d; k++) {       // centre of the MFMA panel build (kernel_build.hip: cross_build_mfma_kernel)
+        double s = 0.0;
+        for (int64_t i = 0; i < N; i++) s += X_[i * d + k];
+        ctx->xcenter[k] = s / (double)N;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dX, X_, sizeof(double) * N * d, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dy, 0, sizeof(double) * ctx->Np, st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dnoise, 0, sizeof(double) * ctx->Np, st));
@@ -494,11 +500,12 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
         HIP_TRY(ctx, hipMalloc((void**)&src, (size_t)n * 16));
         HIP_TRY(ctx, hipMalloc((void**)&dst, (size_t)n * 16));
         HIP_TRY(ctx, hipMemsetAsync(src, 1, (size_t)n * 16, ctx->stream));
-        hipLaunchKernelGGL(stream_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, src, dst, n);
+        // four workgroups per CU: the best copy shape of tools/r04/hbm_ceiling.hip (5.8 TB/s on 2 GB, 6.9 inside the Infinity Cache)
+        hipLaunchKernelGGL(stream_copy_kernel, dim3(1024), dim3(256), 0, ctx->stream, src, dst, n);
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         const int reps = 5;
         for (int r = 0; r < reps; r++)
-            hipLaunchKernelGGL(stream_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, src, dst, n);
+            hipLaunchKernelGGL(stream_copy_kernel, dim3(1024), dim3(256), 0, ctx->stream, src, dst, n);
         HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
         HIP_TRY(ctx, hipEventSynchronize(e1));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
@@ -609,11 +616,13 @@ extern "C" int gpry_microbench(gpry_ctx* ctx, int kind, int64_t bytes, double* v
         int64_t n = bytes / 16;
         double2* dst = nullptr;
         HIP_TRY(ctx, hipMalloc((void**)&dst, (size_t)n * 16));
-        hipLaunchKernelGGL(stream_fill_kernel, dim3(2048), dim3(256), 0, ctx->stream, dst, n, 1.0);
+        // one workgroup per CU, grid-stride: 6.5 TB/s on a 2-GB buffer where 8 workgroups per CU reach 4.6-4.7
+        // (tools/r04/hbm_ceiling.hip, profiles/r04_hbm_ceiling.md)
+        hipLaunchKernelGGL(stream_fill_kernel, dim3(256), dim3(256), 0, ctx->stream, dst, n, 1.0);
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         const int reps = 5;
         for (int r = 0; r < reps; r++)
-            hipLaunchKernelGGL(stream_fill_kernel, dim3(2048), dim3(256), 0, ctx->stream, dst, n, 2.0 + r);
+            hipLaunchKernelGGL(stream_fill_kernel, dim3(256), dim3(256), 0, ctx->stream, dst, n, 2.0 + r);
         HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
         HIP_TRY(ctx, hipEventSynchronize(e1));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));

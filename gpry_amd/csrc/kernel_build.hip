@@ -309,6 +309,170 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
     if (in_chunk && mean_part) mean_part[(int64_t)jc * mc + ml] = macc;
 }
 
+// ------------------------------------------------------------------------------------
+// The same panel with the distances on the matrix pipe (the NORA sweep and large predict batches; gpry/gpr.py:1179).
+// cross_build_kernel above is FP64-VALU-issue-bound: ~75 wave-instructions per (candidate, training row), 2 d of them the
+// differences and squares of the distance.  Here r^2 = |x|^2 + |y|^2 - 2 x.y with the dot products as
+// v_mfma_f64_16x16x4_f64 (d / 4 instructions per 16 x 16 block of pairs, issued beside the vector work of the other
+// waves): 3 vector instructions per pair instead of 2 d.  The expanded form cancels, so both sides are CENTRED first
+// (x - c, y - c with c = the mean of the training rows per dimension: distances do not change, the norms shrink to the
+// spread of the data): the absolute error of r^2 is ~4 eps (|x - c|^2 + |y - c|^2), i.e. 1e-14 ... 1e-12 relative in
+// C k(r) for length scales down to a hundredth of the box -- the posterior tolerances are 1e-8 (mean) and 1e-9 C
+// (variance).  The exact difference form stays for gpry_kernel_cross (K* itself is compared at 1e-13), the small
+// batches and the Kriging-believer registrations.
+// Workgroup = 128 training rows x 256 candidates as above; wave w owns candidates 64 w .. 64 w + 63 as four MFMA column
+// blocks; per 16 training rows (A operand from LDS) 4 x d/4 MFMAs give each lane 4 x 4 pairs: rows g + 4 q (g = lane >> 4),
+// candidate lane & 15 of each block, stored as 128-byte row segments.
+// Ycs: Np x DP centred scaled training rows (zero rows for the padding), row-major; Xcs: DP x ldm centred scaled candidates.
+template <int DP, int KID>
+__global__ __launch_bounds__(256) void cross_build_mfma_kernel(
+    const double* __restrict__ Xcs, int64_t ldm, int64_t mc,
+    const double* __restrict__ Ycs, const double* __restrict__ alpha_,
+    double* __restrict__ Kst, int64_t ldk, double* __restrict__ mean_part, KernParams kp) {
+    constexpr int S = DP + 2, KS = DP / 4;
+    __shared__ __attribute__((aligned(16))) double Yl[128 * S];
+    __shared__ double yn[128], al[128];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, r = lane & 15, g = lane >> 4;
+    const int jc = blockIdx.y;
+    const int64_t mb = (int64_t)blockIdx.x * 256 + 64 * w;      // first candidate of this wave (local index in the chunk)
+    for (int e = t; e < 128 * (DP / 2); e += 256) {
+        const int row = e / (DP / 2), k2 = (e - row * (DP / 2)) * 2;
+        *reinterpret_cast<double2*>(Yl + row * S + k2) = *reinterpret_cast<const double2*>(Ycs + ((int64_t)jc * 128 + row) * DP + k2);
+    }
+    if (t < 128) al[t] = alpha_ ? alpha_[jc * 128 + t] : 0.0;
+    // B operands: coordinate 4 kk + g of candidate r of block tl; |x - c|^2 of that candidate
+    double xb[4][KS], xn[4];
+#pragma unroll
+    for (int tl = 0; tl < 4; tl++) {
+        double s = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+            xb[tl][kk] = Xcs[(int64_t)(4 * kk + g) * ldm + mb + 16 * tl + r];
+            s = fma(xb[tl][kk], xb[tl][kk], s);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        xn[tl] = s;
+    }
+    __syncthreads();
+    if (t < 128) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < DP; k++) s = fma(Yl[t * S + k], Yl[t * S + k], s);
+        yn[t] = s;
+    }
+    __syncthreads();
+    const int64_t left = kp.N - (int64_t)jc * 128;
+    const int nvalid = left >= 128 ? 128 : (left > 0 ? (int)left : 0);      // training rows of this chunk (the rest: zero padding)
+    double macc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int j0 = 0; j0 < 128; j0 += 16) {
+        double a[KS], ynq[4], alq[4];
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) a[kk] = Yl[(j0 + r) * S + 4 * kk + g];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { ynq[q] = yn[j0 + g + 4 * q]; alq[q] = al[j0 + g + 4 * q]; }
+#pragma unroll
+        for (int tl = 0; tl < 4; tl++) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], xb[tl][kk], acc, 0, 0, 0);
+            const bool in_chunk = mb + 16 * tl + r < mc;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int jj = j0 + g + 4 * q;
+                double r2 = fma(-2.0, acc[q], xn[tl] + ynq[q]);
+                r2 = fmax(r2, 0.0);
+                double v = kp.C * corr_r2_fast<KID>(r2);
+                if (jj >= nvalid) v = 0.0;
+                macc[tl] = fma(alq[q], v, macc[tl]);
+                if (in_chunk) Kst[((int64_t)jc * 128 + jj) * ldk + mb + 16 * tl + r] = v;
+            }
+        }
+    }
+    if (mean_part) {
+#pragma unroll
+        for (int tl = 0; tl < 4; tl++) {
+            double s = macc[tl];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0 && mb + 16 * tl + r < mc) mean_part[(int64_t)jc * mc + mb + 16 * tl + r] = s;
+        }
+    }
+}
+// centred scaled training rows for cross_build_mfma_kernel: Ycs[i][k] = (X[i][k] - c_k) / l_k, zero rows / columns as padding
+__global__ __launch_bounds__(256) void center_train_kernel(const double* __restrict__ X, double* __restrict__ Ycs, int64_t N, int64_t Np, int d,
+                                                           int dsel, AffParams ap, AffParams cen) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Np * dsel) return;
+    const int64_t i = idx / dsel;
+    const int k = (int)(idx - i * dsel);
+    Ycs[idx] = (i < N && k < d) ? (X[i * d + k] - cen.lo[k]) / ap.ls[k] : 0.0;
+}
+// ... and the candidates: Xcs[k * ldm + ml] = ((x_k - lo_k) / span_k - c_k) / l_k
+__global__ __launch_bounds__(256) void center_cand_kernel(const double* __restrict__ Xc, int64_t M, int64_t m0, int64_t mc, int d, int dsel,
+                                                          int has_aff, AffParams ap, AffParams cen, double* __restrict__ Xcs, int64_t ldm) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= mc * dsel) return;
+    const int64_t ml = idx / dsel;
+    const int k = (int)(idx - ml * dsel);
+    const int64_t m = m0 + ml;
+    double v = 0.0;
+    if (k < d && m < M) {
+        v = Xc[m * d + k];
+        if (has_aff) v = (v - ap.lo[k]) / ap.span[k];
+        v = (v - cen.lo[k]) / ap.ls[k];
+    }
+    Xcs[(int64_t)k * ldm + ml] = v;
+}
+
+int launch_cross_prepare(gpry_ctx* ctx) {
+    const int dsel = ctx->d <= 4 ? 4 : ctx->d <= 8 ? 8 : ctx->d <= 16 ? 16 : ctx->d <= 24 ? 24 : 32;
+    if (ctx->Np * dsel > ctx->ycs_cap) {
+        if (ctx->dYcs) GPRY_TRY(dev_free(ctx, ctx->dYcs));
+        ctx->dYcs = nullptr; ctx->ycs_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dYcs, ctx->Np * dsel));
+        ctx->ycs_cap = ctx->Np * dsel;
+    }
+    AffParams ap = make_ap(ctx, false), cen;
+    for (int k = 0; k < GPRY_MAX_DIM; k++) { cen.ls[k] = 1.0; cen.span[k] = 1.0; cen.lo[k] = k < ctx->d ? ctx->xcenter[k] : 0.0; }
+    hipLaunchKernelGGL(center_train_kernel, dim3((unsigned)((ctx->Np * dsel + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dX, ctx->dYcs,
+                       ctx->N, ctx->Np, ctx->d, dsel, ap, cen);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// after launch_cross_prepare (same theta, same training set)
+int launch_cross_build_mfma(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk, double* Kst, double* mean_part,
+                            int raw_affine) {
+    hipStream_t st = ctx->stream;
+    KernParams kp = make_kp(ctx);
+    kp.has_aff = raw_affine && ctx->tf.has_x_affine;
+    AffParams ap = make_ap(ctx, kp.has_aff), cen;
+    for (int k = 0; k < GPRY_MAX_DIM; k++) { cen.ls[k] = 1.0; cen.span[k] = 1.0; cen.lo[k] = k < ctx->d ? ctx->xcenter[k] : 0.0; }
+    if (ctx->d > 32) return gpry_fail(ctx, -1, "d > 32 is not supported");
+    const int dsel = ctx->d <= 4 ? 4 : ctx->d <= 8 ? 8 : ctx->d <= 16 ? 16 : ctx->d <= 24 ? 24 : 32;
+    const int64_t ldm = round_up(mc, 256);
+    if (dsel * ldm > ctx->xcs_cap) {
+        if (ctx->dXcs) GPRY_TRY(dev_free(ctx, ctx->dXcs));
+        ctx->dXcs = nullptr; ctx->xcs_cap = 0;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dXcs, dsel * ldm));
+        ctx->xcs_cap = dsel * ldm;
+    }
+    hipLaunchKernelGGL(center_cand_kernel, dim3((unsigned)((ldm * dsel + 255) / 256)), dim3(256), 0, st, Xc, ctx->sw_M, m0, ldm, ctx->d, dsel,
+                       kp.has_aff, ap, cen, ctx->dXcs, ldm);
+    dim3 grid((unsigned)((mc + 255) / 256), (unsigned)(ctx->Np / 128));
+#define CM2(DP, KID) hipLaunchKernelGGL((cross_build_mfma_kernel<DP, KID>), grid, dim3(256), 0, st, ctx->dXcs, ldm, mc, ctx->dYcs, \
+                                        ctx->dalpha_, Kst, ldk, mean_part, kp)
+#define CM4(KID) { if (dsel == 4) CM2(4, KID); else if (dsel == 8) CM2(8, KID); else if (dsel == 16) CM2(16, KID); \
+                   else if (dsel == 24) CM2(24, KID); else CM2(32, KID); }
+    DISPATCH_KID(ctx->kernel_id, CM4)
+#undef CM4
+#undef CM2
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 // (Round 3, measured and removed: reading the training rows of a chunk with scalar loads -- constant address space,
 // s_load_dwordx16, SGPR operands of the v_add_f64 -- instead of broadcasting them from LDS: same bits, 11.2 vs 11.2 ms per
 // 1e6 candidates at N = 4096, d = 16 with Matern-5/2, 10.4 vs 9.0 ms with RBF, 2.5 vs 1.9 ms at N = 1024: the LDS pipe
