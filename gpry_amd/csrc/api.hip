@@ -614,7 +614,9 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
     fp.want_std = want_std; fp.want_acq = want_acq;
     ctx->sw_M = M;
     // distances of the panel from the matrix pipe (cross_build_mfma_kernel; "cross_mfma" = 0: the difference form)
-    const bool fast_panel = ctx->opt_cross_mfma && !small_build;
+    // (not for Matern-1/2: exp(-r) has a cusp at r = 0, where the rounding noise e of the expanded r^2 becomes sqrt(e) in r --
+    // 1e-7 in k for a candidate on a training point; the smoother kernels see e itself)
+    const bool fast_panel = ctx->opt_cross_mfma && !small_build && ctx->kernel_id != GPRY_MATERN12;
     if (fast_panel) GPRY_TRY(launch_cross_prepare(ctx));
     for (int64_t m0 = 0; m0 < M; m0 += chunk) {
         int64_t mc = (M - m0 < chunk) ? M - m0 : chunk;

@@ -38,7 +38,6 @@ struct gpry_ctx {
     int opt_gemm_small = 32;     // launches of at most this many 128 x 128 tiles run with 64 x 64 tiles (0: never)
     int64_t opt_predict_small = 2048;  // mean-only gpry_predict of at most this many points: one fused launch
     int opt_chol_overlap = 1;    // 1: trailing-update tiles ride in the panel launches (potrf_lower_overlap)
-    int64_t opt_chol_overlap_max = 0;   // largest Np for that schedule (0: 7168; measured: -10 % at 6144, -1 % at 7168, +3 % at 8192)
 
     // training set (transformed space)
     int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size

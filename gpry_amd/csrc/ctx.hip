@@ -235,7 +235,6 @@ const OptionSpec OPTIONS[] = {
     OPT_INT("timing", opt_timing, 0, 1, (void)0),
     OPT_INT("chol", opt_chol, 0, 1, c->lml_cache = false),
     OPT_INT("chol_overlap", opt_chol_overlap, 0, 1, (void)0),
-    OPT_INT("chol_overlap_max", opt_chol_overlap_max, 0, BIG, (void)0),
     OPT_INT("factor_pipeline", opt_factor_pipeline, 0, 1, (void)0),
     OPT_INT("factor_pipeline_min", opt_factor_pipeline_min, 0, BIG, (void)0),
     OPT_INT("gemm_dma", opt_gemm_dma, 0, 1, (void)0),

@@ -82,8 +82,7 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *   factorisation (gpry/gpr.py:1453-1465)
  *     "chol" 0/1              0 (default): hand-written MFMA Cholesky + V = L^-1; 1: rocSOLVER dpotrf / dtrtri (comparator)
  *     "chol_overlap" 0/1      1 (default): trailing-update tiles ride in the Cholesky panel launches; 0: separate trailing
- *                             launches (the production schedule above "chol_overlap_max"; bit-identical factors below it)
- *     "chol_overlap_max"      largest padded size for the riding tiles (0 = default 7168)
+ *                             launches (the production schedule above 7168 padded rows; bit-identical factors below)
  *     "factor_pipeline" 0/1   V = L^-1 is queued phase by phase on a second stream underneath the Cholesky panel chain
  *                             (default 1; bit-identical), from "factor_pipeline_min" padded rows on (default 4096)
  *     "gemm_dma" 0/1          1 (default): LDS-DMA staged, software-pipelined GEMM engine for the sweep contraction and the
@@ -100,6 +99,9 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *     "lml_batch_mb"          upper limit of the scratch arena of such a batch in MiB (default 16384; longer batches go in chunks)
  *   predict / sweep (gpry/gpr.py:1022-1273, gpry/gp_acquisition.py:971-1108)
  *     "sweep_chunk"           candidates per sweep chunk (default 32768, rounded up to a multiple of 1024)
+ *     "cross_mfma" 0/1        1 (default): the cross-kernel panel of sweeps and large predict batches takes its squared
+ *                             distances from the matrix pipe (centred coordinates, |x|^2 + |y|^2 - 2 x.y); 0: the difference
+ *                             form (comparator; gpry_kernel_cross, the small batches and Matern-1/2 always use it)
  *     "topk_host"             largest pool that gpry_sweep_topk selects on the host from one kernel's records
  *                             (default 16384; 0 = always the device radix select)
  *     "predict_small"         mean-only gpry_predict of at most this many points is one fused launch (default 2048)

@@ -1159,3 +1159,43 @@ def test_full_size_config1_multi_add_vs_oracle():
     assert np.max(np.abs(out["y"] - allr["y"])) <= 1e-8 * np.max(np.abs(allr["y"]))
     assert np.max(np.abs(out["sigma"] ** 2 - allr["sigma"] ** 2)) <= 1e-9 * C
     assert int(np.argmax(out["acq"])) == int(np.argmax(allr["acq"]))          # acquisition arg-max identical
+
+
+@pytest.mark.parametrize("kid", [0, 1, 2, 3])
+@pytest.mark.parametrize("N,d,ls", [(700, 3, 0.3), (1500, 8, 0.05), (3000, 16, 0.3), (2100, 20, 1.5), (900, 5, 0.01)])
+def test_cross_kernel_panel_with_distances_from_the_matrix_pipe(dev, N, d, ls, kid):
+    """Round 4: the sweep's K*^T panel (gpry/gpr.py:1179) takes r^2 = |x - c|^2 + |y - c|^2 - 2 (x - c).(y - c) with the dot
+    products on the matrix pipe (``cross_build_mfma_kernel``, option ``cross_mfma``; c = mean of the training rows, so that
+    the cancellation is relative to the spread of the data).  Against the difference form (``cross_mfma`` = 0) and against
+    the oracle: mean rel <= 1e-8, |delta var| <= 1e-9 C -- also with length scales of 1 % of the box, with a candidate ON a
+    training point (r^2 = 0 comes out as rounding noise and is clamped) and a ragged chunk.  Matern-1/2 keeps the difference
+    form whatever the option says (the cusp of exp(-r) at r = 0 turns noise e in r^2 into sqrt(e) in k): there the two
+    runs must agree bit for bit."""
+    M = 5000 + 13
+    bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M, seed=N + kid)
+    Xc[7] = X[11]                                   # a candidate on a training point
+    m = orc.OracleGPR(bounds, kernel_id=kid)
+    m.theta = np.log(np.array([3.0] + [ls] * d))
+    m.fitted = True
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    C = np.exp(m.theta[0]) * m.pre_y.std_ ** 2
+    out = {}
+    try:
+        for mf in (1, 0):
+            dev.set_option("cross_mfma", mf)
+            dev.set_option("sweep_chunk", 2048)      # several chunks, the last one ragged
+            r = dev.sweep_logexp(Xc, 0.1, 0.0, 1e-2, want=("y", "sigma"))
+            out[mf] = (r["y"].copy(), r["sigma"].copy())
+    finally:
+        dev.set_option("cross_mfma", 1)
+        dev.set_option("sweep_chunk", 32768)
+    scale = max(1.0, np.max(np.abs(out[0][0])))
+    if kid == 1:
+        np.testing.assert_array_equal(out[1][0], out[0][0])
+        np.testing.assert_array_equal(out[1][1], out[0][1])
+    assert np.max(np.abs(out[1][0] - out[0][0])) <= 1e-9 * scale
+    assert np.max(np.abs(out[1][1] ** 2 - out[0][1] ** 2)) <= 1e-10 * C
+    rm, rs = m.predict(Xc[:1500], return_std=True)
+    assert np.max(np.abs(out[1][0][:1500] - rm)) <= 1e-8 * max(1.0, np.max(np.abs(rm)))
+    assert np.max(np.abs(out[1][1][:1500] ** 2 - rs ** 2)) <= 1e-9 * C
