@@ -20,7 +20,7 @@
 //
 // One row stride (130 doubles) keeps the row-wise MFMA fragment reads conflict-free and the k-wise ones 2-way.  The
 // factor does NOT travel back to HBM: gpry_factorize cannot adopt it (lml_cache stays false) and
-// runs the general chain once per fit -- the prediction factor keeps its operation order.
+// runs the general chain once per fit -- the prediction factor keeps its operation order (profiles/HISTORY.md section 4.2).
 #include "kern_math.h"
 #include "chol16.h"
 
@@ -32,7 +32,7 @@
 // Results travel as self-validating 16-byte units {value, stamp}, each written by ONE store instruction (one PCIe write
 // inside a cache line), so that the host may pick them up the moment they land instead of waiting for the end-of-kernel
 // signal: round 2 measured that wait at 15-18 us per evaluation, and learned that a status word written "last" does not
-// arrive last (inbound writes to different cache lines are not ordered on this platform).  No
+// arrive last (inbound writes to different cache lines are not ordered on this platform, profiles/HISTORY.md section 4.5).  No
 // order between the units is assumed: the host reads a value only from a unit whose stamp is this evaluation's.
 struct LsUnit { unsigned long long payload, stamp; };
 #define LS_INFO_UNIT 40

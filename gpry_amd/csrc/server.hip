@@ -16,7 +16,7 @@
 // the payload of that request -- and republishes the request to its followers through device memory (release /
 // acquire at agent scope).  Device -> host: per (slice, point) ONE 16-byte store {partial sum, stamp}: a single PCIe
 // write inside one cache line.  (Round 2 learned that inbound writes to DIFFERENT lines are not ordered here,
-// a status word written "last" overtook its data in 2 % of the calls.  No ordering between
+// profiles/HISTORY.md section 4.5: a status word written "last" overtook its data in 2 % of the calls.  No ordering between
 // units is assumed anywhere in this protocol; every unit proves its own freshness.)  The host spins on the stamps,
 // adds the slices in the fixed order of the one-launch path and applies y_std, y_mean, clip and mask.
 //

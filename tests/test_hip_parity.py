@@ -804,7 +804,7 @@ def test_split_k_contraction_of_small_batches_equals_the_one_pass_contraction(de
 @pytest.mark.parametrize("N", [2048, 2300, 4096])
 def test_sweep_with_alternating_k_walk_is_chunking_independent(dev, N):
     """The super-tiles of an XCD alternate the direction of their k walk so that the row tiles of a super-tile sit at
-    the same k and share the K*^T panel in L2.  The direction is a function of the row tile
+    the same k and share the K*^T panel in L2 (profiles/HISTORY.md section 4.1(b)).  The direction is a function of the row tile
     alone: the bits of a candidate's sigma must not depend on the chunking (which moves its column inside a launch and
     switches between the paired and the plain super-tile order), the mean is untouched, and against the register-staged
     engine (``gemm_dma`` = 0: every tile walks k upwards) the variance moves by rounding only; both agree with the oracle."""

@@ -112,7 +112,7 @@ def test_restart_farm_over_the_devices_of_one_process_equals_the_sequential_fit(
 def test_concurrent_fit_is_reproducible_over_many_runs(monkeypatch):
     """The same comparison thirty times over (tests/tools/stress_concurrent_fit.py runs hundreds): a race in the
     hand-over of LML results shows up as a different evaluation count in a few percent of the fits -- host-side
-    polling of results in mapped memory did exactly that while passing the single
+    polling of results in mapped memory did exactly that (profiles/HISTORY.md section 4.5) while passing the single
     comparison above most of the time."""
     monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0")      # the thread farm is under test, not the side-by-side runs
     g = load_golden("fit")
