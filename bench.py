@@ -652,18 +652,32 @@ def launch_ranks(n, argv, script=None, timeout=None, env_extra=None):
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
+    import collections
+    import tempfile
+    progress = os.path.join(tempfile.mkdtemp(prefix="gpry_bench_"), "rank0_progress.json")
     procs = []
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "GPRY_BENCH_LAUNCHER": "self",
+                    "GPRY_BENCH_PROGRESS_FILE": progress,
                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, start_new_session=True,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
     lines = []
     reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
     reader.start()
+    # every rank's stderr is passed on as it comes and its tail kept: if a rank dies, the line says why
+    tails = [collections.deque(maxlen=12) for _ in range(n)]
+
+    def relay(r):
+        for ln in procs[r].stderr:
+            tails[r].append(ln.rstrip("\n"))
+            sys.stderr.write(ln)
+    relays = [threading.Thread(target=relay, args=(r,), daemon=True) for r in range(n)]
+    for th in relays:
+        th.start()
 
     def end_all(sig=signal.SIGTERM):
         for pr in procs:
@@ -679,10 +693,14 @@ def launch_ranks(n, argv, script=None, timeout=None, env_extra=None):
 
     old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     t0, first_fail, why, t_end = time.time(), None, None, None
+    fail_order = []          # ranks in the order in which they were seen to have failed on their own
     try:
         while any(pr.poll() is None for pr in procs):
             time.sleep(0.2)
             now = time.time()
+            for r, pr in enumerate(procs):
+                if t_end is None and pr.poll() not in (None, 0) and r not in fail_order:
+                    fail_order.append(r)
             if first_fail is None and any(pr.poll() not in (None, 0) for pr in procs):
                 first_fail = now
             if why is None and first_fail is not None and now - first_fail > float(os.environ.get("GPRY_BENCH_FAIL_GRACE", "30")):
@@ -699,11 +717,15 @@ def launch_ranks(n, argv, script=None, timeout=None, env_extra=None):
         for sg, h in old.items():
             signal.signal(sg, h)
     reader.join(timeout=10)
+    for th in relays:
+        th.join(timeout=5)
     codes = [pr.returncode for pr in procs]
     # the worst code a rank returned itself; ranks the launcher had to end (negative = signal) only count if no
     # rank failed on its own
     own = [c for c in codes if c is not None and c > 0]
     worst = max(own) if own else max([128 - c for c in codes if c is not None and c < 0] or [0])
+    if fail_order and codes[fail_order[0]] is not None and codes[fail_order[0]] > 0:
+        worst = codes[fail_order[0]]                          # the code of the rank that went down first
     if why is not None:
         print(f"bench.py: launcher ended the run ({why}); rank exit codes {codes}", file=sys.stderr)
         worst = worst or 124
@@ -712,11 +734,44 @@ def launch_ranks(n, argv, script=None, timeout=None, env_extra=None):
     for ln in out:
         if not ln.lstrip().startswith("{"):
             print(ln, file=sys.stderr)
+    failed = [r for r, c in enumerate(codes) if c not in (0, None)]
+    for r in failed:                                          # (a run that ended between two polls)
+        if codes[r] is not None and codes[r] > 0 and r not in fail_order and t_end is None:
+            fail_order.append(r)
+    error = None
+    if failed or why is not None:
+        # the first rank that went down is the cause; whoever followed (a peer whose collective broke, the ranks the
+        # launcher ended) is listed behind it
+        first = fail_order[:1]
+        error = {"failed_ranks": first or failed, "failed_in_order": fail_order, "exit_codes": codes, "launcher": why,
+                 "stderr_tail": {str(r): list(tails[r])[-6:] for r in (first or failed)[:4]}}
+    line = None
     if json_lines:
-        print(json_lines[-1], flush=True)
+        line = json_lines[-1]
+        if error is not None:           # rank 0 reported, a peer failed afterwards: the line keeps its numbers and says so
+            try:
+                obj = json.loads(line)
+                obj["error"] = error
+                line = json.dumps(obj)
+            except ValueError:
+                pass
+    elif os.path.exists(progress):      # rank 0 never got to its line: its last snapshot, marked as such
+        try:
+            obj = json.load(open(progress))
+            obj["error"] = error or {"failed_ranks": [], "exit_codes": codes, "launcher": "rank 0 printed no result line"}
+            line = json.dumps(obj)
+        except (OSError, ValueError):
+            line = None
+    if line is not None:
+        print(line, flush=True)
     elif worst == 0:
         print("bench.py: rank 0 printed no result line", file=sys.stderr)
         worst = 1
+    try:
+        os.remove(progress)
+        os.rmdir(os.path.dirname(progress))
+    except OSError:
+        pass
     return worst
 
 
@@ -788,6 +843,11 @@ def main(argv=None):
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
         comm, dist, comm_kind, n_rccl = connect(args, rank, world, dev)
 
+    if rank == 0 and world > 1:
+        M_each = [int(min(M_total, (r + 1) * -(-M_total // world)) - min(M_total, r * -(-M_total // world))) for r in range(world)]
+        progress_snapshot({"metric": "gp_refit_plus_nora_acq_cycle_throughput", "value": None, "unit": "candidates/s", "n_gpus": world,
+                           "config": {"workload": "BASELINE configs[3]", "N_train": N, "d": d, "M_total": M_total,
+                                      "M_per_gpu_by_rank": M_each, "comm": comm_kind, "rccl_ranks": n_rccl}}, "after the rendezvous")
     # --gpus N means N processes with one GPU each: a 1-process run must not pick up the other GPUs of
     # the node through NORA's in-process device group (its default is every visible GPU)
     sharded = comm is not None and world > 1
@@ -974,6 +1034,8 @@ def main(argv=None):
         except Exception as e:
             result["measured_peaks"] = {"error": repr(e)}
 
+    if rank == 0 and world > 1:
+        progress_snapshot(result, "after the timed region (scaling_check pending)")
     # ---- strong scaling: the same cycle on ONE GPU of this node, measured in this very run, so
     # that the line carries its own speed-up (whole cycle and device sweep)
     if world > 1 and args.scaling == "strong" and args.extras == "auto" and rank == 0:
@@ -1017,13 +1079,30 @@ def main(argv=None):
             cpu_row = result["cpu_baseline"]["small_n"].get(key)
             if isinstance(row, dict) and "fit_full_evals" in row and cpu_row and "fit_full_s" not in cpu_row:
                 cpu_row["fit_full_s_priced"] = row["fit_full_evals"] * cpu_row["lml_grad_us"] * 1e-6
+    # rank 0 prints BEFORE the closing barriers: a rank that dies late (after the timed region) then cannot take the
+    # line with it -- rank 0 needs no further collective to report
+    if rank == 0:
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()      # gloo: the other ranks wait here while rank 0 measures its extras
-    if rank == 0:
-        print(json.dumps(result))
-    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def progress_snapshot(result, stage):
+    """Self-launched N-GPU runs: rank 0 leaves what it knows so far (configuration incl. ``rccl_ranks`` and the shard sizes
+    after the rendezvous; the measured cycle after the timed region) in the file the launcher named.  If a rank fails
+    before rank 0 prints its line, the launcher prints the last snapshot with an ``error`` object that says which rank
+    and why (``launch_ranks``)."""
+    path = os.environ.get("GPRY_BENCH_PROGRESS_FILE", "")
+    if not path:
+        return
+    try:
+        with open(path + ".tmp", "w") as f:
+            json.dump(dict(result, partial=stage), f)
+        os.replace(path + ".tmp", path)
+    except OSError:
+        pass
 
 
 if __name__ == "__main__":

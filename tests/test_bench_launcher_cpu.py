@@ -54,6 +54,32 @@ def test_a_failing_rank_ends_the_group_with_its_code():
     assert not out.stdout.strip()
 
 
+def test_a_rank_that_fails_late_leaves_rank_0s_line_with_an_error_object():
+    """rank 0 prints before the closing barriers, so a peer that dies behind the timed region cannot take
+    the line with it; the launcher adds which rank failed, the exit codes and the tail of that rank's stderr."""
+    out = _launch(2, ["--allow-gloo"], {"GPRY_BENCH_DOUBLE_FAIL_LATE_RANK": "1", "GPRY_BENCH_FAIL_GRACE": "3"})
+    assert out.returncode == 9, (out.returncode, out.stderr[-2000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["value"] > 0 and res["n_gpus"] == 2 and res["config"]["rccl_ranks"] == 0 and res["config"]["M_per_gpu"] == 1500
+    assert res["error"]["failed_ranks"] == [1] and res["error"]["exit_codes"][1] == 9
+    assert any("fails behind the timed region" in ln for ln in res["error"]["stderr_tail"]["1"])
+
+
+def test_a_rank_that_fails_after_the_rendezvous_leaves_rank_0s_snapshot():
+    """... and one that dies in its first step, when rank 0 has no result yet: the launcher prints rank 0's last snapshot
+    (transport, ``rccl_ranks``, the shard of every rank) marked ``partial`` with the same error object."""
+    out = _launch(2, ["--allow-gloo"], {"GPRY_BENCH_DOUBLE_FAIL_MID_RANK": "1", "GPRY_BENCH_FAIL_GRACE": "3"})
+    assert out.returncode == 8, (out.returncode, out.stderr[-2000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["partial"] == "after the rendezvous" and res["value"] is None
+    assert res["config"]["M_per_gpu_by_rank"] == [1500, 1500] and res["config"]["comm"] == "gloo-fallback"
+    assert res["error"]["failed_ranks"] == [1] and res["error"]["exit_codes"][1] == 8
+
+
 def test_the_watchdog_ends_a_hanging_run():
     out = _launch(2, ["--allow-gloo"], {"GPRY_BENCH_DOUBLE_HANG_RANK": "1"}, timeout=12)
     assert out.returncode != 0 and "time limit" in out.stderr
