@@ -63,7 +63,9 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
             gpry_ctx* c; bool armed = false;
             ~PipeGuard() { if (armed) trtri_pipeline_abort(c); }
         } guard{ctx};
-        if (ctx->opt_factor_pipeline && ctx->opt_chol == 0 && ctx->Np >= ctx->opt_factor_pipeline_min) {
+        // (a batched evaluation has thetas enough to fill the GPU: its V = L^-1 stays behind potrf on the main stream;
+        // the two schedules give the same bits)
+        if (ctx->opt_factor_pipeline && ctx->opt_chol == 0 && ctx->Np >= ctx->opt_factor_pipeline_min && ctx->bn == 1) {
             const int rc = trtri_pipeline_begin(ctx, A, V, T, ctx->Np);
             if (rc < 0) return rc;
             piped = rc == 0;
@@ -156,11 +158,9 @@ static int ensure_batch_buffers(gpry_ctx* ctx, int64_t arena_doubles, int64_t re
     }
     return 0;
 }
-// is the batched chain built for this context's size and options?  (the comparators -- rocSOLVER, separate trailing launches --
-// and the pipelined chain of the large sizes are not batched: one evaluation after another there)
+// is the batched chain built for this context's size and options?  (rocSOLVER is not batched: one evaluation after another)
 static bool lml_batch_usable(const gpry_ctx* ctx) {
-    return ctx->N > 0 && ctx->Np > 128 && ctx->Np <= ctx->opt_lml_batch && ctx->d <= 32 && ctx->opt_chol == 0 && ctx->opt_chol_overlap &&
-           (!ctx->opt_factor_pipeline || ctx->Np < ctx->opt_factor_pipeline_min);
+    return ctx->N > 0 && ctx->Np > 128 && ctx->Np <= ctx->opt_lml_batch && ctx->d <= 32 && ctx->opt_chol == 0;
 }
 static int lml_batch_general(gpry_ctx* ctx, const double* thetas, int64_t B, int want_grad, double* lml, double* grad, int* info) {
     const int w = ctx->d + 1;

@@ -628,7 +628,6 @@ static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int
 }
 
 int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
-    if (ctx->bn > 1) return gpry_fail(ctx, -1, "batched chain: the schedule with separate trailing launches is not batched");
     hipStream_t st = ctx->stream;
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
     ctx->info_cleared = false;
@@ -639,8 +638,8 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
         for (int64_t j0 = K0; j0 < K0 + ob; j0 += 64) {
             const int P = (int)((Np - j0) / 64);
             arrivals += P;
-            PanelArgs pa = {A, Np, j0, K0, K0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals, 0};
-            hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)P), dim3(256), 0, st, pa, (const TileItem*)nullptr, P);
+            PanelArgs pa = {A, Np, j0, K0, K0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals, ctx->bstride};
+            hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)P, 1, (unsigned)ctx->bn), dim3(256), 0, st, pa, (const TileItem*)nullptr, P);
             GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));
         }
         GPRY_TRY(trailing_update(ctx, A, Np, K0, K0 + ob, (int)ob));
@@ -764,7 +763,6 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
     OverlapPlan* pl = nullptr;
     const bool too_large = Np > 7168;       // measured: -10 % at 6144, -1 % at 7168, +3 % at 8192 against separate trailing launches
     const int prc = too_large ? 1 : overlap_plan_get(ctx, Np, &pl);
-    if (prc == 1 && ctx->bn > 1) return gpry_fail(ctx, -1, "batched chain: no fused Cholesky schedule for Np = %lld", (long long)Np);
     if (prc == 1) return potrf_lower_fused(ctx, A, Np);
     if (prc) return prc;
     hipStream_t st = ctx->stream;

@@ -64,8 +64,10 @@ struct gpry_ctx {
     const double* bpar = nullptr;      // device, set 0: [C, l_1 .. l_d] as the host computes them for one evaluation
     double* barena = nullptr; int64_t barena_cap = 0;     // doubles
     void* hbres = nullptr; void* hbres_dev = nullptr; int64_t hbres_cap = 0;   // results of a batch (pinned, device-mapped)
-    int64_t opt_lml_batch = 2048;      // largest Np whose gpry_lml_batch runs as one chain (0: thetas one after another)
-    int64_t opt_lml_batch_mb = 16384;  // upper limit of the arena (MiB): longer batches go through in chunks
+    int64_t opt_lml_batch = 4096;      // largest Np whose gpry_lml_batch runs as one chain (0: thetas one after another); measured
+                                       // against the thread farm of three contexts: full fits 2.2x faster at N = 1024, 1.4x at 2048,
+                                       // 1.1x at 4096, 0.9x at 8192 (tools/r04/time_fit_crossover.py, bench.py --workload farm)
+    int64_t opt_lml_batch_mb = 49152;  // upper limit of the arena (MiB of the 288 GB): longer batches go through in chunks
 
     double* dX = nullptr;      // N x d raw transformed training rows (row-major, ld = d)
     double* dXs = nullptr;     // Np x dpad rows scaled by 1/l (pad rows = 0)

@@ -91,6 +91,20 @@ def fit_contexts():
         return 3
 
 
+_BATCH_SPLIT_MIN_N = 1536         # training sets from this size on split a round's thetas over several contexts (measured: -5 ... -8 % from N = 1664 on, +20 % at 512)
+_BATCH_SPLIT_MIN_SHARE = 2        # ... as long as every context gets at least this many
+
+
+def batch_contexts():
+    """Contexts on ONE GPU that share the thetas of a side-by-side round (``GPRY_HIP_FIT_BATCH_CONTEXTS``, default 2;
+    1 = all of them through the model's own context).  With several GPUs in the process every GPU gets its contexts as
+    ``fit_context_devices`` deals them out."""
+    try:
+        return max(1, int(os.environ.get("GPRY_HIP_FIT_BATCH_CONTEXTS", "2")))
+    except ValueError:
+        return 2
+
+
 def fit_context_devices(own, n_restarts, spec=None):
     """Device index of every context that shares the optimiser restarts of one fit in THIS process; entry 0
     is the model's own context.
@@ -699,7 +713,7 @@ class GaussianProcessRegressor(_RM, _BE):
 
     def _can_step_restarts_together(self):
         """Can ``gpry_lml_batch`` evaluate a round's thetas together?  N <= 128, d <= 16: ONE launch with a workgroup per
-        run (the single-launch objective); above that and up to the device's ``lml_batch`` limit (2048): ONE chain of
+        run (the single-launch objective); above that and up to the device's ``lml_batch`` limit (4096): ONE chain of
         launches whose every kernel carries all runs.  Then the optimiser runs of a fit advance side by side."""
         if (self.optimizer != "fmin_l_bfgs_b" or getattr(self, "fit_lockstep", True) is False
                 or os.environ.get("GPRY_HIP_FIT_LOCKSTEP", "1") == "0"):
@@ -724,6 +738,42 @@ class GaussianProcessRegressor(_RM, _BE):
         kern = clone(self.kernel_)
         fast = hasattr(kern, "set_theta_and_full")
         dev, d = self.device, self.d
+        # Above a few hundred points a round's thetas are split over several contexts driven from as many host threads: the
+        # latency-bound Cholesky panel chain of one share runs beside the matrix products of the others (the thread farm's
+        # trick, kept inside the side-by-side driver).  The contexts follow ``fit_context_devices`` (all GPUs of a
+        # single-process run); every theta is evaluated by ONE context with the arithmetic of a single evaluation.
+        devs = [dev]
+        if self.n >= _BATCH_SPLIT_MIN_N and batch_contexts() > 1 and hasattr(dev, "set_train"):
+            ctx_devs = fit_context_devices(getattr(dev, "device", 0), len(starts), getattr(self, "fit_devices", None))
+            want = ctx_devs[1:batch_contexts()] if len(set(ctx_devs)) == 1 else ctx_devs[1:]
+            kid, theta_full0 = self.kernel_.device_spec(self.d)
+            spare = list(self._fit_devs)
+            for idx in want:
+                hit = next((pr for pr in spare if pr[0] == idx), None)
+                if hit is None:
+                    hit = (idx, type(dev)(idx))
+                    self._fit_devs.append(hit)
+                else:
+                    spare.remove(hit)
+                hit[1].set_train(self.X_train_, self.y_train_, self.alpha)
+                hit[1].set_theta(kid, theta_full0)
+                devs.append(hit[1])
+        pool = None
+        if len(devs) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=len(devs))
+
+        def evaluate(fulls):
+            """(lml, grad_full) of all rows, the rows dealt out in contiguous shares over the contexts."""
+            n = len(fulls)
+            k = min(len(devs), max(1, n // _BATCH_SPLIT_MIN_SHARE)) if pool is not None else 1
+            if k <= 1:
+                out = dev.lml_batch(fulls, True)
+                return out[0], out[1]
+            cuts = [round(i * n / k) for i in range(k + 1)]
+            futs = [pool.submit(devs[i].lml_batch, fulls[cuts[i]:cuts[i + 1]], True) for i in range(k)]
+            parts = [f.result() for f in futs]
+            return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
 
         def fg(Thetas):
             fulls = []
@@ -733,7 +783,7 @@ class GaussianProcessRegressor(_RM, _BE):
                 else:
                     kern.theta = np.asarray(th, dtype=float)
                     fulls.append(np.array(kern.device_spec(d)[1], dtype=float))
-            lml, grad_full, _ = dev.lml_batch(np.array(fulls), True)
+            lml, grad_full = evaluate(np.array(fulls))
             self.n_eval_loglike += len(Thetas)
             F, G = np.empty(len(Thetas)), np.zeros((len(Thetas), len(Thetas[0])))
             for j, th in enumerate(Thetas):
@@ -749,8 +799,12 @@ class GaussianProcessRegressor(_RM, _BE):
                 F[j] = -lml[j]
             return F, G
 
-        X, F, nfev = lockstep.minimize_lockstep(fg, np.array(starts, dtype=float), np.asarray(bounds, dtype=float))
-        self.fit_stats = {"contexts": 1, "devices": [getattr(dev, "device", 0)], "side_by_side": True,
+        try:
+            X, F, nfev = lockstep.minimize_lockstep(fg, np.array(starts, dtype=float), np.asarray(bounds, dtype=float))
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
+        self.fit_stats = {"contexts": len(devs), "devices": [getattr(dv, "device", 0) for dv in devs], "side_by_side": True,
                           "evals_per_run": [int(v) for v in nfev]}
         return [(X[i], F[i]) for i in range(len(starts))]
 

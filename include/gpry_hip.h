@@ -95,8 +95,8 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                             evaluation is not kept for gpry_factorize)
  *     "lml_cache" 0/1         gpry_factorize adopts the factor of the last gpry_lml when theta is the same (default 1)
  *     "lml_batch"             largest padded size at which gpry_lml_batch runs all its thetas through ONE chain of launches
- *                             (default 2048; 0 = one after another)
- *     "lml_batch_mb"          upper limit of the scratch arena of such a batch in MiB (default 16384; longer batches go in chunks)
+ *                             (default 4096: beyond it the host's thread farm of three contexts is faster; 0 = one after another)
+ *     "lml_batch_mb"          upper limit of the scratch arena of such a batch in MiB (default 49152; longer batches go in chunks)
  *   predict / sweep (gpry/gpr.py:1022-1273, gpry/gp_acquisition.py:971-1108)
  *     "sweep_chunk"           candidates per sweep chunk (default 32768, rounded up to a multiple of 1024)
  *     "cross_mfma" 0/1        1 (default): the cross-kernel panel of sweeps and large predict batches takes its squared
@@ -164,7 +164,7 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml,
 /* B evaluations of the same objective in one call (thetas: B x (1 + d), lml: B, grad: B x (1 + d) or NULL, info: B or NULL,
  * each as gpry_lml).  The optimiser runs of a multi-restart fit (gpry/gpr.py:883-994, one after another there) stepped side
  * by side hand over one theta per run and round.  N <= 128, d <= 16: one launch, one workgroup per theta; larger training
- * sets up to option "lml_batch" padded rows (default 2048): ONE chain of launches in which every kernel (covariance build,
+ * sets up to option "lml_batch" padded rows (default 4096): ONE chain of launches in which every kernel (covariance build,
  * Cholesky panel steps, V = L^-1 levels, K^-1 = V^T V, traces) carries all thetas, each with its own scratch set; either way
  * every theta gets the arithmetic -- and the bits -- of a single gpry_lml call, and a theta whose matrix is not positive
  * definite returns (-inf, 0, info > 0) on its own.  Beyond that size the thetas are evaluated one after another. */

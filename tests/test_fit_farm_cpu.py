@@ -92,6 +92,29 @@ def test_restarts_stepped_side_by_side_select_the_sequential_optimum(monkeypatch
     np.testing.assert_array_equal(b[3], a[3])
 
 
+def test_side_by_side_rounds_split_over_several_contexts_give_the_same_fit(monkeypatch):
+    """From ``_BATCH_SPLIT_MIN_N`` points on a round's thetas are dealt out in contiguous shares over
+    ``GPRY_HIP_FIT_BATCH_CONTEXTS`` contexts (host threads): every theta is still evaluated once, by one context, so the fit
+    is the one-context fit bit for bit; rounds with fewer thetas than two per context stay on the model's own context."""
+    from gpry_amd import gpr as G
+    g = load_golden("fit_mid")
+    p = "f6b_k0_"
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "1")
+    monkeypatch.setattr(G, "_BATCH_SPLIT_MIN_N", 100)
+    out = {}
+    for k in ("1", "3"):
+        monkeypatch.setenv("GPRY_HIP_FIT_BATCH_CONTEXTS", k)
+        monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", k)
+        gpr = make_gpr(g[p + "bounds"], 0, n_restarts_optimizer=7, random_state=3)
+        gpr.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=True)
+        assert gpr.fit_stats["side_by_side"] and gpr.fit_stats["contexts"] == int(k)
+        out[k] = (gpr.kernel_.theta.copy(), gpr.log_marginal_likelihood_value_, gpr.n_eval_loglike,
+                  [dv.n_lml for _, dv in gpr._fit_devs])
+    np.testing.assert_array_equal(out["3"][0], out["1"][0])
+    assert out["3"][1] == out["1"][1] and out["3"][2] == out["1"][2]
+    assert len(out["3"][3]) == 2 and all(n > 0 for n in out["3"][3])          # the other contexts did evaluate
+
+
 def test_side_by_side_gate_follows_the_size_limit_of_the_batched_chain(monkeypatch):
     """Up to the device's ``lml_batch`` limit the restarts of a fit of more than 128 points are stepped together as well
     (F6b: the reference's fit of 200 points), above it the thread farm / sequential loop takes over; d > 16 at N <= 128 has

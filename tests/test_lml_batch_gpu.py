@@ -76,6 +76,36 @@ def test_batched_chain_has_the_bits_of_single_evaluations_and_the_oracle_values(
         dv.close()
 
 
+@pytest.mark.parametrize("N,d,B,kid", [(4096, 16, 5, 3), (5000, 6, 4, 0), (7300, 8, 3, 3)])
+def test_batched_chain_at_the_sizes_of_the_pipelined_and_the_separate_launch_schedules(N, d, B, kid):
+    """From Np = 4096 on a single evaluation queues V = L^-1 underneath potrf on a second stream, and above Np = 7168 the
+    Cholesky runs with separate trailing launches: a batch keeps everything on the main stream (it has thetas enough to fill
+    the GPU) and carries the thetas through the separate-launch schedule as well -- the per-theta bits are still those of the
+    single evaluations (the schedules are bit-identical), and the values are the oracle's at the sizes its blocked
+    restatement reaches in seconds."""
+    from gpry_amd import _lib
+    rng, X, y, alpha = _problem(N, d, N + d)
+    base = np.log(np.array([2.0] + [0.5] * d))
+    thetas = base + rng.uniform(-0.4, 0.4, (B, d + 1))
+    dv = _lib.Device(0)
+    try:
+        dv.set_train(X, y, alpha)
+        dv.set_theta(kid, base)
+        dv.set_option("lml_batch", 8192)        # (the default stops at 4096, where the host's thread farm takes over)
+        single = [dv.lml(th, True) for th in thetas]
+        lml, grad, info = dv.lml_batch(thetas, True)
+        for b, (l1, g1, i1) in enumerate(single):
+            assert info[b] == i1 == 0
+            assert lml[b] == l1, (b, lml[b], l1)
+            np.testing.assert_array_equal(grad[b], g1)
+        if N <= 4096:
+            rl, rg = orc.log_marginal_likelihood_blocked(X, y, alpha, thetas[0], kid)     # (memory-light restatement, pinned on F3)
+            assert abs(lml[0] - rl) <= 1e-10 * max(1.0, abs(rl))
+            assert np.max(np.abs(grad[0] - rg)) <= 1e-7 * max(1.0, np.max(np.abs(rg)))
+    finally:
+        dv.close()
+
+
 def test_batches_longer_than_the_arena_go_through_in_chunks():
     """``lml_batch_mb`` caps the scratch arena: a batch that does not fit is cut into chunks (and one that cannot hold two
     sets is evaluated theta by theta) -- same bits either way."""
@@ -91,14 +121,14 @@ def test_batches_longer_than_the_arena_go_through_in_chunks():
             out = dv.lml_batch(thetas, True)
             for a, b in zip(ref, out):
                 np.testing.assert_array_equal(a, b)
-        dv.set_option("lml_batch_mb", 16384)
+        dv.set_option("lml_batch_mb", 49152)
         dv.set_option("lml_batch", 0)           # off: one after another
         out = dv.lml_batch(thetas, True)
         for a, b in zip(ref, out):
             np.testing.assert_array_equal(a, b)
         # 130 thetas: more than one chain carries (96)
         many = np.repeat(thetas, 12, axis=0)[:130]
-        dv.set_option("lml_batch", 2048)
+        dv.set_option("lml_batch", 4096)
         lm, gr, inf = dv.lml_batch(many, True)
         for b in range(130):
             assert lm[b] == ref[0][b // 12] and inf[b] == 0

@@ -134,15 +134,17 @@ def test_device_group_over_distinct_gpus_reproduces_the_reference(tag, transport
 
 
 def test_restart_farm_over_distinct_gpus_in_one_process_equals_the_sequential_fit(monkeypatch):
-    """configs[4] in ONE process on real devices: the restarts of a fit above the batched-chain limit are dealt out over a
-    context on every visible GPU (``fit_context_devices``) and select what the sequential loop selects, bit for bit."""
+    """configs[4] in ONE process on real devices: the restarts of a fit (thread farm: ``GPRY_HIP_FIT_LOCKSTEP=0``) are dealt
+    out over a context on every visible GPU (``fit_context_devices``) and select what the sequential loop selects, bit for
+    bit."""
     n = min(_n_gpus(), 8)
     if n < 2:
         pytest.skip("needs at least two visible GPUs")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import gpry_oracle as orc
     from test_host_mirror_gpu import make_gpr
-    bounds, X, y, _ = orc.synthetic_like_goldens(2300, 6, 8, seed=5)      # > 2048: the thread farm, not the batched chain
+    bounds, X, y, _ = orc.synthetic_like_goldens(2300, 6, 8, seed=5)
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "0")          # the thread farm is under test, not the side-by-side runs
     out = {}
     for mode in ("farm", "sequential"):
         monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")

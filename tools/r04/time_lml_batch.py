@@ -16,7 +16,7 @@ def best_of(f, reps=5):
         t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
     return min(ts)
 
-sizes = [(256, 4), (400, 6), (800, 8), (1024, 8), (1600, 8), (2048, 16)]
+sizes = [(256, 4), (400, 6), (800, 8), (1024, 8), (1600, 8), (2048, 16), (4096, 16), (8192, 20)]
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     sizes = [(400, 6), (1024, 8)]
 dv = _lib.Device(0)
@@ -28,7 +28,7 @@ for N, d in sizes:
     base = np.log(np.array([2.0] + [0.5] * d)); dv.set_theta(kid, base)
     t1 = best_of(lambda: dv.lml(base, True))
     row = [f"N={N} d={d} kid={kid}: single {t1 * 1e3:.3f}"]
-    for B in (2, 4, 8, 16, 32, 64):
+    for B in ((2, 4, 8, 16, 32, 64) if N <= 2048 else (2, 4, 8, 16) if N <= 4096 else (2, 4, 8)):
         th = base + rng.uniform(-0.3, 0.3, (B, d + 1))
         tb = best_of(lambda: dv.lml_batch(th, True), reps=3)
         row.append(f"B={B} {tb * 1e3:.2f} | {B * t1 * 1e3:.2f} | x{B * t1 / tb:.1f}")
@@ -36,7 +36,7 @@ for N, d in sizes:
 dv.close()
 
 print("# full fit (ms, best of 2; evaluations): one after another | 3 contexts | side by side (same optimum as sequential?)")
-for N, d in ((200, 4), (400, 6), (800, 8), (1600, 8)) if not (len(sys.argv) > 1 and sys.argv[1] == "quick") else ((400, 6),):
+for N, d in ((200, 4), (400, 6), (800, 8), (1600, 8), (4096, 16)) if not (len(sys.argv) > 1 and sys.argv[1] == "quick") else ((400, 6),):
     bounds, X, y, Xc, truth = bench.synthetic(N, d, 16)
     res = {}
     for mode, env in (("sequential", ("1", "0")), ("3 contexts", ("3", "0")), ("side by side", ("1", "1"))):
