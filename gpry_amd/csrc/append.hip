@@ -174,6 +174,11 @@ static int append_chunk(gpry_ctx* ctx, const double* Xn, const double* yn, const
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dy + N0, yn, sizeof(double) * k, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dnoise + N0, an, sizeof(double) * k, hipMemcpyHostToDevice, st));
     ctx->N = N0 + k;
+    // centre of the MFMA panel build: the running sums continue in row order, so that a context that grew by border rows
+    // holds the centre -- to the bit -- of one that received the whole set at once (members of a device group do)
+    for (int a = 0; a < k; a++)
+        for (int c = 0; c < ctx->d; c++) ctx->xsum[c] += Xn[(int64_t)a * ctx->d + c];
+    for (int c = 0; c < ctx->d; c++) ctx->xcenter[c] = ctx->xsum[c] / (double)ctx->N;
     GPRY_TRY(launch_scale_train(ctx));
     GPRY_TRY(launch_kernel_rows(ctx, N0, k, W, Bk, Cb));
     auto splits = [&](int64_t tiles) { int n = 1; while (n < 16 && tiles * n * 2 <= 512 && Np / (n * 2) >= 64) n *= 2; return n; };

@@ -104,7 +104,8 @@ struct gpry_ctx {
     int64_t xcs_cap = 0;
     double* dYcs = nullptr;    // Np x dsel: centred scaled training rows of the MFMA panel build (launch_cross_prepare)
     int64_t ycs_cap = 0;
-    double xcenter[GPRY_MAX_DIM] = {0};    // mean of the training rows per dimension (set_train): the centre both sides are shifted by
+    double xcenter[GPRY_MAX_DIM] = {0};    // mean of the training rows per dimension: the centre both sides are shifted by
+    double xsum[GPRY_MAX_DIM] = {0};       // its running sums, in row order (set_train, append_rows)
     int opt_cross_mfma = 1;    // 1 (default): the sweep's cross-kernel panel takes its distances from the matrix pipe
     double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
     int64_t kst_cap = 0;       // doubles allocated

@@ -291,7 +291,8 @@ int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const doub
     hipStream_t st = ctx->stream;
     for (int k = 0; k < d; k++) {       // centre of the MFMA panel build (kernel_build.hip: cross_build_mfma_kernel)
         double s = 0.0;
-        for (int64_t i = 0; i < N; i++) s += X_[i * d + k];
+        for (int64_t i = 0; i < N; i++) s += X_[i * d + k];        // row order: gpry_append_rows continues the sums
+        ctx->xsum[k] = s;
         ctx->xcenter[k] = s / (double)N;
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dX, X_, sizeof(double) * N * d, hipMemcpyHostToDevice, st));

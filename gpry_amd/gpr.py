@@ -91,18 +91,21 @@ def fit_contexts():
         return 3
 
 
-_BATCH_SPLIT_MIN_N = 1536         # training sets from this size on split a round's thetas over several contexts (measured: -5 ... -8 % from N = 1664 on, +20 % at 512)
-_BATCH_SPLIT_MIN_SHARE = 2        # ... as long as every context gets at least this many
+_BATCH_GROUP_MIN_RUNS = 3         # a group of a side-by-side fit holds at least this many runs
 
 
-def batch_contexts():
-    """Contexts on ONE GPU that share the thetas of a side-by-side round (``GPRY_HIP_FIT_BATCH_CONTEXTS``, default 2;
-    1 = all of them through the model's own context).  With several GPUs in the process every GPU gets its contexts as
-    ``fit_context_devices`` deals them out."""
-    try:
-        return max(1, int(os.environ.get("GPRY_HIP_FIT_BATCH_CONTEXTS", "2")))
-    except ValueError:
+def batch_contexts(n_train=None):
+    """Independent groups (device contexts, host threads) that the runs of a side-by-side fit are dealt out over:
+    ``GPRY_HIP_FIT_BATCH_CONTEXTS`` if set, else by the size of the training set (measured, tools/r04/time_fit_crossover.py)."""
+    env = os.environ.get("GPRY_HIP_FIT_BATCH_CONTEXTS", "")
+    if env != "":
+        try:
+            return max(1, int(env))
+        except ValueError:
+            pass
+    if n_train is None:
         return 2
+    return 1 if n_train <= 128 else 3
 
 
 def fit_context_devices(own, n_restarts, spec=None):
@@ -732,20 +735,22 @@ class GaussianProcessRegressor(_RM, _BE):
         """The runs of a multi-restart fit stepped together (``gpry_amd.lockstep``: scipy's own L-BFGS-B routine, one
         reverse-communication call per run and round), the objective of a round evaluated for all runs in one
         ``gpry_lml_batch``.  Every run sees the values -- to the bit -- and takes the steps it would take alone, so
-        the optima and the selected one are those of the sequential loop."""
+        the optima and the selected one are those of the sequential loop.
+
+        Above a few hundred points the runs are dealt out (run i to group i mod k) over k INDEPENDENT groups, each with a
+        lock-step driver, a host thread and a device context of its own (``batch_contexts``; the contexts follow
+        ``fit_context_devices``, i.e. all GPUs of a single-process run): a round costs the latency of the kernel chain
+        whatever its width, and the chains of the groups run beside each other on the GPU -- the thread farm's overlap
+        with the batching inside every thread.  No group waits for another; a run never changes group."""
         from gpry_amd import lockstep
         self._upload_train()
-        kern = clone(self.kernel_)
-        fast = hasattr(kern, "set_theta_and_full")
         dev, d = self.device, self.d
-        # Above a few hundred points a round's thetas are split over several contexts driven from as many host threads: the
-        # latency-bound Cholesky panel chain of one share runs beside the matrix products of the others (the thread farm's
-        # trick, kept inside the side-by-side driver).  The contexts follow ``fit_context_devices`` (all GPUs of a
-        # single-process run); every theta is evaluated by ONE context with the arithmetic of a single evaluation.
+        n_runs = len(starts)
         devs = [dev]
-        if self.n >= _BATCH_SPLIT_MIN_N and batch_contexts() > 1 and hasattr(dev, "set_train"):
-            ctx_devs = fit_context_devices(getattr(dev, "device", 0), len(starts), getattr(self, "fit_devices", None))
-            want = ctx_devs[1:batch_contexts()] if len(set(ctx_devs)) == 1 else ctx_devs[1:]
+        k = min(batch_contexts(self.n), max(1, n_runs // _BATCH_GROUP_MIN_RUNS)) if hasattr(dev, "set_train") else 1
+        if k > 1:
+            ctx_devs = fit_context_devices(getattr(dev, "device", 0), n_runs, getattr(self, "fit_devices", None))
+            want = [ctx_devs[i % len(ctx_devs)] if len(set(ctx_devs)) > 1 else ctx_devs[0] for i in range(1, k)]
             kid, theta_full0 = self.kernel_.device_spec(self.d)
             spare = list(self._fit_devs)
             for idx in want:
@@ -758,55 +763,55 @@ class GaussianProcessRegressor(_RM, _BE):
                 hit[1].set_train(self.X_train_, self.y_train_, self.alpha)
                 hit[1].set_theta(kid, theta_full0)
                 devs.append(hit[1])
-        pool = None
-        if len(devs) > 1:
+        starts = np.array(starts, dtype=float)
+        bounds = np.asarray(bounds, dtype=float)
+        counts = [0] * k
+
+        def make_fg(g):
+            kern = clone(self.kernel_)              # (kernel objects are not shared between threads)
+            fast = hasattr(kern, "set_theta_and_full")
+            dv = devs[g]
+
+            def fg(Thetas):
+                fulls = []
+                for th in Thetas:
+                    if fast:
+                        fulls.append(np.array(kern.set_theta_and_full(th, d)[1], dtype=float))
+                    else:
+                        kern.theta = np.asarray(th, dtype=float)
+                        fulls.append(np.array(kern.device_spec(d)[1], dtype=float))
+                lml, grad_full, _ = dv.lml_batch(np.array(fulls), True)
+                counts[g] += len(Thetas)
+                F, G = np.empty(len(Thetas)), np.zeros((len(Thetas), len(Thetas[0])))
+                for j, th in enumerate(Thetas):
+                    if not np.isfinite(lml[j]):
+                        F[j] = np.inf
+                        continue
+                    if fast:
+                        kern.set_theta_and_full(th, d)
+                        G[j] = -kern.grad_from_full_fast(grad_full[j], d)
+                    else:
+                        kern.theta = np.asarray(th, dtype=float)
+                        G[j] = -kern.grad_from_full(grad_full[j], d)
+                    F[j] = -lml[j]
+                return F, G
+            return fg
+
+        members = [list(range(g, n_runs, k)) for g in range(k)]
+        if k == 1:
+            out = [lockstep.minimize_lockstep(make_fg(0), starts, bounds)]
+        else:
             from concurrent.futures import ThreadPoolExecutor
-            pool = ThreadPoolExecutor(max_workers=len(devs))
-
-        def evaluate(fulls):
-            """(lml, grad_full) of all rows, the rows dealt out in contiguous shares over the contexts."""
-            n = len(fulls)
-            k = min(len(devs), max(1, n // _BATCH_SPLIT_MIN_SHARE)) if pool is not None else 1
-            if k <= 1:
-                out = dev.lml_batch(fulls, True)
-                return out[0], out[1]
-            cuts = [round(i * n / k) for i in range(k + 1)]
-            futs = [pool.submit(devs[i].lml_batch, fulls[cuts[i]:cuts[i + 1]], True) for i in range(k)]
-            parts = [f.result() for f in futs]
-            return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
-
-        def fg(Thetas):
-            fulls = []
-            for th in Thetas:
-                if fast:
-                    fulls.append(np.array(kern.set_theta_and_full(th, d)[1], dtype=float))
-                else:
-                    kern.theta = np.asarray(th, dtype=float)
-                    fulls.append(np.array(kern.device_spec(d)[1], dtype=float))
-            lml, grad_full = evaluate(np.array(fulls))
-            self.n_eval_loglike += len(Thetas)
-            F, G = np.empty(len(Thetas)), np.zeros((len(Thetas), len(Thetas[0])))
-            for j, th in enumerate(Thetas):
-                if not np.isfinite(lml[j]):
-                    F[j] = np.inf
-                    continue
-                if fast:
-                    kern.set_theta_and_full(th, d)
-                    G[j] = -kern.grad_from_full_fast(grad_full[j], d)
-                else:
-                    kern.theta = np.asarray(th, dtype=float)
-                    G[j] = -kern.grad_from_full(grad_full[j], d)
-                F[j] = -lml[j]
-            return F, G
-
-        try:
-            X, F, nfev = lockstep.minimize_lockstep(fg, np.array(starts, dtype=float), np.asarray(bounds, dtype=float))
-        finally:
-            if pool is not None:
-                pool.shutdown(wait=True)
-        self.fit_stats = {"contexts": len(devs), "devices": [getattr(dv, "device", 0) for dv in devs], "side_by_side": True,
-                          "evals_per_run": [int(v) for v in nfev]}
-        return [(X[i], F[i]) for i in range(len(starts))]
+            with ThreadPoolExecutor(max_workers=k) as pool:
+                futs = [pool.submit(lockstep.minimize_lockstep, make_fg(g), starts[members[g]], bounds) for g in range(k)]
+                out = [f.result() for f in futs]
+        X, F, nfev = np.empty_like(starts), np.empty(n_runs), np.zeros(n_runs, dtype=int)
+        for g in range(k):
+            X[members[g]], F[members[g]], nfev[members[g]] = out[g]
+        self.n_eval_loglike += sum(counts)
+        self.fit_stats = {"contexts": k, "devices": [getattr(dv, "device", 0) for dv in devs], "side_by_side": True,
+                          "evals_per_run": [int(v) for v in nfev], "evals_per_context": list(counts)}
+        return [(X[i], F[i]) for i in range(n_runs)]
 
     def _concurrent_restarts(self, starts, bounds, ctx_devs):
         """The optimiser runs of a multi-restart fit are independent: they are worked off by one host

@@ -92,27 +92,33 @@ def test_restarts_stepped_side_by_side_select_the_sequential_optimum(monkeypatch
     np.testing.assert_array_equal(b[3], a[3])
 
 
-def test_side_by_side_rounds_split_over_several_contexts_give_the_same_fit(monkeypatch):
-    """From ``_BATCH_SPLIT_MIN_N`` points on a round's thetas are dealt out in contiguous shares over
-    ``GPRY_HIP_FIT_BATCH_CONTEXTS`` contexts (host threads): every theta is still evaluated once, by one context, so the fit
-    is the one-context fit bit for bit; rounds with fewer thetas than two per context stay on the model's own context."""
-    from gpry_amd import gpr as G
+def test_side_by_side_runs_dealt_out_over_independent_groups_give_the_same_fit(monkeypatch):
+    """Above 128 points the runs of a side-by-side fit are dealt out (run i to group i mod k) over k independent groups, each
+    with its own lock-step driver, host thread and device context (``batch_contexts``): every run is still evaluated with
+    the arithmetic of single evaluations, so the fit is the one-group fit bit for bit, whatever k; a group never holds fewer
+    than three runs."""
     g = load_golden("fit_mid")
     p = "f6b_k0_"
     monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "1")
-    monkeypatch.setattr(G, "_BATCH_SPLIT_MIN_N", 100)
     out = {}
-    for k in ("1", "3"):
+    for k in ("1", "3", "2"):
         monkeypatch.setenv("GPRY_HIP_FIT_BATCH_CONTEXTS", k)
         monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", k)
         gpr = make_gpr(g[p + "bounds"], 0, n_restarts_optimizer=7, random_state=3)
         gpr.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=True)
-        assert gpr.fit_stats["side_by_side"] and gpr.fit_stats["contexts"] == int(k)
+        want = min(int(k), 7 // 3)
+        assert gpr.fit_stats["side_by_side"] and gpr.fit_stats["contexts"] == want
+        assert sum(gpr.fit_stats["evals_per_context"]) == sum(gpr.fit_stats["evals_per_run"])
         out[k] = (gpr.kernel_.theta.copy(), gpr.log_marginal_likelihood_value_, gpr.n_eval_loglike,
                   [dv.n_lml for _, dv in gpr._fit_devs])
-    np.testing.assert_array_equal(out["3"][0], out["1"][0])
-    assert out["3"][1] == out["1"][1] and out["3"][2] == out["1"][2]
-    assert len(out["3"][3]) == 2 and all(n > 0 for n in out["3"][3])          # the other contexts did evaluate
+    for k in ("3", "2"):
+        np.testing.assert_array_equal(out[k][0], out["1"][0])
+        assert out[k][1] == out["1"][1] and out[k][2] == out["1"][2]
+        assert len(out[k][3]) == 1 and out[k][3][0] > 0          # the second context did evaluate
+    # the default width follows the size of the training set
+    from gpry_amd import gpr as G
+    monkeypatch.delenv("GPRY_HIP_FIT_BATCH_CONTEXTS")
+    assert G.batch_contexts(100) == 1 and G.batch_contexts(1000) == 3
 
 
 def test_side_by_side_gate_follows_the_size_limit_of_the_batched_chain(monkeypatch):

@@ -190,19 +190,21 @@ def test_side_by_side_fit_above_128_points_equals_the_sequential_fit_and_the_ref
     assert neval > 10
 
 
-def test_side_by_side_rounds_split_over_two_contexts_of_one_gpu(monkeypatch):
-    """From 1536 points on a round's thetas are shared by two contexts of the GPU (host threads: the panel chain of one share
-    runs beside the matrix products of the other): same optimum, LML and evaluation count as with one context, bit for bit."""
+def test_side_by_side_runs_in_independent_groups_on_one_gpu(monkeypatch):
+    """The runs of a side-by-side fit dealt out over two / three independent groups (own lock-step driver, host thread and
+    context on the same GPU: their kernel chains run beside each other): same optimum, LML and evaluation count as with
+    one group, bit for bit."""
     from test_host_mirror_gpu import make_gpr
-    bounds, X, y, _ = orc.synthetic_like_goldens(1700, 5, 8, seed=12)
+    bounds, X, y, _ = orc.synthetic_like_goldens(900, 5, 8, seed=12)
     out = {}
-    for k in ("2", "1"):
+    for k in ("3", "2", "1"):
         monkeypatch.setenv("GPRY_HIP_FIT_BATCH_CONTEXTS", k)
         monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "1")
-        gpr = make_gpr(bounds, 3, n_restarts_optimizer=6, random_state=4)
+        gpr = make_gpr(bounds, 3, n_restarts_optimizer=9, random_state=4)
         gpr.fit_devices = [0, 0, 0]
         gpr.append_to_data(X, y, fit_gpr=True)
         assert gpr.fit_stats["side_by_side"] and gpr.fit_stats["contexts"] == int(k)
         out[k] = (gpr.kernel_.theta.copy(), gpr.log_marginal_likelihood_value_, gpr.n_eval_loglike)
-    np.testing.assert_array_equal(out["2"][0], out["1"][0])
-    assert out["2"][1] == out["1"][1] and out["2"][2] == out["1"][2]
+    for k in ("3", "2"):
+        np.testing.assert_array_equal(out[k][0], out["1"][0])
+        assert out[k][1] == out["1"][1] and out[k][2] == out["1"][2]

@@ -8,7 +8,7 @@ import bench
 for N, d in [(int(a), 8) for a in (sys.argv[1:] or ["2048", "2560", "3072", "3584", "4096"])]:
     bounds, X, y, Xc, truth = bench.synthetic(N, d, 16)
     res = {}
-    for mode, env in (("3 contexts", ("3", "0", "1")), ("side by side", ("3", "1", "1")), ("side by side x2", ("3", "1", "2")), ("side by side x3", ("3", "1", "3"))):
+    for mode, env in (("3 contexts", ("3", "0", "1")), ("side by side", ("3", "1", "1")), ("x2 groups", ("3", "1", "2")), ("x3", ("3", "1", "3")), ("x4", ("4", "1", "4")), ("x6", ("6", "1", "6"))):
         os.environ["GPRY_HIP_FIT_CONTEXTS"], os.environ["GPRY_HIP_FIT_LOCKSTEP"], os.environ["GPRY_HIP_FIT_BATCH_CONTEXTS"] = env
         best = None
         gpr = bench.make_gpr(bounds, n_restarts_optimizer=10 + 2 * d)       # ONE model, as in a run: contexts and arenas persist
