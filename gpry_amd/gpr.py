@@ -747,10 +747,15 @@ class GaussianProcessRegressor(_RM, _BE):
         dev, d = self.device, self.d
         n_runs = len(starts)
         devs = [dev]
-        k = min(batch_contexts(self.n), max(1, n_runs // _BATCH_GROUP_MIN_RUNS)) if hasattr(dev, "set_train") else 1
-        if k > 1:
+        k = 1
+        if hasattr(dev, "set_train") and batch_contexts(self.n) > 1:
+            # one GPU: batch_contexts() groups on it; several GPUs in the process: the groups go where fit_context_devices
+            # deals the contexts of a fit (round-robin over the GPUs, its first entries on distinct ones)
             ctx_devs = fit_context_devices(getattr(dev, "device", 0), n_runs, getattr(self, "fit_devices", None))
-            want = [ctx_devs[i % len(ctx_devs)] if len(set(ctx_devs)) > 1 else ctx_devs[0] for i in range(1, k)]
+            k_max = len(ctx_devs) if len(set(ctx_devs)) > 1 else batch_contexts(self.n)
+            k = min(k_max, max(1, n_runs // _BATCH_GROUP_MIN_RUNS))
+        if k > 1:
+            want = [ctx_devs[i] if i < len(ctx_devs) else ctx_devs[0] for i in range(1, k)]
             kid, theta_full0 = self.kernel_.device_spec(self.d)
             spare = list(self._fit_devs)
             for idx in want:

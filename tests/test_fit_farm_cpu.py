@@ -211,6 +211,32 @@ def test_restart_farm_over_several_devices_in_one_process_equals_the_sequential_
     assert [id(dv) for _, dv in par._fit_devs] == ids
 
 
+@pytest.mark.parametrize("devices,expect", [([0, 1, 2, 3, 4, 5, 6, 7], [0, 1, 2, 3]), ([0, 0, 0], [0, 0, 0]), ([0, 5], [0, 5])])
+def test_side_by_side_groups_are_placed_on_the_devices_of_the_process(monkeypatch, devices, expect):
+    """Several GPUs in ONE process: the independent groups of a side-by-side fit go where ``fit_context_devices`` deals the
+    contexts of a fit (12 runs: at most 4 groups of >= 3 runs), every group's context on the device it was dealt; on one GPU
+    ``batch_contexts`` groups share it.  The fit is the sequential fit bit for bit."""
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "1")
+    g = load_golden("fit_mid")
+    p = "f6b_k3_"
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+    monkeypatch.setenv("GPRY_HIP_FIT_BATCH_CONTEXTS", "1")
+    seq = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=12, random_state=11)
+    seq.fit_devices = [devices[0]]
+    seq.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=True)
+    assert seq.fit_stats["contexts"] == 1
+    monkeypatch.delenv("GPRY_HIP_FIT_BATCH_CONTEXTS")
+    par = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=12, random_state=11)
+    par.fit_devices = devices
+    par.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=True)
+    assert par.fit_stats["side_by_side"] and par.fit_stats["devices"] == expect
+    assert [par.device.device] + [idx for idx, _ in par._fit_devs] == expect
+    assert all(n > 0 for n in par.fit_stats["evals_per_context"])
+    np.testing.assert_array_equal(par.kernel_.theta, seq.kernel_.theta)
+    assert par.log_marginal_likelihood_value_ == seq.log_marginal_likelihood_value_
+    assert par.n_eval_loglike == seq.n_eval_loglike
+
+
 def test_host_append_fixed_theta_reproduces_reference_factor():
     """F8 through the host mirror: frozen theta, re-fitted pre-processors, lazy factor."""
     from gpry_amd.kernels import clone
