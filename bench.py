@@ -374,16 +374,23 @@ def small_n_extras():
             thetas = theta + np.random.default_rng(5).uniform(-0.3, 0.3, (32, d + 1))
             full = np.array([np.concatenate(([t[0]], t[1:])) for t in thetas])
             row["lml_grad_batch32_ms"] = _per_call_us(lambda: dev.lml_batch(full, True), 10) * 1e-3
-            best = None
-            for _ in range(2):
-                g2 = make_gpr(bounds, n_restarts_optimizer=10 + 2 * d)
-                g2.append_to_data(X[:4], y[:4], fit_gpr=False)
+            # ONE model refitted, as in a run (gpry/run.py keeps its regressor): contexts and scratch arenas persist; the
+            # first fit, which creates them, is not the one timed
+            g2 = make_gpr(bounds, n_restarts_optimizer=10 + 2 * d)
+            g2.append_to_data(X, y, fit_gpr=False)
+            best, nev = None, 0
+            for rep in range(3):
+                g2.set_random_state(3)
+                e0 = g2.n_eval_loglike
                 t0 = time.perf_counter()
-                g2.append_to_data(X[4:], y[4:], fit_gpr=True)
+                g2.fit_gpr_hyperparameters(start_from_current=False)
                 dt = time.perf_counter() - t0
-                best = dt if best is None else min(best, dt)
+                nev = g2.n_eval_loglike - e0
+                if rep:
+                    best = dt if best is None else min(best, dt)
             stats = getattr(g2, "fit_stats", None) or {}
-            row.update({"fit_full_ms": best * 1e3, "fit_full_restarts": 10 + 2 * d, "fit_full_evals": int(g2.n_eval_loglike),
+            row.update({"fit_full_ms": best * 1e3, "fit_full_restarts": 10 + 2 * d, "fit_full_evals": int(nev),
+                        "fit_full_groups": int(stats.get("contexts", 1)),
                         "fit_full_side_by_side": bool(stats.get("side_by_side")),
                         "fit_full_rounds": int(max(stats.get("evals_per_run", [0])))})
             del g2

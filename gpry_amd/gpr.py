@@ -105,7 +105,9 @@ def batch_contexts(n_train=None):
             pass
     if n_train is None:
         return 2
-    return 1 if n_train <= 128 else 3
+    # measured on one MI355X (26 restarts, d = 8): N = 200 60 / 60 / 60 ms with 1 / 2 / 3 groups, 400: 61 / 57 / 55, 800: 124 /
+    # 113 / 103, 1600: 310 / 278 / 257, 4096: 2302 / 2140 / 2157; four and six groups are slower everywhere
+    return 1 if n_train <= 300 else 3
 
 
 def fit_context_devices(own, n_restarts, spec=None):

@@ -118,7 +118,7 @@ def test_side_by_side_runs_dealt_out_over_independent_groups_give_the_same_fit(m
     # the default width follows the size of the training set
     from gpry_amd import gpr as G
     monkeypatch.delenv("GPRY_HIP_FIT_BATCH_CONTEXTS")
-    assert G.batch_contexts(100) == 1 and G.batch_contexts(1000) == 3
+    assert G.batch_contexts(100) == 1 and G.batch_contexts(300) == 1 and G.batch_contexts(1000) == 3
 
 
 def test_side_by_side_gate_follows_the_size_limit_of_the_batched_chain(monkeypatch):
