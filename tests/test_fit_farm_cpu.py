@@ -225,7 +225,7 @@ def test_side_by_side_groups_are_placed_on_the_devices_of_the_process(monkeypatc
     seq.fit_devices = [devices[0]]
     seq.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=True)
     assert seq.fit_stats["contexts"] == 1
-    monkeypatch.delenv("GPRY_HIP_FIT_BATCH_CONTEXTS")
+    monkeypatch.setenv("GPRY_HIP_FIT_BATCH_CONTEXTS", "3")      # (what models of more than 300 points get by default)
     par = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=12, random_state=11)
     par.fit_devices = devices
     par.append_to_data(g[p + "X"], g[p + "y"], fit_gpr=True)
