@@ -302,18 +302,14 @@ int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t N
 // expected up to and including this launch).  Without this the result depends on all workgroups
 // starting before the first one finishes -- not true when another stream shares the GPU.
 struct PanelArgs {
-    double* A; int64_t ld, j0, K0, Kfar, n_real;
+    double* A; int64_t ld, j0, K0, n_real;
     int* info; int* arrive; int target;
     int64_t bstride;        // batched launch (gpry_ctx::bn): A, info and arrive of theta blockIdx.z lie this many doubles further on
 };
 #define PANEL_SMEM_DOUBLES (4 * 64 * PLD + 64 + 8)
 
-// One panel step for the 64-row block `bx` of the panel.  FAR: the columns [Kfar, K0) -- the previous outer
-// block, 128 wide -- have not been applied to this panel by a trailing update yet (the fused schedule
-// leaves that to the panel step so that no trailing tile sits on the panel chain): their product is
-// accumulated from zero over all 128 k and then subtracted, exactly what the trailing update's SYRK tile
-// does (same MFMA sequence, same single rounding of C - acc), so the factor stays bit-identical.
-template <bool FAR>
+// One panel step for the 64-row block `bx` of the panel: the columns [K0, j0) of the same rows are applied first
+// (left-looking, 64 at a time), then the 64 x 64 factor and the row solves.
 __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* smem, const int bx, const int tb) {
     double* __restrict__ A = bset(pa.A, tb, pa.bstride);
     const int64_t ld = pa.ld, j0 = pa.j0, K0 = pa.K0, n_real = pa.n_real;
@@ -330,7 +326,7 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const bool is_diag = bx == 0;
     const int64_t R = j0 + 64 * (int64_t)bx;
-    const int64_t Kfirst = FAR ? pa.Kfar : K0;     // the chunk that comes in with the first loads
+    const int64_t Kfirst = K0;                     // the chunk that comes in with the first loads
     const int kprev = (int)(j0 - K0);          // columns of the outer block already factorised: 0, 64, 128, ...
     if (t == 0) s_bad = 0;
     {
@@ -350,64 +346,8 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     __syncthreads();
     // ---- left-looking update with the previous columns of the outer block, 64 at a time (the first
     // chunk came in with the loads above; an outer block of 256 columns has up to three)
-    if (FAR) {
-        v4d accD[3], accB[4];
-#pragma unroll
-        for (int q = 0; q < 3; q++) accD[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; q++) accB[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int fc = 0; fc < 2; fc++) {
-            if (fc) {
-                __syncthreads();
-                double2 rPt[8], rPo[8];
-                load_block_issue(A + j0 * ld + Kfirst + 64, ld, t, rPt);
-                load_block_issue(A + R * ld + Kfirst + 64, ld, t, rPo);
-                load_block_commit(sPt, t, rPt);
-                load_block_commit(sPo, t, rPo);
-                __syncthreads();
-            }
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int tl = w + 4 * q;
-                if (tl < 10) {
-                    const int rw = tl < 1 ? 0 : tl < 3 ? 1 : tl < 6 ? 2 : 3;
-                    const int n = tl - rw * (rw + 1) / 2;
-                    accD[q] = mfma_nt16<false>(accD[q], sPt + (rw * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
-                }
-            }
-            if (!is_diag) {
-#pragma unroll
-                for (int n = 0; n < 4; n++)
-                    accB[n] = mfma_nt16<false>(accB[n], sPo + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const int tl = w + 4 * q;
-            if (tl < 10) {
-                const int rw = tl < 1 ? 0 : tl < 3 ? 1 : tl < 6 ? 2 : 3;
-                const int n = tl - rw * (rw + 1) / 2;
-                double* T = sD + (rw * 16) * PLD + n * 16;
-                v4d v = tile_load(T, lane);
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = v[e] - accD[q][e];
-                tile_store(T, v, lane);
-            }
-        }
-        if (!is_diag) {
-#pragma unroll
-            for (int n = 0; n < 4; n++) {
-                double* U = sB + (w * 16) * PLD + n * 16;
-                v4d v = tile_load(U, lane);
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = v[e] - accB[n][e];
-                tile_store(U, v, lane);
-            }
-        }
-    }
     for (int c0 = 0; c0 < kprev; c0 += 64) {
-        if (c0 || FAR) {
+        if (c0) {
             __syncthreads();                       // everybody is done with the previous chunk
             double2 rPt[8], rPo[8];
             load_block_issue(A + j0 * ld + K0 + c0, ld, t, rPt);
@@ -520,7 +460,9 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
 // trailing launches: bit-identical.  Small on purpose: ~10 us, shorter than a panel step, so that tiles
 // riding in a panel launch never set its length (a lone 128 x 128 x 128 tile takes 32-36 us).
 #define S64 130
-struct TileItem { int64_t a_off, b_off, c_off; int32_t n, pad; };    // n consecutive panels (128 columns apart) in one visit
+// n consecutive panels (128 columns apart) in one visit, then (half != 0) the 64 columns at ha_off / hb_off: the first
+// half of the panel that has only just been completed (its second half is applied by the next panel step itself)
+struct TileItem { int64_t a_off, b_off, c_off, ha_off, hb_off; int32_t n, half; };
 __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
                                                  const int* info) {
     if (*info != 0) return;
@@ -541,23 +483,28 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
     if (diag) sB = sA;
     // A lagging tile takes several pending panels in one visit: each one accumulated from zero and subtracted
     // with one rounding, in order -- the values a store / reload between them would give.
+    const int nvisit = (int)it.n + (it.half ? 1 : 0);
 #pragma unroll 1
-    for (int u = 0; u < (int)it.n; u++) {
-        const double* Ag = A + it.a_off + (int64_t)u * 128;
-        const double* Bg = A + it.b_off + (int64_t)u * 128;
+    for (int u = 0; u < nvisit; u++) {
+        const bool half = u >= (int)it.n;       // the last visit of a tile with `half`: 64 k instead of 128
+        const double* Ag = half ? A + it.ha_off : A + it.a_off + (int64_t)u * 128;
+        const double* Bg = half ? A + it.hb_off : A + it.b_off + (int64_t)u * 128;
+        const int kd = half ? 64 : 128;
         if (u) __syncthreads();                 // everybody has read the previous panel's images
         // LDS-DMA: one wave instruction moves one 1-KiB row (128 k) of an operand straight into its padded LDS
-        // row -- no staging registers, all 16 (+16) rows of a wave in flight at once
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int row = w * 16 + i;
-            gd_dma16(Ag + (int64_t)row * ld + 2 * lane, sA + row * S64);
-        }
-        if (!diag) {
+        // row -- no staging registers, all 16 (+16) rows of a wave in flight at once (a half row: lanes 0-31)
+        if (!half || lane < 32) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int row = w * 16 + i;
-                gd_dma16(Bg + (int64_t)row * ld + 2 * lane, sB + row * S64);
+                gd_dma16(Ag + (int64_t)row * ld + 2 * lane, sA + row * S64);
+            }
+            if (!diag) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int row = w * 16 + i;
+                    gd_dma16(Bg + (int64_t)row * ld + 2 * lane, sB + row * S64);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -569,13 +516,16 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
             for (int ni = 0; ni < 2; ni++) acc[mi][ni] = (v4d){0.0, 0.0, 0.0, 0.0};
         const double* pa = sA + (wr * 32 + r) * S64 + g;
         const double* pb = sB + (wc * 32 + r) * S64 + g;
+#pragma unroll 1
+        for (int kh = 0; kh < kd; kh += 64) {       // k ascending, 64 at a time (one or two passes)
 #pragma unroll 4
-        for (int k0 = 0; k0 < 128; k0 += 4) {
-            const double a0 = pa[k0], a1 = pa[16 * S64 + k0], b0 = pb[k0], b1 = pb[16 * S64 + k0];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            for (int k0 = kh; k0 < kh + 64; k0 += 4) {
+                const double a0 = pa[k0], a1 = pa[16 * S64 + k0], b0 = pb[k0], b1 = pb[16 * S64 + k0];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int mi = 0; mi < 2; mi++)
@@ -601,29 +551,29 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
     const int bx = (int)blockIdx.x;
     const int tb = (int)blockIdx.z;             // theta of a batched launch (gpry_ctx::bn)
     if (bx < P) {
-        if (pa.Kfar < pa.K0) panel_step_body<true>(pa, smem, bx, tb);
-        else panel_step_body<false>(pa, smem, bx, tb);
+        panel_step_body(pa, smem, bx, tb);
     } else {
         syrk64_tile_body(bset(pa.A, tb, pa.bstride), pa.ld, items[bx - P], smem, bset(pa.info, tb, pa.bstride));
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Schedule with separate trailing launches: A = L L^T in place (lower; the strict upper triangle is left untouched), outer
-// blocks of OB columns = OB / 64 panel steps, then one MFMA SYRK (K = OB) on the trailing matrix.  This is the production
-// path above Np = 7168 (the riding 64 x 64 tiles of the fused schedule below are a latency device, not a throughput one)
-// with OB = 256, and with OB = 128 the comparator of the fused schedule ("chol_overlap" = 0: bit-identical factors).
+// Schedule with separate trailing launches: A = L L^T in place (lower; the strict upper triangle is left untouched), panel
+// steps of 64 columns and MFMA SYRK / GEMM launches on the trailing matrix.  This is the production path above Np = 7168
+// (the riding 64 x 64 tiles of the fused schedule below are a latency device, not a throughput one) with outer blocks of
+// 256 columns, and below it the comparator of the fused schedule ("chol_overlap" = 0: bit-identical factors).
 // Outer block: the trailing matrix is read and written once per outer block, and a trailing update costs >= 40 us however
 // small it is, so wider blocks halve both; the panel steps pay for it with up to three extra 64-column chunks in their
 // left-looking update (crossover at Np ~ 6144: 128 / 256 columns 4.80 / 4.80 ms there, 8.12 / 7.84 at 8192).
-static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int64_t r0, int kdepth) {
-    if (r0 >= Np) return 0;
+// C[r0:, c0:c0+nc] -= A[r0:, K0:K0+kdepth] A[c0:c0+nc, K0:K0+kdepth]^T (lower tiles only when the block is square on the diagonal)
+static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int64_t r0, int64_t c0, int64_t nc, int kdepth) {
+    if (r0 >= Np || nc <= 0) return 0;
     GemmArgs g = {};
     g.A = A + r0 * Np + K0; g.lda = Np;
-    g.B = A + r0 * Np + K0; g.ldb = Np;
-    g.C = A + r0 * Np + r0; g.ldc = Np;
-    g.M = (int)(Np - r0); g.N = (int)(Np - r0); g.K = kdepth;
-    g.kmode = KM_FULL; g.lower_only = 1; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
+    g.B = A + c0 * Np + K0; g.ldb = Np;
+    g.C = A + r0 * Np + c0; g.ldc = Np;
+    g.M = (int)(Np - r0); g.N = (int)nc; g.K = kdepth;
+    g.kmode = KM_FULL; g.lower_only = (r0 == c0 && nc == Np - r0) ? 1 : 0; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
     return gemm_f64_launch(ctx, g, false, true, EPI_SUB);
 }
 
@@ -632,38 +582,54 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
     ctx->info_cleared = false;
     int arrivals = 0;
-    const int64_t OB = Np > 7168 ? 256 : 128;
-    for (int64_t K0 = 0; K0 < Np; K0 += OB) {
-        const int64_t ob = (Np - K0 < OB) ? Np - K0 : OB;
-        for (int64_t j0 = K0; j0 < K0 + ob; j0 += 64) {
-            const int P = (int)((Np - j0) / 64);
-            arrivals += P;
-            PanelArgs pa = {A, Np, j0, K0, K0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals, ctx->bstride};
-            hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)P, 1, (unsigned)ctx->bn), dim3(256), 0, st, pa, (const TileItem*)nullptr, P);
-            GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));
+    auto panel = [&](int64_t j0, int64_t Kfrom) -> int {
+        const int P = (int)((Np - j0) / 64);
+        arrivals += P;
+        PanelArgs pa = {A, Np, j0, Kfrom, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals, ctx->bstride};
+        hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)P, 1, (unsigned)ctx->bn), dim3(256), 0, st, pa, (const TileItem*)nullptr, P);
+        return trtri_pipeline_step(ctx, (int)(j0 / 64) + 1);
+    };
+    if (Np > 7168) {
+        // production: outer blocks of 256 columns; a step applies the earlier strips of its own block (up to 192 k)
+        const int64_t OB = 256;
+        for (int64_t K0 = 0; K0 < Np; K0 += OB) {
+            const int64_t ob = (Np - K0 < OB) ? Np - K0 : OB;
+            for (int64_t j0 = K0; j0 < K0 + ob; j0 += 64) GPRY_TRY(panel(j0, K0));
+            GPRY_TRY(trailing_update(ctx, A, Np, K0, K0 + ob, K0 + ob, Np - (K0 + ob), (int)ob));
         }
-        GPRY_TRY(trailing_update(ctx, A, Np, K0, K0 + ob, (int)ob));
+    } else {
+        // comparator of the fused schedule (same updates, same order, same arithmetic per element): every step applies the
+        // strip before its own; behind a block of two strips, its FIRST strip goes onto the next strip (64 k) and the whole
+        // block (128 k) onto everything right of that
+        for (int64_t K0 = 0; K0 < Np; K0 += 128) {
+            for (int64_t j0 = K0; j0 < K0 + 128; j0 += 64) GPRY_TRY(panel(j0, j0 >= 64 ? j0 - 64 : 0));
+            const int64_t r0 = K0 + 128;
+            if (r0 >= Np) break;
+            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0, r0, 64, 64));
+            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0 + 64, r0 + 64, Np - (r0 + 64), 128));
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused schedule (default up to Np = 7168).  Outer blocks of 128 columns (two panel steps).  Panel p's
-// trailing update is cut into 64 x 64 tiles (r, c) in units of 64 rows / columns.  Column c of block
-// bc = c / 2 needs the panels p = 0 .. bc-1 in order, each after panel p is complete:
-//   * p = bc-1 on the FIRST 64 columns of a block (c even) is applied by the panel step itself
-//     (panel_step_body<true>): the only part that sits on the panel chain;
-//   * p = bc-1 on the SECOND 64 columns (c odd) rides in the block's first launch, beside the panel step
-//     that works on the first 64 columns;
-//   * everything older (p <= bc-2) rides in any launch after panel p and before block bc, most urgent
-//     first (slack = launches left - updates left), two / one rounds of the CUs the panel step leaves free
-//     (first / second launch of a block); a tile far from its deadline waits until two panels are pending and
-//     applies both in one visit, C staying in registers in between.
-// The plan depends on Np only and is cached on the device.  Every element receives the same updates in
-// the same order with the same arithmetic as in potrf_lower_fused with chol_outer = 128: bit-identical
-// factors (tools/ab_chol_overlap.py, tests).  Above Np = 7168 the tiles no longer fit under the panel chain
-// (the 64 x 64 tile is a latency device, not a throughput one): potrf_lower_fused takes over.
+// Fused schedule (default up to Np = 7168).  One launch per 64-column strip c (launch c factors strip c); a panel of the
+// trailing update = the 128 columns of two strips (2p, 2p + 1), cut into 64 x 64 tiles (r, c).  Strip c of block bc = c / 2
+// receives, in this order,
+//   * the panels p <= bc - 2 (c even) / p <= bc - 1 (c odd) as riding tiles, 128 k per visit, in any launch after the
+//     panel is complete and before launch c, most urgent first (slack = launches left - updates left), one round of the CUs
+//     the panel step leaves free per launch; a tile far from its deadline waits until two panels are pending and applies
+//     both in one visit, C staying in registers in between;
+//   * c even: the FIRST half of panel bc - 1 (strip c - 2, 64 k) as a riding tile in launch c - 1, the launch that
+//     factors the second half (round 4; until then the panel step of launch c applied all 128 columns of panel bc - 1
+//     itself, 17.6k cycles of its ~ 55k, on the panel chain);
+//   * the strip before it (c - 1) by the panel step of launch c itself: left-looking, 64 k -- every step the same.
+// A tile is visited by ONE workgroup per launch (pending panels and the half in the same visit).  The plan depends on Np
+// only and is cached on the device.  Every element receives the same updates in the same order with the same arithmetic as
+// in potrf_lower_fused below Np = 7168: bit-identical factors (tools/ab_chol_overlap.py, tests).  Above Np = 7168 the
+// tiles no longer fit under the panel chain (the 64 x 64 tile is a latency device, not a throughput one):
+// potrf_lower_fused takes over with outer blocks of 256 columns.
 struct OverlapPlan {
     int64_t Np = 0;
     TileItem* d_items = nullptr;
@@ -687,19 +653,24 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
     std::vector<int> done((size_t)n64 * n64, 0), last((size_t)n64 * n64, -1);
+    std::vector<char> halfdone((size_t)n64 * n64, 0);
     std::vector<TileItem> items;
-    struct Cand { int slack, c, r, p, n; };
+    struct Cand { int slack, c, r, p, n, half; };
     std::vector<Cand> cand;
-    auto item = [&](int r, int c, int p, int n) {
+    auto item = [&](int r, int c, int p, int n, int half) {
         TileItem it;
         it.a_off = (int64_t)r * 64 * Np + (int64_t)p * 128;      // 64 rows from tile row r, the 128 columns of panel p
         it.b_off = (int64_t)c * 64 * Np + (int64_t)p * 128;
         it.c_off = (int64_t)r * 64 * Np + (int64_t)c * 64;
-        it.n = n; it.pad = 0;
+        it.ha_off = (int64_t)r * 64 * Np + (int64_t)(c - 2) * 64;     // the 64 columns of strip c - 2
+        it.hb_off = (int64_t)c * 64 * Np + (int64_t)(c - 2) * 64;
+        it.n = n; it.half = half;
         return it;
     };
     const int multi = 2;                         // panels per visit of a lagging tile
-    const int rounds_first = 2, rounds_second = 1;       // tile rounds (of the CUs the panel step leaves free) per launch of a block
+    // tile rounds (of the CUs the panel step leaves free) per launch: with every panel step the same length, one round each
+    // (measured at N = 4096: 1570 us with 1 / 1, 1601 with 2 / 1, 1625 with 2 / 2, 1632 with 3 / 2; no difference up to 2048)
+    const int rounds_first = 1, rounds_second = 1;
     for (int l = 0; l < nl; l++) {
         const int b = l / 2;
         const int P = (int)((Np - ((int64_t)b * 128 + 64 * (l & 1))) / 64);
@@ -709,10 +680,19 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
         // columns not yet factored: c >= 2b (+1 in the block's second launch: its first 64 columns are done)
         for (int c = 2 * b + (l & 1) > 2 ? 2 * b + (l & 1) : 2; c < n64; c++) {
             const int bc = c / 2;
-            const int need = (c & 1) ? bc : bc - 1;              // updates that ride (the panel does p = bc-1 for even c)
+            const int need = (c & 1) ? bc : bc - 1;              // whole panels that ride
+            // c even: the first half of panel bc - 1 (strip c - 2) rides in launch c - 1, behind the whole panels
+            const bool half_now = !(c & 1) && l == c - 1;
             for (int r = c; r < n64; r++) {
                 const int p = done[(size_t)r * n64 + c];
-                if (p >= need || p > b - 1 || last[(size_t)r * n64 + c] >= l) continue;
+                if (last[(size_t)r * n64 + c] >= l) continue;
+                if (half_now) {
+                    // everything this strip still waits for goes into ONE visit: the pending whole panels, then the half
+                    const int n = need - p;                      // (all of them are complete: p < need <= bc - 1 <= b)
+                    cand.push_back({0, c, r, p, n, 1});
+                    continue;
+                }
+                if (p >= need || p > b - 1) continue;
                 const int avail = (need < b ? need : b) - p;     // panels p .. p + avail - 1 are complete and wanted
                 int slack;
                 if ((c & 1) && p == bc - 1) slack = (2 * bc) - l;                           // must run in launch 2 bc
@@ -720,7 +700,7 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
                 int n = avail < multi ? avail : multi;
                 // far tiles wait until `multi` panels are pending (fewer, longer visits); near ones cannot
                 if (n < multi && slack > 2 * multi) continue;
-                cand.push_back({slack, c, r, p, n});
+                cand.push_back({slack, c, r, p, n, 0});
             }
         }
         std::sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) {
@@ -732,8 +712,9 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
         int n_taken = 0;
         for (const Cand& q : cand) {
             if (n_taken >= cap && q.slack > 1) continue;          // not urgent and the launch is full
-            items.push_back(item(q.r, q.c, q.p, q.n));
+            items.push_back(item(q.r, q.c, q.p, q.n, q.half));
             done[(size_t)q.r * n64 + q.c] = q.p + q.n; last[(size_t)q.r * n64 + q.c] = l;
+            if (q.half) halfdone[(size_t)q.r * n64 + q.c] = 1;
             n_taken++;
         }
         pl.count.push_back(n_taken);
@@ -742,7 +723,7 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
         if (cnext >= 2 && cnext < n64) {
             const int bc = cnext / 2, need = (cnext & 1) ? bc : bc - 1;
             for (int r = cnext; r < n64; r++)
-                if (done[(size_t)r * n64 + cnext] != need) { pl = OverlapPlan(); return 1; }
+                if (done[(size_t)r * n64 + cnext] != need || (!(cnext & 1) && !halfdone[(size_t)r * n64 + cnext])) { pl = OverlapPlan(); return 1; }
         }
     }
     if (!items.empty()) {
@@ -775,8 +756,8 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
             const int64_t j0 = K0 + 64 * s;
             const int P = (int)((Np - j0) / 64);
             arrivals += P;
-            PanelArgs pa = {A, Np, j0, K0, (K0 > 0 && s == 0) ? K0 - 128 : K0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals,
-                            ctx->bstride};
+            // every step applies the strip before its own (64 k, left-looking) itself
+            PanelArgs pa = {A, Np, j0, j0 >= 64 ? j0 - 64 : 0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals, ctx->bstride};
             hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + pl->count[l]), 1, (unsigned)ctx->bn), dim3(256), 0, st, pa,
                                pl->d_items + pl->first[l], P);
             GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));
