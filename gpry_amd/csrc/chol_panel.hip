@@ -80,6 +80,18 @@ __device__ __forceinline__ void fmac_row_bcast(double& acc, double a, double b, 
     }
 }
 #undef FMAC_BCAST_CASE
+// acc -= a[lane c of this lane's 16-lane row] * b   (negation as the source modifier of the DPP operand)
+#define FMSUB_BCAST_CASE(C) case C: asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:" #C " row_mask:0xf bank_mask:0xf" \
+                                                 : "+v"(acc) : "v"(a), "v"(b)); break;
+__device__ __forceinline__ void fmsub_row_bcast(double& acc, double a, double b, int c) {
+    switch (c) {
+        FMSUB_BCAST_CASE(0) FMSUB_BCAST_CASE(1) FMSUB_BCAST_CASE(2) FMSUB_BCAST_CASE(3) FMSUB_BCAST_CASE(4) FMSUB_BCAST_CASE(5)
+        FMSUB_BCAST_CASE(6) FMSUB_BCAST_CASE(7) FMSUB_BCAST_CASE(8) FMSUB_BCAST_CASE(9) FMSUB_BCAST_CASE(10)
+        FMSUB_BCAST_CASE(11) FMSUB_BCAST_CASE(12) FMSUB_BCAST_CASE(13) FMSUB_BCAST_CASE(14) FMSUB_BCAST_CASE(15)
+        default: break;
+    }
+}
+#undef FMSUB_BCAST_CASE
 
 // Cholesky of the 16x16 block at S (LDS, stride PLD) by one wave, one ROW per lane (lanes 16..63 repeat
 // lanes 0..15): column j takes the pivot through v_readlane and the scaled column entries L[c][j] of the
@@ -104,13 +116,13 @@ __device__ __forceinline__ int chol16_wave(double* S, double* rd, int lane) {
         const double rinv = pivot_rsqrt(djj);
         if (i == j) { my_d = djj; my_r = rinv; }
         double lij = x[j] * rinv;                               // L[i][j] (rows i < j: unused values)
-        double nlij = -lij;
         // x[c] -= L[i][j] * L[c][j]: the factor of row c is lane c of every 16-lane DPP row (the four
-        // rows of the wave are replicas), fused into the multiply-add as a row_newbcast operand
-        asm volatile("s_nop 1" : "+v"(lij), "+v"(nlij));        // VALU write -> DPP read of the same VGPR
+        // rows of the wave are replicas), fused into the multiply-add as a row_newbcast operand, the sign as its
+        // source modifier
+        asm volatile("s_nop 1" : "+v"(lij));                    // VALU write -> DPP read of the same VGPR
 #pragma unroll
-        for (int c = j + 1; c < 16; c++) fmac_row_bcast(x[c], lij, nlij, c);   // rows i < c: entries nobody reads
-        x[j] = i > j ? lij : 0.0;                               // the diagonal entry follows below
+        for (int c = j + 1; c < 16; c++) fmsub_row_bcast(x[c], lij, lij, c);   // rows i < c: entries nobody reads
+        x[j] = lij;                                             // (rows i <= j: values nobody reads; the diagonal follows below)
     }
     // L[i][i] = sqrt(d_i) = d_i / sqrt(d_i) refined by one Newton step (to the last bit), all sixteen at
     // once, one per lane, instead of four FP64 instructions in every column step
