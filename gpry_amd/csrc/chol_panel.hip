@@ -314,7 +314,8 @@ int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t N
 // expected up to and including this launch).  Without this the result depends on all workgroups
 // starting before the first one finishes -- not true when another stream shares the GPU.
 struct PanelArgs {
-    double* A; int64_t ld, j0, K0, n_real;
+    double* A; int64_t ld, j0, K0, n_real;      // j0, K0: columns relative to A; n_real: real (unpadded) size of the WHOLE matrix
+    int64_t col0;           // A is the trailing submatrix from column col0 of the whole matrix on (tail of the large schedule)
     int* info; int* arrive; int target;
     int64_t bstride;        // batched launch (gpry_ctx::bn): A, info and arrive of theta blockIdx.z lie this many doubles further on
 };
@@ -435,7 +436,7 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     __syncthreads();
     if (s_bad) {
         if (is_diag && t == 0) {
-            int64_t col = j0 + s_bad;                       // 1-based failing column
+            int64_t col = pa.col0 + j0 + s_bad;             // 1-based failing column of the whole matrix
             atomicCAS(info, 0, (int)(col <= n_real ? col : n_real));
         }
         return;
@@ -570,63 +571,85 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
 }
 
 // ---------------------------------------------------------------------------------------------
-// Schedule with separate trailing launches: A = L L^T in place (lower; the strict upper triangle is left untouched), panel
-// steps of 64 columns and MFMA SYRK / GEMM launches on the trailing matrix.  This is the production path above Np = 7168
-// (the riding 64 x 64 tiles of the fused schedule below are a latency device, not a throughput one) with outer blocks of
-// 256 columns, and below it the comparator of the fused schedule ("chol_overlap" = 0: bit-identical factors).
-// Outer block: the trailing matrix is read and written once per outer block, and a trailing update costs >= 40 us however
-// small it is, so wider blocks halve both; the panel steps pay for it with up to three extra 64-column chunks in their
-// left-looking update (crossover at Np ~ 6144: 128 / 256 columns 4.80 / 4.80 ms there, 8.12 / 7.84 at 8192).
-// C[r0:, c0:c0+nc] -= A[r0:, K0:K0+kdepth] A[c0:c0+nc, K0:K0+kdepth]^T (lower tiles only when the block is square on the diagonal)
-static int trailing_update(gpry_ctx* ctx, double* A, int64_t Np, int64_t K0, int64_t r0, int64_t c0, int64_t nc, int kdepth) {
-    if (r0 >= Np || nc <= 0) return 0;
+// Host side.  A = L L^T in place (lower; the strict upper triangle is left untouched), panel steps of 64 columns.  Three
+// chains, all on sub-blocks (A, ld, n) so that they compose:
+//   blocked_head      outer blocks of 256 columns, the trailing matrix updated by one MFMA SYRK launch per block (read and
+//                     written once per 256 columns; a step applies the earlier strips of its own block, up to 192 k)
+//   separate_chain    the comparator of the riding-tile chain: same updates, same order, same arithmetic per element, every
+//                     trailing update its own launch
+//   riding_chain      trailing tiles riding in the panel launches (plan below)
+// potrf_lower_overlap (default) = riding_chain up to Np = 4608.  Beyond that the riding tiles no longer fit under the panel
+// chain (the 64 x 64 tile is a latency device, not a throughput one: alone it lost to separate launches from Np ~ 7168 on), so
+// the first columns go through blocked_head -- where the trailing matrix is large and the SYRK launches fill the GPU -- and
+// the last 4608, an independent factorisation of the updated trailing block, through riding_chain (round 4: 6.60 -> 5.98 ms
+// at Np = 8192, 4.98 -> 4.54 at 7168; the SYRK launches of that part had shrunk to one 35-us tile latency each).
+// potrf_lower_fused ("chol_overlap" = 0) = the same with separate_chain in place of riding_chain: bit-identical factors.
+// C[r0:, c0:c0+nc] -= A[r0:, K0:K0+kdepth] A[c0:c0+nc, K0:K0+kdepth]^T on the n x n matrix at A (leading dimension ld); lower
+// tiles only when the block is square on the diagonal
+static int trailing_update(gpry_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t K0, int64_t r0, int64_t c0, int64_t nc, int kdepth) {
+    if (r0 >= n || nc <= 0) return 0;
     GemmArgs g = {};
-    g.A = A + r0 * Np + K0; g.lda = Np;
-    g.B = A + c0 * Np + K0; g.ldb = Np;
-    g.C = A + r0 * Np + c0; g.ldc = Np;
-    g.M = (int)(Np - r0); g.N = (int)nc; g.K = kdepth;
-    g.kmode = KM_FULL; g.lower_only = (r0 == c0 && nc == Np - r0) ? 1 : 0; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
+    g.A = A + r0 * ld + K0; g.lda = ld;
+    g.B = A + c0 * ld + K0; g.ldb = ld;
+    g.C = A + r0 * ld + c0; g.ldc = ld;
+    g.M = (int)(n - r0); g.N = (int)nc; g.K = kdepth;
+    g.kmode = KM_FULL; g.lower_only = (r0 == c0 && nc == n - r0) ? 1 : 0; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
     return gemm_f64_launch(ctx, g, false, true, EPI_SUB);
+}
+struct ChainState { int arrivals = 0; };
+static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t col0, int64_t j0, int64_t Kfrom,
+                        const TileItem* items, int n_items) {
+    const int P = (int)((n - j0) / 64);
+    cs.arrivals += P;
+    PanelArgs pa = {A, ld, j0, Kfrom, ctx->N, col0, ctx->dinfo, ctx->dinfo + 2, cs.arrivals, ctx->bstride};
+    hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + n_items), 1, (unsigned)ctx->bn), dim3(256), 0, ctx->stream, pa, items, P);
+    return trtri_pipeline_step(ctx, (int)((col0 + j0) / 64) + 1);
+}
+// columns [0, head) of the n x n matrix at A (head a multiple of 256, or n)
+static int blocked_head(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t head) {
+    const int64_t OB = 256;
+    for (int64_t K0 = 0; K0 < head; K0 += OB) {
+        const int64_t ob = (n - K0 < OB) ? n - K0 : OB;
+        for (int64_t j0 = K0; j0 < K0 + ob; j0 += 64) GPRY_TRY(panel_launch(ctx, cs, A, ld, n, 0, j0, K0, nullptr, 0));
+        GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + ob, K0 + ob, n - (K0 + ob), (int)ob));
+    }
+    return 0;
+}
+// every step applies the strip before its own; behind a block of two strips, its FIRST strip goes onto the next strip (64 k)
+// and the whole block (128 k) onto everything right of that
+static int separate_chain(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t col0) {
+    for (int64_t K0 = 0; K0 < n; K0 += 128) {
+        for (int64_t j0 = K0; j0 < K0 + 128; j0 += 64) GPRY_TRY(panel_launch(ctx, cs, A, ld, n, col0, j0, j0 >= 64 ? j0 - 64 : 0, nullptr, 0));
+        const int64_t r0 = K0 + 128;
+        if (r0 >= n) break;
+        GPRY_TRY(trailing_update(ctx, A, ld, n, K0, r0, r0, 64, 64));
+        GPRY_TRY(trailing_update(ctx, A, ld, n, K0, r0 + 64, r0 + 64, n - (r0 + 64), 128));
+    }
+    return 0;
+}
+// columns that go through the riding-tile chain at the end of a large factorisation: the last LARGE_TAIL, behind whole
+// outer blocks
+static int64_t large_tail(int64_t Np) {
+    const int64_t tail = 4608;       // measured 3072 ... 6144 at Np = 4608 ... 8192: profiles/r04_potrf.md
+    if (Np <= tail) return Np;
+    int64_t head = (Np - tail + 255) / 256 * 256;       // whole outer blocks in front
+    if (head > Np) head = Np;
+    return Np - head;
 }
 
 int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
-    hipStream_t st = ctx->stream;
-    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
+    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));
     ctx->info_cleared = false;
-    int arrivals = 0;
-    auto panel = [&](int64_t j0, int64_t Kfrom) -> int {
-        const int P = (int)((Np - j0) / 64);
-        arrivals += P;
-        PanelArgs pa = {A, Np, j0, Kfrom, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals, ctx->bstride};
-        hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)P, 1, (unsigned)ctx->bn), dim3(256), 0, st, pa, (const TileItem*)nullptr, P);
-        return trtri_pipeline_step(ctx, (int)(j0 / 64) + 1);
-    };
-    if (Np > 7168) {
-        // production: outer blocks of 256 columns; a step applies the earlier strips of its own block (up to 192 k)
-        const int64_t OB = 256;
-        for (int64_t K0 = 0; K0 < Np; K0 += OB) {
-            const int64_t ob = (Np - K0 < OB) ? Np - K0 : OB;
-            for (int64_t j0 = K0; j0 < K0 + ob; j0 += 64) GPRY_TRY(panel(j0, K0));
-            GPRY_TRY(trailing_update(ctx, A, Np, K0, K0 + ob, K0 + ob, Np - (K0 + ob), (int)ob));
-        }
-    } else {
-        // comparator of the fused schedule (same updates, same order, same arithmetic per element): every step applies the
-        // strip before its own; behind a block of two strips, its FIRST strip goes onto the next strip (64 k) and the whole
-        // block (128 k) onto everything right of that
-        for (int64_t K0 = 0; K0 < Np; K0 += 128) {
-            for (int64_t j0 = K0; j0 < K0 + 128; j0 += 64) GPRY_TRY(panel(j0, j0 >= 64 ? j0 - 64 : 0));
-            const int64_t r0 = K0 + 128;
-            if (r0 >= Np) break;
-            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0, r0, 64, 64));
-            GPRY_TRY(trailing_update(ctx, A, Np, K0, r0 + 64, r0 + 64, Np - (r0 + 64), 128));
-        }
-    }
+    ChainState cs;
+    const int64_t tail = large_tail(Np), head = Np - tail;
+    GPRY_TRY(blocked_head(ctx, cs, A, Np, Np, head));
+    if (tail) GPRY_TRY(separate_chain(ctx, cs, A + head * Np + head, Np, tail, head));
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused schedule (default up to Np = 7168).  One launch per 64-column strip c (launch c factors strip c); a panel of the
+// Riding-tile chain on an n x n matrix.  One launch per 64-column strip c (launch c factors strip c); a panel of the
 // trailing update = the 128 columns of two strips (2p, 2p + 1), cut into 64 x 64 tiles (r, c).  Strip c of block bc = c / 2
 // receives, in this order,
 //   * the panels p <= bc - 2 (c even) / p <= bc - 1 (c odd) as riding tiles, 128 k per visit, in any launch after the
@@ -637,13 +660,11 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
 //     factors the second half (round 4; until then the panel step of launch c applied all 128 columns of panel bc - 1
 //     itself, 17.6k cycles of its ~ 55k, on the panel chain);
 //   * the strip before it (c - 1) by the panel step of launch c itself: left-looking, 64 k -- every step the same.
-// A tile is visited by ONE workgroup per launch (pending panels and the half in the same visit).  The plan depends on Np
-// only and is cached on the device.  Every element receives the same updates in the same order with the same arithmetic as
-// in potrf_lower_fused below Np = 7168: bit-identical factors (tools/ab_chol_overlap.py, tests).  Above Np = 7168 the
-// tiles no longer fit under the panel chain (the 64 x 64 tile is a latency device, not a throughput one):
-// potrf_lower_fused takes over with outer blocks of 256 columns.
+// A tile is visited by ONE workgroup per launch (pending panels and the half in the same visit).  The plan depends on
+// (n, ld) only and is cached on the device.  Every element receives the same updates in the same order with the same arithmetic
+// as in separate_chain: bit-identical factors (tests).
 struct OverlapPlan {
-    int64_t Np = 0;
+    int64_t n = 0, ld = 0;
     TileItem* d_items = nullptr;
     std::vector<int> first, count;      // per launch: slice of d_items
 };
@@ -655,13 +676,13 @@ void overlap_plan_free(gpry_ctx* ctx) {
     ctx->chol_plan = nullptr;
 }
 // returns 1 if no valid plan exists (the caller takes the schedule with separate trailing launches)
-static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
+static int overlap_plan_get(gpry_ctx* ctx, int64_t n, int64_t ld, OverlapPlan** out) {
     if (!ctx->chol_plan) ctx->chol_plan = new OverlapPlan();
     OverlapPlan& pl = *static_cast<OverlapPlan*>(ctx->chol_plan);
-    if (pl.Np == Np) { *out = &pl; return 0; }
+    if (pl.n == n && pl.ld == ld) { *out = &pl; return 0; }
     if (pl.d_items) { (void)hipFree(pl.d_items); pl.d_items = nullptr; }
     pl = OverlapPlan();
-    const int nb = (int)(Np / 128), n64 = (int)(Np / 64), nl = 2 * nb;
+    const int nb = (int)(n / 128), n64 = (int)(n / 64), nl = 2 * nb;
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
     std::vector<int> done((size_t)n64 * n64, 0), last((size_t)n64 * n64, -1);
@@ -669,14 +690,14 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
     std::vector<TileItem> items;
     struct Cand { int slack, c, r, p, n, half; };
     std::vector<Cand> cand;
-    auto item = [&](int r, int c, int p, int n, int half) {
+    auto item = [&](int r, int c, int p, int nn, int half) {
         TileItem it;
-        it.a_off = (int64_t)r * 64 * Np + (int64_t)p * 128;      // 64 rows from tile row r, the 128 columns of panel p
-        it.b_off = (int64_t)c * 64 * Np + (int64_t)p * 128;
-        it.c_off = (int64_t)r * 64 * Np + (int64_t)c * 64;
-        it.ha_off = (int64_t)r * 64 * Np + (int64_t)(c - 2) * 64;     // the 64 columns of strip c - 2
-        it.hb_off = (int64_t)c * 64 * Np + (int64_t)(c - 2) * 64;
-        it.n = n; it.half = half;
+        it.a_off = (int64_t)r * 64 * ld + (int64_t)p * 128;      // 64 rows from tile row r, the 128 columns of panel p
+        it.b_off = (int64_t)c * 64 * ld + (int64_t)p * 128;
+        it.c_off = (int64_t)r * 64 * ld + (int64_t)c * 64;
+        it.ha_off = (int64_t)r * 64 * ld + (int64_t)(c - 2) * 64;     // the 64 columns of strip c - 2
+        it.hb_off = (int64_t)c * 64 * ld + (int64_t)(c - 2) * 64;
+        it.n = nn; it.half = half;
         return it;
     };
     const int multi = 2;                         // panels per visit of a lagging tile
@@ -685,7 +706,7 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
     const int rounds_first = 1, rounds_second = 1;
     for (int l = 0; l < nl; l++) {
         const int b = l / 2;
-        const int P = (int)((Np - ((int64_t)b * 128 + 64 * (l & 1))) / 64);
+        const int P = (int)((n - ((int64_t)b * 128 + 64 * (l & 1))) / 64);
         const int rounds = (l & 1) ? rounds_second : rounds_first;
         const int cap = rounds * (ncu > P ? ncu - P : 0);
         cand.clear();
@@ -700,8 +721,8 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
                 if (last[(size_t)r * n64 + c] >= l) continue;
                 if (half_now) {
                     // everything this strip still waits for goes into ONE visit: the pending whole panels, then the half
-                    const int n = need - p;                      // (all of them are complete: p < need <= bc - 1 <= b)
-                    cand.push_back({0, c, r, p, n, 1});
+                    const int nn = need - p;                     // (all of them are complete: p < need <= bc - 1 <= b)
+                    cand.push_back({0, c, r, p, nn, 1});
                     continue;
                 }
                 if (p >= need || p > b - 1) continue;
@@ -709,10 +730,10 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
                 int slack;
                 if ((c & 1) && p == bc - 1) slack = (2 * bc) - l;                           // must run in launch 2 bc
                 else slack = (2 * bc - l) - ((bc - 1) - p);                                  // older updates: before block bc
-                int n = avail < multi ? avail : multi;
+                int nn = avail < multi ? avail : multi;
                 // far tiles wait until `multi` panels are pending (fewer, longer visits); near ones cannot
-                if (n < multi && slack > 2 * multi) continue;
-                cand.push_back({slack, c, r, p, n, 0});
+                if (nn < multi && slack > 2 * multi) continue;
+                cand.push_back({slack, c, r, p, nn, 0});
             }
         }
         std::sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) {
@@ -744,37 +765,36 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
         if (e != hipSuccess) {
             if (pl.d_items) (void)hipFree(pl.d_items);
             pl = OverlapPlan();
-            return gpry_fail(ctx, -2, "Cholesky overlap plan (Np = %lld): %s", (long long)Np, hipGetErrorString(e));
+            return gpry_fail(ctx, -2, "Cholesky overlap plan (n = %lld): %s", (long long)n, hipGetErrorString(e));
         }
     }
-    pl.Np = Np;
+    pl.n = n; pl.ld = ld;
     *out = &pl;
     return 0;
 }
 
-int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
-    OverlapPlan* pl = nullptr;
-    const bool too_large = Np > 7168;       // measured: -10 % at 6144, -1 % at 7168, +3 % at 8192 against separate trailing launches
-    const int prc = too_large ? 1 : overlap_plan_get(ctx, Np, &pl);
-    if (prc == 1) return potrf_lower_fused(ctx, A, Np);
-    if (prc) return prc;
-    hipStream_t st = ctx->stream;
-    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), st));
-    ctx->info_cleared = false;
-    int arrivals = 0;
+static int riding_chain(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t col0, const OverlapPlan* pl) {
     int l = 0;
-    for (int64_t K0 = 0; K0 < Np; K0 += 128) {
+    for (int64_t K0 = 0; K0 < n; K0 += 128)
         for (int s = 0; s < 2; s++, l++) {
             const int64_t j0 = K0 + 64 * s;
-            const int P = (int)((Np - j0) / 64);
-            arrivals += P;
             // every step applies the strip before its own (64 k, left-looking) itself
-            PanelArgs pa = {A, Np, j0, j0 >= 64 ? j0 - 64 : 0, ctx->N, ctx->dinfo, ctx->dinfo + 2, arrivals, ctx->bstride};
-            hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + pl->count[l]), 1, (unsigned)ctx->bn), dim3(256), 0, st, pa,
-                               pl->d_items + pl->first[l], P);
-            GPRY_TRY(trtri_pipeline_step(ctx, (int)(j0 / 64) + 1));
+            GPRY_TRY(panel_launch(ctx, cs, A, ld, n, col0, j0, j0 >= 64 ? j0 - 64 : 0, pl->d_items + pl->first[l], pl->count[l]));
         }
-    }
+    return 0;
+}
+
+int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
+    const int64_t tail = large_tail(Np), head = Np - tail;
+    OverlapPlan* pl = nullptr;
+    const int prc = tail ? overlap_plan_get(ctx, tail, Np, &pl) : 1;
+    if (prc == 1) return potrf_lower_fused(ctx, A, Np);
+    if (prc) return prc;
+    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));
+    ctx->info_cleared = false;
+    ChainState cs;
+    GPRY_TRY(blocked_head(ctx, cs, A, Np, Np, head));
+    GPRY_TRY(riding_chain(ctx, cs, A + head * Np + head, Np, tail, head, pl));
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -140,7 +140,7 @@ struct gpry_ctx {
                                        // (gemm_dma.hip; a gain up to 5120, neutral at 6144, a loss at 8192); 0 = off
     int64_t opt_topk_host = 16384;    // pools up to this size are selected on the host (gpry_sweep_topk)
     int opt_factor_pipeline = 1;  // 1: V = L^-1 phases run on stream2 underneath potrf
-    int opt_factor_pipeline_min = 4096;   // from this Np on (neutral at 3072, a loss at 2048: tools/ab_factor_pipeline.py)
+    int opt_factor_pipeline_min = 1280;   // from this Np on (ahead by 2-6% from 1280 up, level below: tools/r04/ab_pipeline_now.py)
     void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
 
     // resident predict kernel (server.hip)
@@ -304,8 +304,8 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
 // host_res (nullable, mapped host memory): [logdet/2, quad, grad...] and dinfo[0..1] as doubles at info_at, status last
 
 // ---- chol.hip ----------------------------------------------------------------------
-int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // panel steps, trailing update as its own launches (Np > 7168; comparator)
-int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);     // panel step + previous trailing tiles in ONE launch (default)
+int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // panel steps, every trailing update its own launch (comparator)
+int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);     // panel step + earlier trailing tiles in ONE launch; above Np = 4608 behind SYRK-updated outer blocks (default)
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
 // V = L^-1 queued phase by phase underneath potrf (chol.hip); begin returns 1 when the size is not cut
 int trtri_pipeline_begin(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);

@@ -81,10 +81,11 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *     "timing" 0/1            per-stage HIP-event timers (gpry_timing_get); off by default, switched on by gpry_timing_reset
  *   factorisation (gpry/gpr.py:1453-1465)
  *     "chol" 0/1              0 (default): hand-written MFMA Cholesky + V = L^-1; 1: rocSOLVER dpotrf / dtrtri (comparator)
- *     "chol_overlap" 0/1      1 (default): trailing-update tiles ride in the Cholesky panel launches; 0: separate trailing
- *                             launches (the production schedule above 7168 padded rows; bit-identical factors below)
+ *     "chol_overlap" 0/1      1 (default): trailing-update tiles ride in the Cholesky panel launches (above 4608 padded rows:
+ *                             for the last 4608 columns, behind blocks of 256 columns with one SYRK launch each); 0: every
+ *                             trailing update its own launch (comparator; bit-identical factors)
  *     "factor_pipeline" 0/1   V = L^-1 is queued phase by phase on a second stream underneath the Cholesky panel chain
- *                             (default 1; bit-identical), from "factor_pipeline_min" padded rows on (default 4096)
+ *                             (default 1; bit-identical), from "factor_pipeline_min" padded rows on (default 1280)
  *     "gemm_dma" 0/1          1 (default): LDS-DMA staged, software-pipelined GEMM engine for the sweep contraction and the
  *                             128-aligned products of the factor chain; 0: register-staged engine (comparator)
  *     "gemm_streamk"          largest padded size at which the top levels of V = L^-1 and K^-1 = V^T V run as stream-K

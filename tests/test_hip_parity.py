@@ -926,13 +926,14 @@ def test_bordered_append_reports_a_non_positive_definite_border(dev):
         dev.predict(X[:3], return_std=True)           # no valid factor any more: the caller must refactorise
 
 
-@pytest.mark.parametrize("N", [100, 200, 300, 1100, 2100, 3100, 4096, 5000, 6100])
+@pytest.mark.parametrize("N", [100, 200, 300, 1100, 2100, 3100, 4096, 5000, 6100, 7300, 8192])
 def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, N):
-    """Default schedule up to Np = 7168: the trailing update is cut into 64 x 64 tiles that ride as extra
-    workgroups in the panel launches (deadline-driven plan), the panel steps apply the previous panel to their
-    own columns themselves.  Same updates, same order, same arithmetic as the schedule with separate trailing
-    launches (outer block 128): the factor must be bit-identical; a non-positive-definite matrix must report
-    the same leading minor."""
+    """Default schedule: the trailing update is cut into 64 x 64 tiles that ride as extra workgroups in the panel
+    launches (deadline-driven plan), the panel steps apply the previous strip to their own columns themselves.
+    Above Np = 4608 only the last 4608 columns are factored that way (the trailing block behind outer blocks of
+    256 columns with one SYRK launch each).  Same updates, same order, same arithmetic as the schedule with
+    separate trailing launches: the factor must be bit-identical; a non-positive-definite matrix must report
+    the same leading minor (in the tail: as a column of the whole matrix)."""
     d = 4
     rng = np.random.default_rng(N)
     X = rng.uniform(0, 1, (N, d))
@@ -942,7 +943,7 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
     theta = np.log(np.array([3.0, 0.4, 0.5, 0.6, 0.7]))
     dev.set_theta(3, theta)
     try:
-        dev.set_option("chol_overlap", 0)           # separate trailing launches, outer block 128 (up to Np = 7168)
+        dev.set_option("chol_overlap", 0)           # every trailing update its own launch
         assert dev.factorize() == 0
         L0, V0, a0 = dev.get_factor()
         lml0 = dev.lml(theta, True)
@@ -972,10 +973,10 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
         dev.set_option("chol_overlap", 1)
 
 
-@pytest.mark.parametrize("N", [1000, 1100, 2100, 4096, 5000, 6100, 7300])
+@pytest.mark.parametrize("N", [1000, 1100, 1300, 1700, 2100, 4096, 5000, 6100, 7300])
 def test_pipelined_factor_chain_is_bit_identical(dev, N):
     """V = L^-1 queued phase by phase on a second stream underneath the Cholesky panel chain
-    (``factor_pipeline=1``, default from Np = 4096): same products, same split-K factors, same operands as
+    (``factor_pipeline=1``, default from Np = 1280): same products, same split-K factors, same operands as
     the serial chain -- L, V, alpha_, the LML and its gradient must be bit-identical, on power-of-two and
     ragged block counts, with both Cholesky schedules, and a non-positive-definite matrix must report the
     same leading minor."""
@@ -988,7 +989,7 @@ def test_pipelined_factor_chain_is_bit_identical(dev, N):
     theta = np.log(np.array([3.0, 0.4, 0.5, 0.6, 0.7, 0.8]))
     dev.set_theta(3, theta)
     try:
-        dev.set_option("factor_pipeline_min", 0)        # default: from Np = 4096 on
+        dev.set_option("factor_pipeline_min", 0)        # default: from Np = 1280 on
         for overlap in (1, 0):
             dev.set_option("chol_overlap", overlap)
             dev.set_option("factor_pipeline", 0)
@@ -1019,7 +1020,7 @@ def test_pipelined_factor_chain_is_bit_identical(dev, N):
     finally:
         dev.set_option("chol_overlap", 1)
         dev.set_option("factor_pipeline", 1)
-        dev.set_option("factor_pipeline_min", 4096)
+        dev.set_option("factor_pipeline_min", 1280)
 
 
 

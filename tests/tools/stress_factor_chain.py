@@ -35,6 +35,6 @@ for N, d in ((4096, 16), (5000, 8), (3000, 4), (6100, 6)):
             bad += 1
             print(f"N={N} repetition {r}: differs from the first", flush=True)
     print(f"N={N}: {reps} repetitions done", flush=True)
-dev.set_option("factor_pipeline_min", 4096)
+dev.set_option("factor_pipeline_min", 1280)
 print(f"{bad} deviations")
 sys.exit(1 if bad else 0)

@@ -41,5 +41,5 @@ for N, d in [(int(a), 8 if int(a) < 4096 else (16 if int(a) < 8192 else 20)) for
             print(f"N={N:5d} factor_pipeline={pipe} stream-K {int(spine < 0)}: factorize {tf:7.3f} ms  lml+grad {tl:7.3f} ms   stage timers us: "
                   f"potrf {t['potrf']:8.1f} trtri {t['trtri']:7.1f} lauum {t['lauum']:7.1f}   V bit-identical to the first: {np.array_equal(V, ref)}  max |dV| {np.max(np.abs(V - ref)):.1e}", flush=True)
 dev.set_option("factor_pipeline", 1)
-dev.set_option("factor_pipeline_min", 4096)
+dev.set_option("factor_pipeline_min", 1280)
 dev.set_option("gemm_streamk", 5632)
