@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/r04
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout 2400 python -m pytest $R/tests -x -q -m gpu 2>&1 | tail -8 > $R/gpurun_out/r04/all_gpu_tests.log
+timeout 2400 python -m pytest $R/tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $R/gpurun_out/r04/all_gpu_tests.log
 timeout 1200 python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/r04/bench_final.json 2> $R/gpurun_out/r04/bench_final.err
 rm -rf /tmp/prof_b
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o p -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-baseline off --extras off > $R/gpurun_out/r04/bench_under_rocprof.json 2> /dev/null
