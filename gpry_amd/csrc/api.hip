@@ -594,7 +594,11 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
                      double zeta, double baseline, double sigma_n, bool allow_split = false) {
     const int64_t Np = ctx->Np;
     const int nt = (int)(Np / 128);
+    // candidates per chunk: the K* panel of a chunk (Np x chunk doubles) is 1 GiB at Np = 4096 and stays that size for smaller
+    // models -- at Np = 1024 the 1e5 candidates of BASELINE configs[1] are ONE launch of 6256 tiles instead of three and a
+    // ragged fourth (contraction 0.60 -> 0.71 of peak); a candidate's result does not depend on the chunking
     int64_t chunk = ctx->opt_sweep_chunk;
+    if (chunk <= 0) chunk = Np < 4096 ? round_up(32768 * 4096 / Np, 1024) : 32768;
     if (chunk > round_up(M, 128)) chunk = round_up(M, 128);
     if (Np * chunk > ctx->kst_cap) {
         if (ctx->dKst) GPRY_TRY(dev_free(ctx, ctx->dKst));

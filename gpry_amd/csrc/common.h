@@ -31,7 +31,7 @@ struct gpry_ctx {
 
     // options
     int opt_chol = 0;
-    int64_t opt_sweep_chunk = 32768;
+    int64_t opt_sweep_chunk = 0;         // 0: 32768 at Np >= 4096, proportionally more below (same panel bytes)
     int opt_timing = 0;          // per-stage HIP-event timers: off until gpry_timing_reset (or "timing" = 1) asks for them
     bool xs_foreign = false;     // dXs holds coordinates scaled for an LML evaluation's theta, not the prediction factor's (ensure_pred_xs)
     bool info_cleared = false;   // dinfo[0..3] were zeroed by launch_scale_train and nothing has touched them since

@@ -99,7 +99,8 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                             (default 4096: beyond it the host's thread farm of three contexts is faster; 0 = one after another)
  *     "lml_batch_mb"          upper limit of the scratch arena of such a batch in MiB (default 49152; longer batches go in chunks)
  *   predict / sweep (gpry/gpr.py:1022-1273, gpry/gp_acquisition.py:971-1108)
- *     "sweep_chunk"           candidates per sweep chunk (default 32768, rounded up to a multiple of 1024)
+ *     "sweep_chunk"           candidates per sweep chunk, rounded up to a multiple of 1024 (default 0 = 32768 from 4096 padded
+ *                             training rows on and proportionally more below: the K* panel of a chunk stays 1 GiB)
  *     "cross_mfma" 0/1        1 (default): the cross-kernel panel of sweeps and large predict batches takes its squared
  *                             distances from the matrix pipe (centred coordinates, |x|^2 + |y|^2 - 2 x.y); 0: the difference
  *                             form (comparator; gpry_kernel_cross, the small batches and Matern-1/2 always use it)

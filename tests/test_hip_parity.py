@@ -628,7 +628,7 @@ def test_multi_chunk_sweep_with_masks_vs_oracle(dev, M, chunk):
         dev.set_option("sweep_chunk", chunk)
         out = dev.sweep_logexp(Xc, zeta, m.y_max, m.noise_level, mask=mask)
     finally:
-        dev.set_option("sweep_chunk", 32768)
+        dev.set_option("sweep_chunk", 0)
     fin = np.isfinite(rm)
     assert np.array_equal(np.isneginf(out["y"]), ~fin)
     np.testing.assert_allclose(out["y"][fin], rm[fin], rtol=1e-8, atol=1e-8)
@@ -826,7 +826,7 @@ def test_sweep_with_alternating_k_walk_is_chunking_independent(dev, N):
                 res[dma, chunk] = (out["y"].copy(), out["sigma"].copy())
     finally:
         dev.set_option("gemm_dma", 1)
-        dev.set_option("sweep_chunk", 32768)
+        dev.set_option("sweep_chunk", 0)
     for dma in (1, 0):
         for chunk in (5120, 1024):
             np.testing.assert_array_equal(res[dma, chunk][1], res[dma, 8192][1])
@@ -1190,7 +1190,7 @@ def test_cross_kernel_panel_with_distances_from_the_matrix_pipe(dev, N, d, ls, k
             out[mf] = (r["y"].copy(), r["sigma"].copy())
     finally:
         dev.set_option("cross_mfma", 1)
-        dev.set_option("sweep_chunk", 32768)
+        dev.set_option("sweep_chunk", 0)
     scale = max(1.0, np.max(np.abs(out[0][0])))
     if kid == 1:
         np.testing.assert_array_equal(out[1][0], out[0][0])
