@@ -87,10 +87,11 @@ def minimize_lockstep(fg_batch, X0, bounds, m=10, factr=1e7, pgtol=1e-5, maxfun=
                 _lbfgsb.setulb(m, r.x, low_bnd, upper_bnd, nbd, r.f, r.g, factr, pgtol, r.wa, r.iwa, r.task, r.lsave,
                                r.isave, r.dsave, maxls, r.ln_task)
                 if r.task[0] == 3:                     # wants f and g at r.x
-                    if r.seen_x is not None and np.array_equal(r.x, r.seen_x):
+                    if r.seen_x is not None and not (r.x != r.seen_x).any():
                         # the routine asks again for the point it was just given (scipy's wrapper answers from its cache
                         # without calling the function: neither do we)
-                        r.f, r.g = np.array(r.seen_f), np.array(r.seen_g)
+                        r.f[()] = r.seen_f
+                        r.g[:] = r.seen_g
                         continue
                     waiting.append(i)
                     break
@@ -107,9 +108,14 @@ def minimize_lockstep(fg_batch, X0, bounds, m=10, factr=1e7, pgtol=1e-5, maxfun=
             F, G = fg_batch(np.array([runs[i].x for i in waiting]))
             for j, i in enumerate(waiting):
                 r = runs[i]
-                r.f = np.array(F[j], dtype=np.float64)
-                r.g = np.array(G[j], dtype=np.float64)
-                r.seen_x, r.seen_f, r.seen_g = r.x.copy(), r.f.copy(), r.g.copy()
+                r.f[()] = F[j]
+                r.g[:] = G[j]
+                if r.seen_x is None:
+                    r.seen_x, r.seen_g = r.x.copy(), r.g.copy()
+                else:
+                    r.seen_x[:] = r.x
+                    r.seen_g[:] = r.g
+                r.seen_f = float(F[j])
                 r.nfev += 1
         active = [i for i in active if not runs[i].done]
     return (np.array([r.x for r in runs]), np.array([float(r.f) for r in runs]),
