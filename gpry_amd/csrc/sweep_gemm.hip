@@ -141,6 +141,17 @@ __global__ __launch_bounds__(256, 2) void sweep_gemm_dma_sp_kernel(GemmArgs g) {
         ti = (si << ta) + rowin;
         tj = (sj << tc) + (within & ((1 << tc) - 1));
         valid = s < nsi * nsj && si >= 0 && ti < tiles_m && tj < tiles_n;
+        if (nsi == 1) {
+            // A model of up to 1024 rows is ONE super-row whose row tiles differ by up to 8x in length: every super-tile mixes
+            // them, and the launch ends with long tiles running beside idle slots (a k = 1024 tile takes ~ 200 us of a 1.9-ms
+            // launch at M = 1e5).  Longest row tile first over the WHOLE launch instead: the tail is made of the shortest tiles;
+            // consecutive candidate tiles go to different XCDs, each of which keeps the one V row panel in its L2.
+            const int row = (int)blockIdx.x / tiles_n;
+            ti = tiles_m - 1 - row;
+            tj = (int)blockIdx.x - row * tiles_n;
+            valid = row < tiles_m;
+            desc = false;           // (as above for si = 0: the walk direction is a function of the row tile alone)
+        }
     }
     if (valid) {
     const int row0 = ti * BM, col0 = tj * BN;
@@ -282,7 +293,7 @@ int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g) {
     const int tiles_m = g.M / BM, tiles_n = g.N / BN;
     const int a = (g.tile_map >> 4) & 15, c = 6 - a;
     const int64_t nsi = (tiles_m + (1 << a) - 1) >> a, nsj = (tiles_n + (1 << c) - 1) >> c;
-    const dim3 grid((unsigned)(((nsi * nsj + 7) / 8 * 8) * 64));
+    const dim3 grid(nsi == 1 ? (unsigned)(tiles_m * tiles_n) : (unsigned)(((nsi * nsj + 7) / 8 * 8) * 64));
     hipLaunchKernelGGL(sweep_gemm_dma_sp_kernel, grid, dim3(256), 0, ctx->stream, g);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
