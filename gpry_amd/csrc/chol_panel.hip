@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
 // Host side.  A = L L^T in place (lower; the strict upper triangle is left untouched), panel steps of 64 columns.  Three
 // chains, all on sub-blocks (A, ld, n) so that they compose:
 //   blocked_head      outer blocks of 256 columns, the trailing matrix updated by one MFMA SYRK launch per block (read and
-//                     written once per 256 columns; a step applies the earlier strips of its own block, up to 192 k)
+//                     written once per 256 columns); inside a block the older strips reach the later ones as 64 x 64 tiles
 //   separate_chain    the comparator of the riding-tile chain: same updates, same order, same arithmetic per element, every
 //                     trailing update its own launch
 //   riding_chain      trailing tiles riding in the panel launches (plan below)
@@ -605,13 +605,74 @@ static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, in
     hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + n_items), 1, (unsigned)ctx->bn), dim3(256), 0, ctx->stream, pa, items, P);
     return trtri_pipeline_step(ctx, (int)((col0 + j0) / 64) + 1);
 }
-// columns [0, head) of the n x n matrix at A (head a multiple of 256, or n)
-static int blocked_head(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t head) {
-    const int64_t OB = 256;
-    for (int64_t K0 = 0; K0 < head; K0 += OB) {
-        const int64_t ob = (n - K0 < OB) ? n - K0 : OB;
-        for (int64_t j0 = K0; j0 < K0 + ob; j0 += 64) GPRY_TRY(panel_launch(ctx, cs, A, ld, n, 0, j0, K0, nullptr, 0));
-        GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + ob, K0 + ob, n - (K0 + ob), (int)ob));
+// columns [0, head) of the n x n matrix at A (head a multiple of 256): outer blocks of four strips.  Every step applies the
+// strip before its own; what the third and fourth strip of a block still need from the block's first strips (64 k of strip 0
+// onto strip 2, 128 k of strips 0-1 onto strip 3) is applied as 64 x 64 tiles -- riding in the launches of strip 1 and
+// strip 2 (`ride`: the device list of head_plan_get), or as launches of their own (the comparator) -- and one SYRK launch
+// applies the whole block (256 k) to everything right of it.  (Until round 4 the steps applied up to three earlier strips of
+// their block themselves: 16 / 21 / 27 / 32 us per step at N = 8192.)
+struct HeadPlan {
+    int64_t n = 0, ld = 0, head = 0;
+    TileItem* d_items = nullptr;
+    std::vector<int> first, count;      // per launch (four per outer block): slice of d_items
+};
+static void head_plan_free(gpry_ctx* ctx) {
+    HeadPlan* pl = static_cast<HeadPlan*>(ctx->chol_head_plan);
+    if (!pl) return;
+    if (pl->d_items) (void)hipFree(pl->d_items);
+    delete pl;
+    ctx->chol_head_plan = nullptr;
+}
+static int head_plan_get(gpry_ctx* ctx, int64_t n, int64_t ld, int64_t head, HeadPlan** out) {
+    if (!ctx->chol_head_plan) ctx->chol_head_plan = new HeadPlan();
+    HeadPlan& pl = *static_cast<HeadPlan*>(ctx->chol_head_plan);
+    if (pl.n == n && pl.ld == ld && pl.head == head) { *out = &pl; return 0; }
+    if (pl.d_items) { (void)hipFree(pl.d_items); pl.d_items = nullptr; }
+    pl = HeadPlan();
+    const int n64 = (int)(n / 64);
+    std::vector<TileItem> items;
+    auto item = [&](int r, int c, int64_t K0, int nn, int half) {
+        TileItem it;
+        it.a_off = (int64_t)r * 64 * ld + K0;        // 64 rows from tile row r, the 128 columns of the block's first two strips
+        it.b_off = (int64_t)c * 64 * ld + K0;
+        it.c_off = (int64_t)r * 64 * ld + (int64_t)c * 64;
+        it.ha_off = it.a_off;                        // the 64 columns of the block's first strip
+        it.hb_off = it.b_off;
+        it.n = nn; it.half = half;
+        return it;
+    };
+    for (int64_t K0 = 0; K0 < head; K0 += 256) {
+        const int c0 = (int)(K0 / 64);
+        for (int s = 0; s < 4; s++) {
+            pl.first.push_back((int)items.size());
+            if (s == 1) for (int r = c0 + 2; r < n64; r++) items.push_back(item(r, c0 + 2, K0, 0, 1));
+            if (s == 2) for (int r = c0 + 3; r < n64; r++) items.push_back(item(r, c0 + 3, K0, 1, 0));
+            pl.count.push_back((int)items.size() - pl.first.back());
+        }
+    }
+    if (!items.empty()) {
+        hipError_t e = hipMalloc((void**)&pl.d_items, items.size() * sizeof(TileItem));
+        if (e == hipSuccess) e = hipMemcpy(pl.d_items, items.data(), items.size() * sizeof(TileItem), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (pl.d_items) (void)hipFree(pl.d_items);
+            pl = HeadPlan();
+            return gpry_fail(ctx, -2, "Cholesky head plan (n = %lld): %s", (long long)n, hipGetErrorString(e));
+        }
+    }
+    pl.n = n; pl.ld = ld; pl.head = head;
+    *out = &pl;
+    return 0;
+}
+static int blocked_head(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t head, const HeadPlan* ride) {
+    int l = 0;
+    for (int64_t K0 = 0; K0 < head; K0 += 256) {
+        for (int s = 0; s < 4; s++, l++) {
+            const int64_t j0 = K0 + 64 * s;
+            GPRY_TRY(panel_launch(ctx, cs, A, ld, n, 0, j0, s ? j0 - 64 : j0, ride ? ride->d_items + ride->first[l] : nullptr, ride ? ride->count[l] : 0));
+            if (!ride && s == 1) GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + 128, K0 + 128, 64, 64));
+            if (!ride && s == 2) GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + 192, K0 + 192, 64, 128));
+        }
+        GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + 256, K0 + 256, n - (K0 + 256), 256));
     }
     return 0;
 }
@@ -642,7 +703,7 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
     ctx->info_cleared = false;
     ChainState cs;
     const int64_t tail = large_tail(Np), head = Np - tail;
-    GPRY_TRY(blocked_head(ctx, cs, A, Np, Np, head));
+    GPRY_TRY(blocked_head(ctx, cs, A, Np, Np, head, nullptr));
     if (tail) GPRY_TRY(separate_chain(ctx, cs, A + head * Np + head, Np, tail, head));
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -669,6 +730,7 @@ struct OverlapPlan {
     std::vector<int> first, count;      // per launch: slice of d_items
 };
 void overlap_plan_free(gpry_ctx* ctx) {
+    head_plan_free(ctx);
     OverlapPlan* pl = static_cast<OverlapPlan*>(ctx->chol_plan);
     if (!pl) return;
     if (pl->d_items) (void)hipFree(pl->d_items);
@@ -792,8 +854,10 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
     if (prc) return prc;
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));
     ctx->info_cleared = false;
+    HeadPlan* hp = nullptr;
+    if (head) GPRY_TRY(head_plan_get(ctx, Np, Np, head, &hp));
     ChainState cs;
-    GPRY_TRY(blocked_head(ctx, cs, A, Np, Np, head));
+    GPRY_TRY(blocked_head(ctx, cs, A, Np, Np, head, hp));
     GPRY_TRY(riding_chain(ctx, cs, A + head * Np + head, Np, tail, head, pl));
     HIP_TRY(ctx, hipGetLastError());
     return 0;
