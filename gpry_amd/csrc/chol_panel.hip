@@ -578,11 +578,11 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
 //   separate_chain    the comparator of the riding-tile chain: same updates, same order, same arithmetic per element, every
 //                     trailing update its own launch
 //   riding_chain      trailing tiles riding in the panel launches (plan below)
-// potrf_lower_overlap (default) = riding_chain up to Np = 4608.  Beyond that the riding tiles no longer fit under the panel
+// potrf_lower_overlap (default) = riding_chain up to Np = 3584.  Beyond that the riding tiles no longer fit under the panel
 // chain (the 64 x 64 tile is a latency device, not a throughput one: alone it lost to separate launches from Np ~ 7168 on), so
 // the first columns go through blocked_head -- where the trailing matrix is large and the SYRK launches fill the GPU -- and
-// the last 4608, an independent factorisation of the updated trailing block, through riding_chain (round 4: 6.60 -> 5.98 ms
-// at Np = 8192, 4.98 -> 4.54 at 7168; the SYRK launches of that part had shrunk to one 35-us tile latency each).
+// the last 3584, an independent factorisation of the updated trailing block, through riding_chain (round 4: 6.60 -> 5.72 ms
+// at Np = 8192, 4.98 -> 4.33 at 7168; the SYRK launches of that part had shrunk to one 35-us tile latency each).
 // potrf_lower_fused ("chol_overlap" = 0) = the same with separate_chain in place of riding_chain: bit-identical factors.
 // C[r0:, c0:c0+nc] -= A[r0:, K0:K0+kdepth] A[c0:c0+nc, K0:K0+kdepth]^T on the n x n matrix at A (leading dimension ld); lower
 // tiles only when the block is square on the diagonal
@@ -691,7 +691,7 @@ static int separate_chain(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, 
 // columns that go through the riding-tile chain at the end of a large factorisation: the last LARGE_TAIL, behind whole
 // outer blocks
 static int64_t large_tail(int64_t Np) {
-    const int64_t tail = 4608;       // measured 3072 ... 6144 at Np = 4608 ... 8192: profiles/r04_potrf.md
+    const int64_t tail = 3584;       // flat between 3584 and 4608 at Np = 4096 ... 8192 (sweeps in profiles/r04_potrf.md)
     if (Np <= tail) return Np;
     int64_t head = (Np - tail + 255) / 256 * 256;       // whole outer blocks in front
     if (head > Np) head = Np;

@@ -930,7 +930,7 @@ def test_bordered_append_reports_a_non_positive_definite_border(dev):
 def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, N):
     """Default schedule: the trailing update is cut into 64 x 64 tiles that ride as extra workgroups in the panel
     launches (deadline-driven plan), the panel steps apply the previous strip to their own columns themselves.
-    Above Np = 4608 only the last 4608 columns are factored that way (the trailing block behind outer blocks of
+    Above Np = 3584 only the last 3584 columns are factored that way (the trailing block behind outer blocks of
     256 columns with one SYRK launch each).  Same updates, same order, same arithmetic as the schedule with
     separate trailing launches: the factor must be bit-identical; a non-positive-definite matrix must report
     the same leading minor (in the tail: as a column of the whole matrix)."""
