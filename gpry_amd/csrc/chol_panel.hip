@@ -571,19 +571,20 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
 }
 
 // ---------------------------------------------------------------------------------------------
-// Host side.  A = L L^T in place (lower; the strict upper triangle is left untouched), panel steps of 64 columns.  Three
-// chains, all on sub-blocks (A, ld, n) so that they compose:
-//   blocked_head      outer blocks of 256 columns, the trailing matrix updated by one MFMA SYRK launch per block (read and
-//                     written once per 256 columns); inside a block the older strips reach the later ones as 64 x 64 tiles
-//   separate_chain    the comparator of the riding-tile chain: same updates, same order, same arithmetic per element, every
-//                     trailing update its own launch
-//   riding_chain      trailing tiles riding in the panel launches (plan below)
-// potrf_lower_overlap (default) = riding_chain up to Np = 3584.  Beyond that the riding tiles no longer fit under the panel
-// chain (the 64 x 64 tile is a latency device, not a throughput one: alone it lost to separate launches from Np ~ 7168 on), so
-// the first columns go through blocked_head -- where the trailing matrix is large and the SYRK launches fill the GPU -- and
-// the last 3584, an independent factorisation of the updated trailing block, through riding_chain (round 4: 6.60 -> 5.72 ms
-// at Np = 8192, 4.98 -> 4.33 at 7168; the SYRK launches of that part had shrunk to one 35-us tile latency each).
-// potrf_lower_fused ("chol_overlap" = 0) = the same with separate_chain in place of riding_chain: bit-identical factors.
+// Host side.  A = L L^T in place (lower; the strict upper triangle is left untouched), panel steps of 64 columns.
+// The factorisation is a sequence of SEGMENTS, each a chain of `ncols` strips on the trailing block that starts at its first
+// column (nrows x nrows, leading dimension Np):
+//   * up to Np = LARGE_TAIL one segment: the whole matrix;
+//   * beyond that, outer blocks of up to HEAD_BLOCK columns first -- behind each of them ONE MFMA SYRK launch applies the block to
+//     everything right of it (where the trailing matrix is large these fill the GPU; the trailing matrix is read and written
+//     once per block) -- and the last LARGE_TAIL columns, an independent factorisation of the updated trailing block, as the
+//     final segment (its SYRK launches would be one 35-us tile latency each).
+// Inside a segment every step applies the strip before its own (64 k, left-looking); what a strip needs from the older strips
+// of its segment reaches it as 64 x 64 tiles -- riding in the panel launches by a deadline-driven plan (potrf_lower_overlap,
+// the default), or as launches of their own (potrf_lower_fused, "chol_overlap" = 0: the comparator).  Same updates, same
+// order, same arithmetic per element in both: bit-identical factors.
+// Round 4: potrf 6.65 -> 5.7 ms at Np = 8192, 4.96 -> 4.3 at 7168 (segments; in-block updates as riding tiles instead of
+// up to three extra chunks in the panel steps), 1.70 -> 1.54 at 4096 (half-panel riding): profiles/r04_potrf.md.
 // C[r0:, c0:c0+nc] -= A[r0:, K0:K0+kdepth] A[c0:c0+nc, K0:K0+kdepth]^T on the n x n matrix at A (leading dimension ld); lower
 // tiles only when the block is square on the diagonal
 static int trailing_update(gpry_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t K0, int64_t r0, int64_t c0, int64_t nc, int kdepth) {
@@ -597,6 +598,7 @@ static int trailing_update(gpry_ctx* ctx, double* A, int64_t ld, int64_t n, int6
     return gemm_f64_launch(ctx, g, false, true, EPI_SUB);
 }
 struct ChainState { int arrivals = 0; };
+// one panel step of the n x n block at A (columns col0.. of the whole matrix), tiles riding along
 static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t col0, int64_t j0, int64_t Kfrom,
                         const TileItem* items, int n_items) {
     const int P = (int)((n - j0) / 64);
@@ -605,114 +607,70 @@ static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, in
     hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + n_items), 1, (unsigned)ctx->bn), dim3(256), 0, ctx->stream, pa, items, P);
     return trtri_pipeline_step(ctx, (int)((col0 + j0) / 64) + 1);
 }
-// columns [0, head) of the n x n matrix at A (head a multiple of 256): outer blocks of four strips.  Every step applies the
-// strip before its own; what the third and fourth strip of a block still need from the block's first strips (64 k of strip 0
-// onto strip 2, 128 k of strips 0-1 onto strip 3) is applied as 64 x 64 tiles -- riding in the launches of strip 1 and
-// strip 2 (`ride`: the device list of head_plan_get), or as launches of their own (the comparator) -- and one SYRK launch
-// applies the whole block (256 k) to everything right of it.  (Until round 4 the steps applied up to three earlier strips of
-// their block themselves: 16 / 21 / 27 / 32 us per step at N = 8192.)
-struct HeadPlan {
-    int64_t n = 0, ld = 0, head = 0;
-    TileItem* d_items = nullptr;
-    std::vector<int> first, count;      // per launch (four per outer block): slice of d_items
-};
-static void head_plan_free(gpry_ctx* ctx) {
-    HeadPlan* pl = static_cast<HeadPlan*>(ctx->chol_head_plan);
-    if (!pl) return;
-    if (pl->d_items) (void)hipFree(pl->d_items);
-    delete pl;
-    ctx->chol_head_plan = nullptr;
-}
-static int head_plan_get(gpry_ctx* ctx, int64_t n, int64_t ld, int64_t head, HeadPlan** out) {
-    if (!ctx->chol_head_plan) ctx->chol_head_plan = new HeadPlan();
-    HeadPlan& pl = *static_cast<HeadPlan*>(ctx->chol_head_plan);
-    if (pl.n == n && pl.ld == ld && pl.head == head) { *out = &pl; return 0; }
-    if (pl.d_items) { (void)hipFree(pl.d_items); pl.d_items = nullptr; }
-    pl = HeadPlan();
-    const int n64 = (int)(n / 64);
-    std::vector<TileItem> items;
-    auto item = [&](int r, int c, int64_t K0, int nn, int half) {
-        TileItem it;
-        it.a_off = (int64_t)r * 64 * ld + K0;        // 64 rows from tile row r, the 128 columns of the block's first two strips
-        it.b_off = (int64_t)c * 64 * ld + K0;
-        it.c_off = (int64_t)r * 64 * ld + (int64_t)c * 64;
-        it.ha_off = it.a_off;                        // the 64 columns of the block's first strip
-        it.hb_off = it.b_off;
-        it.n = nn; it.half = half;
-        return it;
-    };
-    for (int64_t K0 = 0; K0 < head; K0 += 256) {
-        const int c0 = (int)(K0 / 64);
-        for (int s = 0; s < 4; s++) {
-            pl.first.push_back((int)items.size());
-            if (s == 1) for (int r = c0 + 2; r < n64; r++) items.push_back(item(r, c0 + 2, K0, 0, 1));
-            if (s == 2) for (int r = c0 + 3; r < n64; r++) items.push_back(item(r, c0 + 3, K0, 1, 0));
-            pl.count.push_back((int)items.size() - pl.first.back());
+
+static const int64_t LARGE_TAIL = 3584, HEAD_BLOCK = 768;       // grid of both in profiles/r04_potrf.md
+struct Segment { int64_t K0; int nrows, ncols; int first_launch; };     // strips of 64; first_launch: index into the plan's per-launch lists
+static std::vector<Segment> segments_of(int64_t Np) {
+    std::vector<Segment> seg;
+    int64_t K0 = 0;
+    int launches = 0;
+    if (Np > LARGE_TAIL) {
+        // the fewest outer blocks of at most HEAD_BLOCK columns that leave at most LARGE_TAIL, all of the same width
+        const int64_t head = Np - LARGE_TAIL, nblk = (head + HEAD_BLOCK - 1) / HEAD_BLOCK;
+        const int64_t ob = round_up((head + nblk - 1) / nblk, 128);
+        for (int64_t b = 0; b < nblk; b++, K0 += ob) {
+            seg.push_back({K0, (int)((Np - K0) / 64), (int)(ob / 64), launches});
+            launches += (int)(ob / 64);
         }
     }
-    if (!items.empty()) {
-        hipError_t e = hipMalloc((void**)&pl.d_items, items.size() * sizeof(TileItem));
-        if (e == hipSuccess) e = hipMemcpy(pl.d_items, items.data(), items.size() * sizeof(TileItem), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            if (pl.d_items) (void)hipFree(pl.d_items);
-            pl = HeadPlan();
-            return gpry_fail(ctx, -2, "Cholesky head plan (n = %lld): %s", (long long)n, hipGetErrorString(e));
-        }
-    }
-    pl.n = n; pl.ld = ld; pl.head = head;
-    *out = &pl;
-    return 0;
+    seg.push_back({K0, (int)((Np - K0) / 64), (int)((Np - K0) / 64), launches});
+    return seg;
 }
-static int blocked_head(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t head, const HeadPlan* ride) {
-    int l = 0;
-    for (int64_t K0 = 0; K0 < head; K0 += 256) {
-        for (int s = 0; s < 4; s++, l++) {
+
+// The comparator of a segment: behind the two strips (2p, 2p + 1) of a panel, strip 2p goes onto strip 2p + 2 (64 k) and the whole
+// panel (128 k) onto every strip right of that, one column strip per launch past the first (the riding tiles never touch a
+// tile above the diagonal; a rectangular launch over several strips would)
+static int separate_chain(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, const Segment& sg) {
+    const int64_t n = (int64_t)sg.nrows * 64;
+    for (int c = 0; c < sg.ncols; c += 2) {
+        const int64_t K0 = (int64_t)c * 64;
+        for (int s = 0; s < 2 && c + s < sg.ncols; s++) {
             const int64_t j0 = K0 + 64 * s;
-            GPRY_TRY(panel_launch(ctx, cs, A, ld, n, 0, j0, s ? j0 - 64 : j0, ride ? ride->d_items + ride->first[l] : nullptr, ride ? ride->count[l] : 0));
-            if (!ride && s == 1) GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + 128, K0 + 128, 64, 64));
-            if (!ride && s == 2) GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + 192, K0 + 192, 64, 128));
+            GPRY_TRY(panel_launch(ctx, cs, A, ld, n, sg.K0, j0, j0 >= 64 ? j0 - 64 : 0, nullptr, 0));
         }
-        GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + 256, K0 + 256, n - (K0 + 256), 256));
+        if (c + 2 < sg.ncols) GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + 128, K0 + 128, 64, 64));
+        if (sg.ncols == sg.nrows) {
+            if (c + 3 < sg.ncols) GPRY_TRY(trailing_update(ctx, A, ld, n, K0, K0 + 192, K0 + 192, n - (K0 + 192), 128));
+        } else {
+            for (int cc = c + 3; cc < sg.ncols; cc++) GPRY_TRY(trailing_update(ctx, A, ld, n, K0, (int64_t)cc * 64, (int64_t)cc * 64, 64, 128));
+        }
     }
     return 0;
 }
-// every step applies the strip before its own; behind a block of two strips, its FIRST strip goes onto the next strip (64 k)
-// and the whole block (128 k) onto everything right of that
-static int separate_chain(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t col0) {
-    for (int64_t K0 = 0; K0 < n; K0 += 128) {
-        for (int64_t j0 = K0; j0 < K0 + 128; j0 += 64) GPRY_TRY(panel_launch(ctx, cs, A, ld, n, col0, j0, j0 >= 64 ? j0 - 64 : 0, nullptr, 0));
-        const int64_t r0 = K0 + 128;
-        if (r0 >= n) break;
-        GPRY_TRY(trailing_update(ctx, A, ld, n, K0, r0, r0, 64, 64));
-        GPRY_TRY(trailing_update(ctx, A, ld, n, K0, r0 + 64, r0 + 64, n - (r0 + 64), 128));
-    }
-    return 0;
-}
-// columns that go through the riding-tile chain at the end of a large factorisation: the last LARGE_TAIL, behind whole
-// outer blocks
-static int64_t large_tail(int64_t Np) {
-    const int64_t tail = 3584;       // flat between 3584 and 4608 at Np = 4096 ... 8192 (sweeps in profiles/r04_potrf.md)
-    if (Np <= tail) return Np;
-    int64_t head = (Np - tail + 255) / 256 * 256;       // whole outer blocks in front
-    if (head > Np) head = Np;
-    return Np - head;
+// behind an outer block: the whole block onto everything right of it
+static int block_update(gpry_ctx* ctx, double* A, int64_t ld, const Segment& sg) {
+    if (sg.ncols == sg.nrows) return 0;
+    const int64_t n = (int64_t)sg.nrows * 64, ob = (int64_t)sg.ncols * 64;
+    return trailing_update(ctx, A, ld, n, 0, ob, ob, n - ob, (int)ob);
 }
 
 int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));
     ctx->info_cleared = false;
     ChainState cs;
-    const int64_t tail = large_tail(Np), head = Np - tail;
-    GPRY_TRY(blocked_head(ctx, cs, A, Np, Np, head, nullptr));
-    if (tail) GPRY_TRY(separate_chain(ctx, cs, A + head * Np + head, Np, tail, head));
+    for (const Segment& sg : segments_of(Np)) {
+        double* As = A + sg.K0 * Np + sg.K0;
+        GPRY_TRY(separate_chain(ctx, cs, As, Np, sg));
+        GPRY_TRY(block_update(ctx, As, Np, sg));
+    }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Riding-tile chain on an n x n matrix.  One launch per 64-column strip c (launch c factors strip c); a panel of the
-// trailing update = the 128 columns of two strips (2p, 2p + 1), cut into 64 x 64 tiles (r, c).  Strip c of block bc = c / 2
-// receives, in this order,
+// Riding tiles of a segment.  One launch per 64-column strip c (launch c factors strip c); a panel of the trailing update =
+// the 128 columns of two strips (2p, 2p + 1), cut into 64 x 64 tiles (r, c).  Strip c of block bc = c / 2 receives, in this
+// order,
 //   * the panels p <= bc - 2 (c even) / p <= bc - 1 (c odd) as riding tiles, 128 k per visit, in any launch after the
 //     panel is complete and before launch c, most urgent first (slack = launches left - updates left), one round of the CUs
 //     the panel step leaves free per launch; a tile far from its deadline waits until two panels are pending and applies
@@ -721,35 +679,27 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np) {
 //     factors the second half (round 4; until then the panel step of launch c applied all 128 columns of panel bc - 1
 //     itself, 17.6k cycles of its ~ 55k, on the panel chain);
 //   * the strip before it (c - 1) by the panel step of launch c itself: left-looking, 64 k -- every step the same.
-// A tile is visited by ONE workgroup per launch (pending panels and the half in the same visit).  The plan depends on
-// (n, ld) only and is cached on the device.  Every element receives the same updates in the same order with the same arithmetic
-// as in separate_chain: bit-identical factors (tests).
+// A tile is visited by ONE workgroup per launch (pending panels and the half in the same visit).  Only the `ncols` strips of
+// the segment receive tiles (an outer block: its SYRK launch takes care of the rest), rows run to the end of the matrix.  The
+// plan depends on Np only and is cached on the device.
 struct OverlapPlan {
-    int64_t n = 0, ld = 0;
+    int64_t Np = 0;
     TileItem* d_items = nullptr;
+    std::vector<Segment> seg;
     std::vector<int> first, count;      // per launch: slice of d_items
 };
 void overlap_plan_free(gpry_ctx* ctx) {
-    head_plan_free(ctx);
     OverlapPlan* pl = static_cast<OverlapPlan*>(ctx->chol_plan);
     if (!pl) return;
     if (pl->d_items) (void)hipFree(pl->d_items);
     delete pl;
     ctx->chol_plan = nullptr;
 }
-// returns 1 if no valid plan exists (the caller takes the schedule with separate trailing launches)
-static int overlap_plan_get(gpry_ctx* ctx, int64_t n, int64_t ld, OverlapPlan** out) {
-    if (!ctx->chol_plan) ctx->chol_plan = new OverlapPlan();
-    OverlapPlan& pl = *static_cast<OverlapPlan*>(ctx->chol_plan);
-    if (pl.n == n && pl.ld == ld) { *out = &pl; return 0; }
-    if (pl.d_items) { (void)hipFree(pl.d_items); pl.d_items = nullptr; }
-    pl = OverlapPlan();
-    const int nb = (int)(n / 128), n64 = (int)(n / 64), nl = 2 * nb;
-    int ncu = 256;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    std::vector<int> done((size_t)n64 * n64, 0), last((size_t)n64 * n64, -1);
-    std::vector<char> halfdone((size_t)n64 * n64, 0);
-    std::vector<TileItem> items;
+// appends the launches of one segment; returns false if a deadline cannot be met
+static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<TileItem>& items, std::vector<int>& first, std::vector<int>& count) {
+    const int nrows = sg.nrows, ncols = sg.ncols;
+    std::vector<int> done((size_t)nrows * ncols, 0), last((size_t)nrows * ncols, -1);
+    std::vector<char> halfdone((size_t)nrows * ncols, 0);
     struct Cand { int slack, c, r, p, n, half; };
     std::vector<Cand> cand;
     auto item = [&](int r, int c, int p, int nn, int half) {
@@ -765,22 +715,20 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t n, int64_t ld, OverlapPlan** 
     const int multi = 2;                         // panels per visit of a lagging tile
     // tile rounds (of the CUs the panel step leaves free) per launch: with every panel step the same length, one round each
     // (measured at N = 4096: 1570 us with 1 / 1, 1601 with 2 / 1, 1625 with 2 / 2, 1632 with 3 / 2; no difference up to 2048)
-    const int rounds_first = 1, rounds_second = 1;
-    for (int l = 0; l < nl; l++) {
+    for (int l = 0; l < ncols; l++) {
         const int b = l / 2;
-        const int P = (int)((n - ((int64_t)b * 128 + 64 * (l & 1))) / 64);
-        const int rounds = (l & 1) ? rounds_second : rounds_first;
-        const int cap = rounds * (ncu > P ? ncu - P : 0);
+        const int P = nrows - l;
+        const int cap = ncu > P ? ncu - P : 0;
         cand.clear();
         // columns not yet factored: c >= 2b (+1 in the block's second launch: its first 64 columns are done)
-        for (int c = 2 * b + (l & 1) > 2 ? 2 * b + (l & 1) : 2; c < n64; c++) {
+        for (int c = 2 * b + (l & 1) > 2 ? 2 * b + (l & 1) : 2; c < ncols; c++) {
             const int bc = c / 2;
             const int need = (c & 1) ? bc : bc - 1;              // whole panels that ride
             // c even: the first half of panel bc - 1 (strip c - 2) rides in launch c - 1, behind the whole panels
             const bool half_now = !(c & 1) && l == c - 1;
-            for (int r = c; r < n64; r++) {
-                const int p = done[(size_t)r * n64 + c];
-                if (last[(size_t)r * n64 + c] >= l) continue;
+            for (int r = c; r < nrows; r++) {
+                const int p = done[(size_t)r * ncols + c];
+                if (last[(size_t)r * ncols + c] >= l) continue;
                 if (half_now) {
                     // everything this strip still waits for goes into ONE visit: the pending whole panels, then the half
                     const int nn = need - p;                     // (all of them are complete: p < need <= bc - 1 <= b)
@@ -803,62 +751,72 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t n, int64_t ld, OverlapPlan** 
             if (x.c != y.c) return x.c < y.c;
             return x.r < y.r;
         });
-        pl.first.push_back((int)items.size());
+        first.push_back((int)items.size());
         int n_taken = 0;
         for (const Cand& q : cand) {
             if (n_taken >= cap && q.slack > 1) continue;          // not urgent and the launch is full
             items.push_back(item(q.r, q.c, q.p, q.n, q.half));
-            done[(size_t)q.r * n64 + q.c] = q.p + q.n; last[(size_t)q.r * n64 + q.c] = l;
-            if (q.half) halfdone[(size_t)q.r * n64 + q.c] = 1;
+            done[(size_t)q.r * ncols + q.c] = q.p + q.n; last[(size_t)q.r * ncols + q.c] = l;
+            if (q.half) halfdone[(size_t)q.r * ncols + q.c] = 1;
             n_taken++;
         }
-        pl.count.push_back(n_taken);
+        count.push_back(n_taken);
         // what the NEXT launch's panel step reads must be complete now
-        const int cnext = (l & 1) ? 2 * (b + 1) : 2 * b + 1;     // the 64-column strip factored next
-        if (cnext >= 2 && cnext < n64) {
+        const int cnext = l + 1;                                 // the 64-column strip factored next
+        if (cnext >= 2 && cnext < ncols) {
             const int bc = cnext / 2, need = (cnext & 1) ? bc : bc - 1;
-            for (int r = cnext; r < n64; r++)
-                if (done[(size_t)r * n64 + cnext] != need || (!(cnext & 1) && !halfdone[(size_t)r * n64 + cnext])) { pl = OverlapPlan(); return 1; }
+            for (int r = cnext; r < nrows; r++)
+                if (done[(size_t)r * ncols + cnext] != need || (!(cnext & 1) && !halfdone[(size_t)r * ncols + cnext])) return false;
         }
     }
+    return true;
+}
+// returns 1 if no valid plan exists (the caller takes the schedule with separate trailing launches)
+static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
+    if (!ctx->chol_plan) ctx->chol_plan = new OverlapPlan();
+    OverlapPlan& pl = *static_cast<OverlapPlan*>(ctx->chol_plan);
+    if (pl.Np == Np) { *out = &pl; return 0; }
+    if (pl.d_items) { (void)hipFree(pl.d_items); pl.d_items = nullptr; }
+    pl = OverlapPlan();
+    int ncu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+    std::vector<TileItem> items;
+    pl.seg = segments_of(Np);
+    for (const Segment& sg : pl.seg)
+        if (!plan_segment(sg, Np, ncu, items, pl.first, pl.count)) { pl = OverlapPlan(); return 1; }
     if (!items.empty()) {
         hipError_t e = hipMalloc((void**)&pl.d_items, items.size() * sizeof(TileItem));
         if (e == hipSuccess) e = hipMemcpy(pl.d_items, items.data(), items.size() * sizeof(TileItem), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             if (pl.d_items) (void)hipFree(pl.d_items);
             pl = OverlapPlan();
-            return gpry_fail(ctx, -2, "Cholesky overlap plan (n = %lld): %s", (long long)n, hipGetErrorString(e));
+            return gpry_fail(ctx, -2, "Cholesky overlap plan (Np = %lld): %s", (long long)Np, hipGetErrorString(e));
         }
     }
-    pl.n = n; pl.ld = ld;
+    pl.Np = Np;
     *out = &pl;
     return 0;
 }
 
-static int riding_chain(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t col0, const OverlapPlan* pl) {
-    int l = 0;
-    for (int64_t K0 = 0; K0 < n; K0 += 128)
-        for (int s = 0; s < 2; s++, l++) {
-            const int64_t j0 = K0 + 64 * s;
-            // every step applies the strip before its own (64 k, left-looking) itself
-            GPRY_TRY(panel_launch(ctx, cs, A, ld, n, col0, j0, j0 >= 64 ? j0 - 64 : 0, pl->d_items + pl->first[l], pl->count[l]));
-        }
-    return 0;
-}
-
 int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
-    const int64_t tail = large_tail(Np), head = Np - tail;
     OverlapPlan* pl = nullptr;
-    const int prc = tail ? overlap_plan_get(ctx, tail, Np, &pl) : 1;
+    const int prc = overlap_plan_get(ctx, Np, &pl);
     if (prc == 1) return potrf_lower_fused(ctx, A, Np);
     if (prc) return prc;
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));
     ctx->info_cleared = false;
-    HeadPlan* hp = nullptr;
-    if (head) GPRY_TRY(head_plan_get(ctx, Np, Np, head, &hp));
     ChainState cs;
-    GPRY_TRY(blocked_head(ctx, cs, A, Np, Np, head, hp));
-    GPRY_TRY(riding_chain(ctx, cs, A + head * Np + head, Np, tail, head, pl));
+    for (const Segment& sg : pl->seg) {
+        double* As = A + sg.K0 * Np + sg.K0;
+        const int64_t n = (int64_t)sg.nrows * 64;
+        for (int c = 0; c < sg.ncols; c++) {
+            const int64_t j0 = (int64_t)c * 64;
+            const int l = sg.first_launch + c;
+            // every step applies the strip before its own (64 k, left-looking) itself
+            GPRY_TRY(panel_launch(ctx, cs, As, Np, n, sg.K0, j0, j0 >= 64 ? j0 - 64 : 0, pl->d_items + pl->first[l], pl->count[l]));
+        }
+        GPRY_TRY(block_update(ctx, As, Np, sg));
+    }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

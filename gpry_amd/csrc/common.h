@@ -141,8 +141,7 @@ struct gpry_ctx {
     int64_t opt_topk_host = 16384;    // pools up to this size are selected on the host (gpry_sweep_topk)
     int opt_factor_pipeline = 1;  // 1: V = L^-1 phases run on stream2 underneath potrf
     int opt_factor_pipeline_min = 1280;   // from this Np on (ahead by 2-6% from 1280 up, level below: tools/r04/ab_pipeline_now.py)
-    void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)
-    void* chol_head_plan = nullptr;   // ... and of the blocked head of a large one   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
+    void* chol_plan = nullptr;    // cached tile schedule of the fused Cholesky (chol_panel.hip)   // cached batch descriptors of the V = L^-1 recursion (chol.hip)
 
     // resident predict kernel (server.hip)
     void* srv = nullptr;
