@@ -305,7 +305,7 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
 
 // ---- chol.hip ----------------------------------------------------------------------
 int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // panel steps, every trailing update its own launch (comparator)
-int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);     // panel step + earlier trailing tiles in ONE launch; above Np = 3584 behind SYRK-updated outer blocks (default)
+int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);     // panel step + earlier trailing tiles in ONE launch; above Np = 3584 segment by segment (default)
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
 // V = L^-1 queued phase by phase underneath potrf (chol.hip); begin returns 1 when the size is not cut
 int trtri_pipeline_begin(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);

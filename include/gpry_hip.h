@@ -81,9 +81,9 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *     "timing" 0/1            per-stage HIP-event timers (gpry_timing_get); off by default, switched on by gpry_timing_reset
  *   factorisation (gpry/gpr.py:1453-1465)
  *     "chol" 0/1              0 (default): hand-written MFMA Cholesky + V = L^-1; 1: rocSOLVER dpotrf / dtrtri (comparator)
- *     "chol_overlap" 0/1      1 (default): trailing-update tiles ride in the Cholesky panel launches (above 3584 padded rows:
- *                             for the last 3584 columns, behind blocks of 256 columns with one SYRK launch each); 0: every
- *                             trailing update its own launch (comparator; bit-identical factors)
+ *     "chol_overlap" 0/1      1 (default): trailing-update tiles ride in the Cholesky panel launches (above 3584 padded rows
+ *                             segment by segment: outer blocks of up to 768 columns, each followed by one SYRK launch, then
+ *                             the last 3584 columns); 0: every update a launch of its own (comparator; bit-identical factors)
  *     "factor_pipeline" 0/1   V = L^-1 is queued phase by phase on a second stream underneath the Cholesky panel chain
  *                             (default 1; bit-identical), from "factor_pipeline_min" padded rows on (default 1280)
  *     "gemm_dma" 0/1          1 (default): LDS-DMA staged, software-pipelined GEMM engine for the sweep contraction and the

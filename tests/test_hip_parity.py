@@ -930,8 +930,8 @@ def test_bordered_append_reports_a_non_positive_definite_border(dev):
 def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, N):
     """Default schedule: the trailing update is cut into 64 x 64 tiles that ride as extra workgroups in the panel
     launches (deadline-driven plan), the panel steps apply the previous strip to their own columns themselves.
-    Above Np = 3584 only the last 3584 columns are factored that way (the trailing block behind outer blocks of
-    256 columns with one SYRK launch each).  Same updates, same order, same arithmetic as the schedule with
+    Above Np = 3584 the matrix is a list of segments: outer blocks of up to 768 columns, each with the riding tiles of
+    its own columns and one SYRK launch behind it for everything to the right, then the last 3584 columns.  Same updates, same order, same arithmetic as the schedule with
     separate trailing launches: the factor must be bit-identical; a non-positive-definite matrix must report
     the same leading minor (in the tail: as a column of the whole matrix)."""
     d = 4
@@ -969,6 +969,19 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
                 dev.set_theta(3, theta)
                 infos.append(dev.factorize())
             assert infos[0] == infos[1] and infos[0] > 0
+        # ... and inside an outer block of the large schedule (its column counts from the start of the whole matrix)
+        if N >= 5000:
+            Xb = X.copy()
+            Xb[700] = Xb[300]
+            alpha = np.full(N, 1e-5)
+            alpha[700] = alpha[300] = -1e-3
+            infos = []
+            for ov in (0, 1):
+                dev.set_option("chol_overlap", ov)
+                dev.set_train(Xb, y, alpha)
+                dev.set_theta(3, theta)
+                infos.append(dev.factorize())
+            assert infos[0] == infos[1] and 300 < infos[0] <= 701
     finally:
         dev.set_option("chol_overlap", 1)
 

@@ -79,7 +79,7 @@ def test_batched_chain_has_the_bits_of_single_evaluations_and_the_oracle_values(
 @pytest.mark.parametrize("N,d,B,kid", [(4096, 16, 5, 3), (5000, 6, 4, 0), (7300, 8, 3, 3)])
 def test_batched_chain_at_the_sizes_of_the_pipelined_and_the_separate_launch_schedules(N, d, B, kid):
     """A single evaluation queues V = L^-1 underneath potrf on a second stream, and above Np = 3584 the Cholesky runs its
-    first columns in outer blocks with separate SYRK launches: a batch keeps everything on the main stream (it has thetas enough
+    first columns in outer blocks with a SYRK launch behind each: a batch keeps everything on the main stream (it has thetas enough
     to fill the GPU) and carries the thetas through the SYRK launches as well -- the per-theta bits are still those of the
     single evaluations (the schedules are bit-identical), and the values are the oracle's at the sizes its blocked
     restatement reaches in seconds."""
