@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const Til
 // of its segment reaches it as 64 x 64 tiles -- riding in the panel launches by a deadline-driven plan (potrf_lower_overlap,
 // the default), or as launches of their own (potrf_lower_fused, "chol_overlap" = 0: the comparator).  Same updates, same
 // order, same arithmetic per element in both: bit-identical factors.
-// Round 4: potrf 6.65 -> 5.7 ms at Np = 8192, 4.96 -> 4.3 at 7168 (segments; in-block updates as riding tiles instead of
+// Round 4: potrf 6.65 -> 5.46 ms at Np = 8192, 4.96 -> 4.1 at 7168 (segments; in-block updates as riding tiles instead of
 // up to three extra chunks in the panel steps), 1.70 -> 1.54 at 4096 (half-panel riding): profiles/r04_potrf.md.
 // C[r0:, c0:c0+nc] -= A[r0:, K0:K0+kdepth] A[c0:c0+nc, K0:K0+kdepth]^T on the n x n matrix at A (leading dimension ld); lower
 // tiles only when the block is square on the diagonal
