@@ -761,6 +761,10 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
             n_taken++;
         }
         count.push_back(n_taken);
+        // longest visits first: when a launch has more tiles than free CUs, the workgroups that start late are the short ones
+        std::stable_sort(items.end() - n_taken, items.end(), [](const TileItem& x, const TileItem& y) {
+            return 2 * x.n + (x.half ? 1 : 0) > 2 * y.n + (y.half ? 1 : 0);
+        });
         // what the NEXT launch's panel step reads must be complete now
         const int cnext = l + 1;                                 // the 64-column strip factored next
         if (cnext >= 2 && cnext < ncols) {
