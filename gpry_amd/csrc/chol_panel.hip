@@ -21,9 +21,31 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// acc += sign * A[16 x K] * B[16 x K]^T ; A, B point at row 0 of their 16-row blocks in LDS
+// acc += sign * A[16 x K] * B[16 x K]^T ; A, B point at row 0 of their 16-row blocks in LDS.  K = 16, 32, 48 or 64: all
+// fragment reads of the product are issued before the first MFMA (a load / wait / MFMA loop exposed the LDS latency in
+// every step: 2.3-2.8k cycles per 16-MFMA tile in the panel step instead of ~1.1k); same MFMA sequence, k ascending.
+template <bool NEG, int KQ>
+__device__ __forceinline__ v4d mfma_nt16_all(v4d acc, const double* A, const double* B, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    double a[KQ], b[KQ];
+#pragma unroll
+    for (int u = 0; u < KQ; u++) { a[u] = A[r * PLD + 4 * u + g]; b[u] = B[r * PLD + 4 * u + g]; }
+    // (without this the scheduler interleaves reads and MFMAs with a full s_waitcnt lgkmcnt(0) every other MFMA)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < KQ; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -a[u] : a[u], b[u], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    return acc;
+}
 template <bool NEG>
 __device__ __forceinline__ v4d mfma_nt16(v4d acc, const double* A, const double* B, int K, int lane) {
+    switch (K) {
+        case 16: return mfma_nt16_all<NEG, 4>(acc, A, B, lane);
+        case 32: return mfma_nt16_all<NEG, 8>(acc, A, B, lane);
+        case 48: return mfma_nt16_all<NEG, 12>(acc, A, B, lane);
+        case 64: return mfma_nt16_all<NEG, 16>(acc, A, B, lane);
+        default: break;
+    }
     const int r = lane & 15, g = lane >> 4;
     for (int k0 = 0; k0 < K; k0 += 4) {
         double a = A[r * PLD + k0 + g];
@@ -168,24 +190,6 @@ __device__ __forceinline__ void trsm16_rows(double* Xr, const double* L, const d
     }
 }
 
-// X[:, 16c .. 16c+15] of the 64-row block sB against the factor in sD, by ONE wave: the update with
-// the columns solved so far (MFMA) and the 16-wide substitution with one row per lane.  Runs on a
-// wave that would otherwise idle while another wave factors the next 16x16 diagonal block.
-__device__ __forceinline__ void solve_block_cols(double* sB, const double* sD, const double* sRd, int c, int lane) {
-    if (c) {
-#pragma unroll 1
-        for (int rt = 0; rt < 4; rt++) {
-            double* T = sB + (rt * 16) * PLD + c * 16;
-            v4d acc = tile_load(T, lane);
-            acc = mfma_nt16<true>(acc, sB + (rt * 16) * PLD, sD + (c * 16) * PLD, c * 16, lane);
-            tile_store(T, acc, lane);
-        }
-        wave_fence();
-    }
-    trsm16_rows<64>(sB + c * 16, sD + (c * 16) * PLD + c * 16, sRd + c * 16, lane);
-    wave_fence();
-}
-
 // 64x64 block global -> LDS in two phases: all eight 16-byte loads of a thread are in flight before
 // the first LDS store (a load/store pair per iteration paid one memory round trip each: the four
 // blocks of a panel step cost 13k cycles that way)
@@ -203,6 +207,24 @@ __device__ __forceinline__ void load_block_commit(double* S, int t, const double
         *reinterpret_cast<double2*>(S + row * PLD + c2) = r[i];
     }
 }
+// The workgroup's own rows (B and P_o, 64x64 each) are dealt to the threads of waves 1..3 only (192 threads x 11 pieces of 16
+// bytes per block, 2048 needed): the panel step keeps them in registers until the wave that holds them first has nothing to
+// do for the factor, and wave 0 is on the factor chain from the first cycle.  Wave 0's lanes (and the surplus pieces) load
+// one fixed element: no branch around the loads, one cache line of extra traffic.  Named registers instead of arrays: arrays
+// that live across the update of D were left in scratch memory by the compiler.
+#define D8_FOR(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define D8_DECL(i) double2 rD##i, rPt##i;
+#define D8_LOAD(i) { const int e_ = t + 256 * i; const int64_t off_ = (int64_t)(e_ >> 5) * ld + (e_ & 31) * 2;        \
+                     rD##i = *reinterpret_cast<const double2*>(gD_ + off_); rPt##i = *reinterpret_cast<const double2*>(gPt_ + off_); }
+#define D8_COMMIT(i) { const int e_ = t + 256 * i; const int o_ = (e_ >> 5) * PLD + (e_ & 31) * 2;                     \
+                       *reinterpret_cast<double2*>(sD + o_) = rD##i; *reinterpret_cast<double2*>(sPt + o_) = rPt##i; }
+#define B3_FOR(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#define B3_DECL(i) double2 rB##i, rPo##i;
+#define B3_LOAD(i) { const int e_ = t - 64 + 192 * i; const bool ok_ = t >= 64 && e_ < 2048;                         \
+                     const int64_t off_ = ok_ ? (int64_t)(e_ >> 5) * ld + (e_ & 31) * 2 : 0;                          \
+                     rB##i = *reinterpret_cast<const double2*>(gB_ + off_); rPo##i = *reinterpret_cast<const double2*>(gPo_ + off_); }
+#define B3_COMMIT(i) { const int e_ = t - 64 + 192 * i; const int o_ = (e_ >> 5) * PLD + (e_ & 31) * 2;               \
+                       if (e_ < 2048) { *reinterpret_cast<double2*>(sB + o_) = rB##i; *reinterpret_cast<double2*>(sPo + o_) = rPo##i; } }
 __device__ __forceinline__ void store_block(double* __restrict__ G, int64_t ld, const double* S, int t,
                                             bool lower_only) {
     for (int e = t; e < 64 * 32; e += 256) {
@@ -314,15 +336,104 @@ int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t N
 // expected up to and including this launch).  Without this the result depends on all workgroups
 // starting before the first one finishes -- not true when another stream shares the GPU.
 struct PanelArgs {
-    double* A; int64_t ld, j0, K0, n_real;      // j0, K0: columns relative to A; n_real: real (unpadded) size of the WHOLE matrix
+    double* A; int64_t ld, j0, K0, n_real;      // j0, K0: columns relative to A (K0 = j0 - 64, or j0 for the first strip); n_real: real (unpadded) size of the WHOLE matrix
     int64_t col0;           // A is the trailing submatrix from column col0 of the whole matrix on (tail of the large schedule)
     int* info; int* arrive; int target;
     int64_t bstride;        // batched launch (gpry_ctx::bn): A, info and arrive of theta blockIdx.z lie this many doubles further on
 };
-#define PANEL_SMEM_DOUBLES (4 * 64 * PLD + 64 + 8)
+#define PANEL_SMEM_DOUBLES (4 * 64 * PLD + 64 + 16)
 
-// One panel step for the 64-row block `bx` of the panel: the columns [K0, j0) of the same rows are applied first
-// (left-looking, 64 at a time), then the 64 x 64 factor and the row solves.
+#ifdef GPRY_PANEL_STAMPS
+// diagnostic build only (tools/r05/build_stamps.sh): s_memtime stamps of three workgroups per panel step
+#define STAMP_STEPS 160
+#define STAMP_SLOTS 8
+__device__ long long g_panel_stamps[STAMP_STEPS][3][4][STAMP_SLOTS];
+#define PANEL_STAMP(slot) do { if (stamp_wg >= 0 && lane == 0) g_panel_stamps[stamp_step][stamp_wg][w][slot] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+// time per kind of own-row task (0: U, 1: M, 2: T incl. its waits, 3: count of tasks), per wave
+__device__ long long g_panel_acc[STAMP_STEPS][3][4][4];
+#define PANEL_ACC_DECL long long acc_t0_ = 0, acc_[4] = {0, 0, 0, 0};
+#define PANEL_ACC_BEGIN do { acc_t0_ = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define PANEL_ACC_END(kind) do { acc_[kind] += (long long)__builtin_amdgcn_s_memtime() - acc_t0_; acc_[3]++; } while (0)
+#define PANEL_ACC_FLUSH do { if (stamp_wg >= 0 && lane == 0) for (int q_ = 0; q_ < 4; q_++) g_panel_acc[stamp_step][stamp_wg][w][q_] = acc_[q_]; } while (0)
+extern "C" int gpry_debug_panel_acc(long long* out, int n) {
+    if (n > STAMP_STEPS * 3 * 4 * 4) n = STAMP_STEPS * 3 * 4 * 4;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_acc), sizeof(long long) * n);
+}
+extern "C" int gpry_debug_panel_stamps(long long* out, int n) {
+    if (n > STAMP_STEPS * 3 * 4 * STAMP_SLOTS) n = STAMP_STEPS * 3 * 4 * STAMP_SLOTS;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_stamps), sizeof(long long) * n);
+}
+// progress codes of every wave of the first workgroups, written straight to mapped host memory: readable while a kernel hangs
+__device__ int* g_panel_progress = nullptr;
+#define PANEL_PROGRESS(code) do { if (g_panel_progress && lane == 0 && bx < 4 && tb == 0) \
+    __hip_atomic_store(g_panel_progress + ((stamp_step & 15) * 4 + bx) * 4 + w, (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+extern "C" int* gpry_debug_progress_buffer() {
+    int* h = nullptr;
+    if (hipHostMalloc((void**)&h, 16 * 4 * 4 * sizeof(int), hipHostMallocMapped) != hipSuccess) return nullptr;
+    memset(h, 0, 16 * 4 * 4 * sizeof(int));
+    int* d = nullptr;
+    if (hipHostGetDevicePointer((void**)&d, h, 0) != hipSuccess) return nullptr;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_panel_progress), &d, sizeof(d)) != hipSuccess) return nullptr;
+    return h;
+}
+extern "C" int gpry_debug_read_info(gpry_ctx* ctx, int* out4) {
+    return (int)hipMemcpy(out4, ctx->dinfo, 4 * sizeof(int), hipMemcpyDeviceToHost);
+}
+#else
+#define PANEL_STAMP(slot) do { } while (0)
+#define PANEL_PROGRESS(code) do { } while (0)
+#define PANEL_ACC_DECL
+#define PANEL_ACC_BEGIN do { } while (0)
+#define PANEL_ACC_END(kind) do { } while (0)
+#define PANEL_ACC_FLUSH do { } while (0)
+#endif
+
+// waits on the LDS words of the panel step are bounded: a wave that has spun for ~0.2 s (or sees that another one has)
+// gives up, the step is reported as failed (info) and marked in info[3] -- never a hung GPU
+#define PANEL_SPIN_CAP (1 << 21)
+// (every value a wave branches on goes through v_readfirstlane: the conditions are wave-uniform by construction, and with
+// that the compiler emits plain scalar loops -- left to its divergence analysis, the task loop below came out as nested
+// exec-masked loops that re-ran a pulled task without pulling the next one)
+__device__ __forceinline__ int lds_peek(int* f, bool acquire) {
+    const int v = acquire ? __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
+                          : __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void lds_wait_ge(int* f, int v, int* s_abort, int id) {       // id: which wait (reported in info[3])
+    for (int n = 0;; n++) {
+        if (lds_peek(f, true) >= v) return;
+        __builtin_amdgcn_s_sleep(1);
+        if (lds_peek(s_abort, false) != 0) return;
+        if (n > PANEL_SPIN_CAP) {
+            __hip_atomic_store(s_abort, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+    }
+}
+__device__ __forceinline__ void lds_publish(int* f, int v, int lane) {         // after a wave_fence(): this wave's LDS writes come first
+    if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_count(int* f, int lane) {
+    if (lane == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One panel step for the 64-row block `bx` of the panel: the strip before its own (columns [K0, j0), 64 of them) is applied
+// first (left-looking), then the 64 x 64 factor and the row solves.
+//
+// Round 5: what does not feed the factor is off the chain.  Until round 4 every workgroup loaded its four 64 x 64 blocks,
+// applied the previous strip to D AND to its own rows (5.9k cycles), factored D (21k), solved its rows (3k) and stored: 38k
+// cycles per step, one after the other.  Now
+//   * all loads of a thread are issued at once, but only D and the previous strip's rows of the diagonal block (P_t) are
+//     waited for and committed to LDS before the factor starts; the workgroup's own rows B and P_o are loaded by waves 1..3
+//     only, stay in registers over their share of the update of D and are committed before those waves first wait for the
+//     factor chain (wave 0, which starts the chain, holds none);
+//   * wave w applies the previous strip to ITS block row of D only (w + 1 tiles; wave 0 starts its 16 x 16 factor after one);
+//   * everything for the workgroup's own rows -- the left-looking update of B (16 tiles of 16 MFMAs), the updates with the
+//     columns solved so far and the four 16-wide solves -- is a list of 32 tasks in dependency order that the waves pull
+//     from an LDS counter once their part of the factor chain is done (wave 0 after one 16 x 16 factor, wave 1 after two ...):
+//     the work fills the time the waves used to idle in, and only the last 16-wide solve is left behind the factor.
+// Every tile sees the same operations in the same order as before (who computes it and when is all that changed; an MFMA chain
+// cut at a multiple of 4 k and resumed from the stored tile is the same chain): factors bit-identical to round 4's.
 __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* smem, const int bx, const int tb) {
     double* __restrict__ A = bset(pa.A, tb, pa.bstride);
     const int64_t ld = pa.ld, j0 = pa.j0, K0 = pa.K0, n_real = pa.n_real;
@@ -334,106 +445,160 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     double* sRd = sPo + 64 * PLD;
     int* s_int = reinterpret_cast<int*>(sRd + 64);
     int& s_bad = s_int[0];
-    int* s_flag = s_int + 2;
+    int* s_abort = s_int + 1;
+    int* s_flag = s_int + 2;        // [0]: 16 x 16 blocks factored, [1 + w]: columns solved by wave w, [5]: own-row column blocks solved
+    int* s_commit = s_int + 10;     // waves (of 1..3) that have committed their share of B / P_o
+    int* s_task = s_int + 11;       // next own-row task x 64 (every lane of a pulling wave adds one)
+    int* s_udone = s_int + 12;      // [c]: tiles of column block c that have the previous strip applied
+    int* s_mdone = s_int + 16;      // [c]: tiles of column block c that have the solved columns applied
     if (*info != 0) return;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar: the wave's role decides its control flow)
     const bool is_diag = bx == 0;
     const int64_t R = j0 + 64 * (int64_t)bx;
-    const int64_t Kfirst = K0;                     // the chunk that comes in with the first loads
-    const int kprev = (int)(j0 - K0);          // columns of the outer block already factorised: 0, 64, 128, ...
-    if (t == 0) s_bad = 0;
+    const bool has_prev = j0 > K0;                 // false for the first strip of a segment
+#ifdef GPRY_PANEL_STAMPS
+    const int stamp_step = (int)((pa.col0 + j0) / 64) < STAMP_STEPS ? (int)((pa.col0 + j0) / 64) : STAMP_STEPS - 1;
+    const int stamp_wg = (tb == 0) ? (bx == 0 ? 0 : bx == 1 ? 1 : bx == 8 ? 2 : -1) : -1;
+#endif
+    PANEL_STAMP(0);
+    if (t < 32) s_int[t] = 0;
+    // all four blocks unconditionally (the diagonal workgroup has R == j0 and the first step of a segment K0 == j0: those
+    // loads repeat D and are never committed): with the loads behind branches the register sets went through scratch memory
+    D8_FOR(D8_DECL)
+    B3_FOR(B3_DECL)
     {
-        // all four blocks unconditionally (the diagonal workgroup has R == j0 and the first step of an
-        // outer block K0 == j0: those loads repeat D and land in buffers nobody reads): with the loads
-        // behind branches the 3 x 128-byte register sets went through scratch memory
-        double2 rD[8], rB[8], rPt[8], rPo[8];
-        load_block_issue(A + j0 * ld + j0, ld, t, rD);
-        load_block_issue(A + R * ld + j0, ld, t, rB);
-        load_block_issue(A + j0 * ld + Kfirst, ld, t, rPt);
-        load_block_issue(A + R * ld + Kfirst, ld, t, rPo);
-        load_block_commit(sD, t, rD);
-        load_block_commit(sB, t, rB);
-        load_block_commit(sPt, t, rPt);
-        load_block_commit(sPo, t, rPo);
+        const double* __restrict__ gD_ = A + j0 * ld + j0;
+        const double* __restrict__ gPt_ = A + j0 * ld + K0;
+        D8_FOR(D8_LOAD)
     }
+    // (what the factor waits for goes out first: loads return in order, and the scheduler had put the own-row loads in front)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const double* __restrict__ gB_ = A + R * ld + j0;
+        const double* __restrict__ gPo_ = A + R * ld + K0;
+        B3_FOR(B3_LOAD)
+    }
+    D8_FOR(D8_COMMIT)
     __syncthreads();
-    // ---- left-looking update with the previous columns of the outer block, 64 at a time (the first
-    // chunk came in with the loads above; an outer block of 256 columns has up to three)
-    for (int c0 = 0; c0 < kprev; c0 += 64) {
-        if (c0) {
-            __syncthreads();                       // everybody is done with the previous chunk
-            double2 rPt[8], rPo[8];
-            load_block_issue(A + j0 * ld + K0 + c0, ld, t, rPt);
-            if (!is_diag) load_block_issue(A + R * ld + K0 + c0, ld, t, rPo);
-            load_block_commit(sPt, t, rPt);
-            if (!is_diag) load_block_commit(sPo, t, rPo);
-            __syncthreads();
-        }
-        // D: only the ten 16x16 tiles on and below the diagonal are ever read (the factor works on the
-        // lower triangle); they are dealt round-robin to the waves (3, 3, 2, 2) instead of a full row each
+    if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PANEL_STAMP(1);
+    PANEL_PROGRESS(1);
+    // ---- the previous strip onto block row w of D (only the tiles on and below the diagonal are ever read)
+    if (has_prev) {
 #pragma unroll 1
-        for (int tl = w; tl < 10; tl += 4) {
-            const int rw = tl < 1 ? 0 : tl < 3 ? 1 : tl < 6 ? 2 : 3;
-            const int n = tl - rw * (rw + 1) / 2;
-            double* T = sD + (rw * 16) * PLD + n * 16;
+        for (int n = 0; n <= w; n++) {
+            double* T = sD + (w * 16) * PLD + n * 16;
             v4d acc = tile_load(T, lane);
-            acc = mfma_nt16<true>(acc, sPt + (rw * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+            acc = mfma_nt16<true>(acc, sPt + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
             tile_store(T, acc, lane);
         }
-        if (!is_diag) {
-#pragma unroll
-            for (int n = 0; n < 4; n++) {
-                double* U = sB + (w * 16) * PLD + n * 16;
-                v4d acb = tile_load(U, lane);
-                acb = mfma_nt16<true>(acb, sPo + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
-                tile_store(U, acb, lane);
-            }
-        }
+        wave_fence();
     }
-    if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    if (!is_diag && w != 0) {       // (wave 0 is on the factor chain first: it holds none of B / P_o)
+        B3_FOR(B3_COMMIT)
+        wave_fence();
+        lds_count(s_commit, lane);
+    }
+    PANEL_STAMP(2);
+    PANEL_PROGRESS(2);
     // ---- Cholesky of the 64x64 diagonal block, blocked by 16, as a dataflow between the four waves
     // (wave w owns block row w) instead of three workgroup barriers per block column:
     //   for cb < w:  wait chol(cb);  T(w,cb): D[w][cb] <- D[w][cb] L[cb][cb]^-T;  publish;
     //                for cc in cb+1..w: (cc < w: wait T(cc,cb))  D[w][cc] -= D[w][cb] D[cc][cb]^T
-    //   chol(w); publish;  then (w < 3, off-diagonal workgroups) the own-row solve of column block w.
+    //   chol(w); publish.
     // Wave cb+1 starts chol(cb+1) as soon as ITS row is done, while the rows below still work on block
-    // column cb: the chain is 4 chol16 + 3 (solve + one tile update) = ~35k cycles instead of 44k.
-    // Same operations on every tile in the same order as the barrier version: bit-identical factors.
+    // column cb: the chain is 4 chol16 + 3 (solve + one tile update).
     // Flags are LDS words written by lane 0 after a wave fence (LDS requests of a wave retire in order).
-    if (w == 0 && lane < 8) s_flag[lane] = 0;      // [0]: blocks factored, [1 + w]: columns solved by wave w, [5]: own-row blocks solved
-    __syncthreads();
-    {
-        for (int cb = 0; cb < w; cb++) {
-            while (__hip_atomic_load(&s_flag[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(1);
-            trsm16_rows(sD + (w * 16) * PLD + cb * 16, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
-            wave_fence();
-            if (lane == 0) __hip_atomic_store(&s_flag[1 + w], cb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (int cc = cb + 1; cc <= w; cc++) {
-                if (cc < w)
-                    while (__hip_atomic_load(&s_flag[1 + cc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(1);
-                double* T = sD + (w * 16) * PLD + cc * 16;
-                v4d acc = tile_load(T, lane);
-                acc = mfma_nt16<true>(acc, sD + (w * 16) * PLD + cb * 16, sD + (cc * 16) * PLD + cb * 16, 16, lane);
-                tile_store(T, acc, lane);
-            }
-            wave_fence();
+    for (int cb = 0; cb < w; cb++) {
+        PANEL_PROGRESS(10 + cb);
+        lds_wait_ge(&s_flag[0], cb + 1, s_abort, 1);
+        PANEL_PROGRESS(14 + cb);
+        trsm16_rows(sD + (w * 16) * PLD + cb * 16, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
+        wave_fence();
+        lds_publish(&s_flag[1 + w], cb + 1, lane);
+        for (int cc = cb + 1; cc <= w; cc++) {
+            if (cc < w) lds_wait_ge(&s_flag[1 + cc], cb + 1, s_abort, 2);
+            double* T = sD + (w * 16) * PLD + cc * 16;
+            v4d acc = tile_load(T, lane);
+            acc = mfma_nt16<true>(acc, sD + (w * 16) * PLD + cb * 16, sD + (cc * 16) * PLD + cb * 16, 16, lane);
+            tile_store(T, acc, lane);
         }
+        wave_fence();
+    }
+    {
         // a failed pivot (not positive definite) still publishes: nobody may wait forever; the first
         // failing column wins (the chol16 calls are ordered by the chain itself)
+        PANEL_PROGRESS(20);
         const int bad = chol16_wave(sD + (w * 16) * PLD + w * 16, sRd + w * 16, lane);
+        PANEL_PROGRESS(21);
         if (bad && lane == 0 && s_bad == 0) s_bad = w * 16 + bad;
         wave_fence();
-        if (lane == 0) __hip_atomic_store(&s_flag[0], w + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!is_diag && w < 3) {
-            // this wave has nothing left to do in the factor: it solves the workgroup's own rows against
-            // its block column (needs the own-row blocks 0..w-1, solved by the waves before it)
-            while (__hip_atomic_load(&s_flag[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < w) __builtin_amdgcn_s_sleep(1);
-            solve_block_cols(sB, sD, sRd, w, lane);
-            if (lane == 0) __hip_atomic_store(&s_flag[5], w + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        lds_publish(&s_flag[0], w + 1, lane);
     }
+    PANEL_STAMP(3);
+    PANEL_PROGRESS(22);
+    if (!is_diag) {
+        // ---- the workgroup's own rows: X = (B - P_o P_t^T) Lkk^-T, 16 columns at a time.  Tasks in dependency order,
+        //   column block c:  U(rt, c), rt = 0..3: the previous strip onto tile (rt, c)          [needs: B, P_o committed]
+        //                    M(rt, c), rt = 0..3 (c > 0): the solved columns onto tile (rt, c)  [U(., c), the solves < c, row c of the factor]
+        //                    T(c): the 16-wide solve of all 64 rows, one row per lane           [M(., c), chol(c)]
+        // pulled from s_task by whichever wave is free.  A wave that waits for a dependency waits for a task pulled earlier
+        // or for the factor chain, which waits for none of this: no deadlock.
+        lds_wait_ge(s_commit, 3, s_abort, 3);
+        PANEL_ACC_DECL
+        for (;;) {
+            // every lane adds one (the compiler folds that into ONE ds_add of 64 and a per-lane offset): no value flows out
+            // of an `if (lane == 0)` -- with the pull under such a branch the loop was compiled into the nest above
+            const int task = __builtin_amdgcn_readfirstlane(
+                __hip_atomic_fetch_add(s_task, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 6;
+            PANEL_PROGRESS(100 + task);
+            if (task >= 32) break;
+            // column block 0: tasks 0..4 (4 U, T); column block c > 0: 5 + 9 (c - 1) .. (4 U, 4 M, T)
+            const int c = task < 5 ? 0 : 1 + (task - 5) / 9;
+            const int k = task < 5 ? task : (task - 5) % 9;
+            PANEL_ACC_BEGIN;
+            if (k < 4) {                                    // U(k, c)
+                if (has_prev) {
+                    double* U = sB + (k * 16) * PLD + c * 16;
+                    v4d acb = tile_load(U, lane);
+                    acb = mfma_nt16<true>(acb, sPo + (k * 16) * PLD, sPt + (c * 16) * PLD, 64, lane);
+                    tile_store(U, acb, lane);
+                    wave_fence();
+                }
+                lds_count(&s_udone[c], lane);
+                PANEL_ACC_END(0);
+            } else if (c > 0 && k < 8) {                    // M(k - 4, c)
+                const int rt = k - 4;
+                lds_wait_ge(&s_udone[c], 4, s_abort, 4);
+                lds_wait_ge(&s_flag[5], c, s_abort, 5);                // X[:, 0 .. 16 c) final
+                lds_wait_ge(&s_flag[1 + c], c, s_abort, 6);            // L[c][0 .. c) final
+                double* T = sB + (rt * 16) * PLD + c * 16;
+                v4d acc = tile_load(T, lane);
+                acc = mfma_nt16<true>(acc, sB + (rt * 16) * PLD, sD + (c * 16) * PLD, c * 16, lane);
+                tile_store(T, acc, lane);
+                wave_fence();
+                lds_count(&s_mdone[c], lane);
+                PANEL_ACC_END(1);
+            } else {                                        // T(c)
+                if (c > 0) lds_wait_ge(&s_mdone[c], 4, s_abort, 7); else lds_wait_ge(&s_udone[0], 4, s_abort, 8);
+                lds_wait_ge(&s_flag[0], c + 1, s_abort, 9);
+                trsm16_rows<64>(sB + c * 16, sD + (c * 16) * PLD + c * 16, sRd + c * 16, lane);
+                wave_fence();
+                lds_publish(&s_flag[5], c + 1, lane);
+                PANEL_ACC_END(2);
+            }
+        }
+        PANEL_ACC_FLUSH;
+    }
+    PANEL_STAMP(4);
+    PANEL_PROGRESS(40);
     __syncthreads();
+    PANEL_STAMP(5);
+    PANEL_PROGRESS(41);
+    if (*s_abort != 0) {            // a bounded wait ran out (never seen; kept so that a protocol error cannot hang the GPU)
+        if (t == 0) { atomicCAS(info, 0, (int)(pa.col0 + j0 + 1 <= n_real ? pa.col0 + j0 + 1 : n_real)); info[3] = 0x5A00 + *s_abort; }
+        return;
+    }
     if (s_bad) {
         if (is_diag && t == 0) {
             int64_t col = pa.col0 + j0 + s_bad;             // 1-based failing column of the whole matrix
@@ -442,27 +607,22 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
         return;
     }
     if (is_diag) {
-        if (t == 0)
-            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+        if (t == 0) {
+            int n = 0;
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(8);
+                if (++n > PANEL_SPIN_CAP) { atomicCAS(info, 0, (int)(pa.col0 + j0 + 1 <= n_real ? pa.col0 + j0 + 1 : n_real)); info[3] = 0x5AFF; break; }
+            }
+        }
         __syncthreads();
         store_block(A + j0 * ld + j0, ld, sD, t, true);
+        PANEL_STAMP(6);
+        PANEL_PROGRESS(60);
         return;
     }
-    // ---- X = B Lkk^-T: the column blocks 0..2 were solved inside the factor loop (by the waves
-    // idling there); the last one is done here, wave w on its own 16-row strip
-    {
-        const int cb = 3;
-        double* T = sB + (w * 16) * PLD + cb * 16;
-        v4d acc = tile_load(T, lane);
-        acc = mfma_nt16<true>(acc, sB + (w * 16) * PLD, sD + (cb * 16) * PLD, cb * 16, lane);
-        tile_store(T, acc, lane);
-        wave_fence();
-        trsm16_rows(T, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
-        wave_fence();
-    }
-    __syncthreads();
     store_block(A + R * ld + j0, ld, sB, t, false);
+    PANEL_STAMP(6);
+    PANEL_PROGRESS(61);
 }
 
 // ---------------------------------------------------------------------------------------------
