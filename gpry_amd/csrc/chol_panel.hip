@@ -190,44 +190,28 @@ __device__ __forceinline__ void trsm16_rows(double* Xr, const double* L, const d
     }
 }
 
-// 64x64 block global -> LDS in two phases: all eight 16-byte loads of a thread are in flight before
-// the first LDS store (a load/store pair per iteration paid one memory round trip each: the four
-// blocks of a panel step cost 13k cycles that way)
-__device__ __forceinline__ void load_block_issue(const double* __restrict__ G, int64_t ld, int t, double2 (&r)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int e = t + 256 * i, row = e >> 5, c2 = (e & 31) * 2;
-        r[i] = *reinterpret_cast<const double2*>(G + (int64_t)row * ld + c2);
-    }
-}
-__device__ __forceinline__ void load_block_commit(double* S, int t, const double2 (&r)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int e = t + 256 * i, row = e >> 5, c2 = (e & 31) * 2;
-        *reinterpret_cast<double2*>(S + row * PLD + c2) = r[i];
-    }
-}
-// The workgroup's own rows (B and P_o, 64x64 each) are dealt to the threads of waves 1..3 only (192 threads x 11 pieces of 16
-// bytes per block, 2048 needed): the panel step keeps them in registers until the wave that holds them first has nothing to
-// do for the factor, and wave 0 is on the factor chain from the first cycle.  Wave 0's lanes (and the surplus pieces) load
-// one fixed element: no branch around the loads, one cache line of extra traffic.  Named registers instead of arrays: arrays
-// that live across the update of D were left in scratch memory by the compiler.
-#define D8_FOR(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-#define D8_DECL(i) double2 rD##i, rPt##i;
-#define D8_LOAD(i) { const int e_ = t + 256 * i; const int64_t off_ = (int64_t)(e_ >> 5) * ld + (e_ & 31) * 2;        \
+// Loads of a panel step (512 threads).  D and P_t (what the factor waits for) are dealt to all eight waves, 4 pieces of 16
+// bytes per thread and block; the workgroup's own rows B and P_o to the four worker waves (threads 256..511, 8 pieces per
+// thread and block), which keep them in registers until the first tasks (the update of D) are done.  The chain waves' lanes
+// load one fixed element for those: no branch around the loads (register sets loaded behind branches went to scratch), one
+// cache line of extra traffic.  Named registers instead of arrays: arrays that live across other work were left in scratch
+// memory by the compiler.
+#define D4_FOR(X) X(0) X(1) X(2) X(3)
+#define D4_DECL(i) double2 rD##i, rPt##i;
+#define D4_LOAD(i) { const int e_ = t + 512 * i; const int64_t off_ = (int64_t)(e_ >> 5) * ld + (e_ & 31) * 2;        \
                      rD##i = *reinterpret_cast<const double2*>(gD_ + off_); rPt##i = *reinterpret_cast<const double2*>(gPt_ + off_); }
-#define D8_COMMIT(i) { const int e_ = t + 256 * i; const int o_ = (e_ >> 5) * PLD + (e_ & 31) * 2;                     \
+#define D4_COMMIT(i) { const int e_ = t + 512 * i; const int o_ = (e_ >> 5) * PLD + (e_ & 31) * 2;                     \
                        *reinterpret_cast<double2*>(sD + o_) = rD##i; *reinterpret_cast<double2*>(sPt + o_) = rPt##i; }
-#define B3_FOR(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
-#define B3_DECL(i) double2 rB##i, rPo##i;
-#define B3_LOAD(i) { const int e_ = t - 64 + 192 * i; const bool ok_ = t >= 64 && e_ < 2048;                         \
+#define B8_FOR(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define B8_DECL(i) double2 rB##i, rPo##i;
+#define B8_LOAD(i) { const int e_ = t - 256 + 256 * i; const bool ok_ = t >= 256;                                     \
                      const int64_t off_ = ok_ ? (int64_t)(e_ >> 5) * ld + (e_ & 31) * 2 : 0;                          \
                      rB##i = *reinterpret_cast<const double2*>(gB_ + off_); rPo##i = *reinterpret_cast<const double2*>(gPo_ + off_); }
-#define B3_COMMIT(i) { const int e_ = t - 64 + 192 * i; const int o_ = (e_ >> 5) * PLD + (e_ & 31) * 2;               \
-                       if (e_ < 2048) { *reinterpret_cast<double2*>(sB + o_) = rB##i; *reinterpret_cast<double2*>(sPo + o_) = rPo##i; } }
+#define B8_COMMIT(i) { const int e_ = t - 256 + 256 * i; const int o_ = (e_ >> 5) * PLD + (e_ & 31) * 2;               \
+                       *reinterpret_cast<double2*>(sB + o_) = rB##i; *reinterpret_cast<double2*>(sPo + o_) = rPo##i; }
 __device__ __forceinline__ void store_block(double* __restrict__ G, int64_t ld, const double* S, int t,
                                             bool lower_only) {
-    for (int e = t; e < 64 * 32; e += 256) {
+    for (int e = t; e < 64 * 32; e += (int)blockDim.x) {
         int row = e >> 5, c2 = (e & 31) * 2;
         double2 v = *reinterpret_cast<const double2*>(S + row * PLD + c2);
         double* p = G + (int64_t)row * ld + c2;
@@ -340,6 +324,7 @@ struct PanelArgs {
     int64_t col0;           // A is the trailing submatrix from column col0 of the whole matrix on (tail of the large schedule)
     int* info; int* arrive; int target;
     int64_t bstride;        // batched launch (gpry_ctx::bn): A, info and arrive of theta blockIdx.z lie this many doubles further on
+    int flags;              // experiments (GPRY_PANEL_FLAGS): 1: the workers do not yield to their SIMD partners
 };
 #define PANEL_SMEM_DOUBLES (4 * 64 * PLD + 64 + 16)
 
@@ -347,30 +332,30 @@ struct PanelArgs {
 // diagnostic build only (tools/r05/build_stamps.sh): s_memtime stamps of three workgroups per panel step
 #define STAMP_STEPS 160
 #define STAMP_SLOTS 8
-__device__ long long g_panel_stamps[STAMP_STEPS][3][4][STAMP_SLOTS];
+__device__ long long g_panel_stamps[STAMP_STEPS][3][8][STAMP_SLOTS];
 #define PANEL_STAMP(slot) do { if (stamp_wg >= 0 && lane == 0) g_panel_stamps[stamp_step][stamp_wg][w][slot] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 // time per kind of own-row task (0: U, 1: M, 2: T incl. its waits, 3: count of tasks), per wave
-__device__ long long g_panel_acc[STAMP_STEPS][3][4][4];
+__device__ long long g_panel_acc[STAMP_STEPS][3][8][4];
 #define PANEL_ACC_DECL long long acc_t0_ = 0, acc_[4] = {0, 0, 0, 0};
 #define PANEL_ACC_BEGIN do { acc_t0_ = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define PANEL_ACC_END(kind) do { acc_[kind] += (long long)__builtin_amdgcn_s_memtime() - acc_t0_; acc_[3]++; } while (0)
 #define PANEL_ACC_FLUSH do { if (stamp_wg >= 0 && lane == 0) for (int q_ = 0; q_ < 4; q_++) g_panel_acc[stamp_step][stamp_wg][w][q_] = acc_[q_]; } while (0)
 extern "C" int gpry_debug_panel_acc(long long* out, int n) {
-    if (n > STAMP_STEPS * 3 * 4 * 4) n = STAMP_STEPS * 3 * 4 * 4;
+    if (n > STAMP_STEPS * 3 * 8 * 4) n = STAMP_STEPS * 3 * 8 * 4;
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_acc), sizeof(long long) * n);
 }
 extern "C" int gpry_debug_panel_stamps(long long* out, int n) {
-    if (n > STAMP_STEPS * 3 * 4 * STAMP_SLOTS) n = STAMP_STEPS * 3 * 4 * STAMP_SLOTS;
+    if (n > STAMP_STEPS * 3 * 8 * STAMP_SLOTS) n = STAMP_STEPS * 3 * 8 * STAMP_SLOTS;
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_stamps), sizeof(long long) * n);
 }
 // progress codes of every wave of the first workgroups, written straight to mapped host memory: readable while a kernel hangs
 __device__ int* g_panel_progress = nullptr;
 #define PANEL_PROGRESS(code) do { if (g_panel_progress && lane == 0 && bx < 4 && tb == 0) \
-    __hip_atomic_store(g_panel_progress + ((stamp_step & 15) * 4 + bx) * 4 + w, (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+    __hip_atomic_store(g_panel_progress + ((stamp_step & 15) * 4 + bx) * 8 + w, (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
 extern "C" int* gpry_debug_progress_buffer() {
     int* h = nullptr;
-    if (hipHostMalloc((void**)&h, 16 * 4 * 4 * sizeof(int), hipHostMallocMapped) != hipSuccess) return nullptr;
-    memset(h, 0, 16 * 4 * 4 * sizeof(int));
+    if (hipHostMalloc((void**)&h, 16 * 4 * 8 * sizeof(int), hipHostMallocMapped) != hipSuccess) return nullptr;
+    memset(h, 0, 16 * 4 * 8 * sizeof(int));
     int* d = nullptr;
     if (hipHostGetDevicePointer((void**)&d, h, 0) != hipSuccess) return nullptr;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_panel_progress), &d, sizeof(d)) != hipSuccess) return nullptr;
@@ -410,6 +395,19 @@ __device__ __forceinline__ void lds_wait_ge(int* f, int v, int* s_abort, int id)
         }
     }
 }
+// Wave w of the chain and worker w + 4 share a SIMD (a workgroup's waves are dealt to the four SIMDs in turn), and the FP64
+// MFMAs of one hold up the FP64 vector instructions of the other (chol16 of wave 0: 4.5k cycles alone, 6.4k beside a worker's
+// tiles, stamped build).  The chain wave that everything waits for is the one that factors next, wave s_flag[0]: its partner
+// pulls no new task until that block is factored.  (Measured against the alternatives, tools/r05/gpu_panel_flags.sh and
+// profiles/r05_potrf.md: no yield -- the chain is 15 % slower and the tail behind it as much shorter; priority for the chain
+// waves -- no effect; the chain on two SIMDs of its own and the workers on the other two -- 3 % slower, the workers' MFMAs
+// then share two matrix pipes.)
+__device__ __forceinline__ void worker_yield(int* blocks_factored, int w, int* s_abort) {
+    for (int n = 0; n < PANEL_SPIN_CAP; n++) {
+        if (lds_peek(blocks_factored, false) != w - 4 || lds_peek(s_abort, false) != 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
 __device__ __forceinline__ void lds_publish(int* f, int v, int lane) {         // after a wave_fence(): this wave's LDS writes come first
     if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -418,20 +416,22 @@ __device__ __forceinline__ void lds_count(int* f, int lane) {
 }
 
 // One panel step for the 64-row block `bx` of the panel: the strip before its own (columns [K0, j0), 64 of them) is applied
-// first (left-looking), then the 64 x 64 factor and the row solves.
+// first (left-looking), then the 64 x 64 factor and the row solves.  Workgroups of EIGHT waves: 0..3 are the factor chain
+// (wave w owns block row w of D), 4..7 are workers.
 //
-// Round 5: what does not feed the factor is off the chain.  Until round 4 every workgroup loaded its four 64 x 64 blocks,
-// applied the previous strip to D AND to its own rows (5.9k cycles), factored D (21k), solved its rows (3k) and stored: 38k
-// cycles per step, one after the other.  Now
-//   * all loads of a thread are issued at once, but only D and the previous strip's rows of the diagonal block (P_t) are
-//     waited for and committed to LDS before the factor starts; the workgroup's own rows B and P_o are loaded by waves 1..3
-//     only, stay in registers over their share of the update of D and are committed before those waves first wait for the
-//     factor chain (wave 0, which starts the chain, holds none);
-//   * wave w applies the previous strip to ITS block row of D only (w + 1 tiles; wave 0 starts its 16 x 16 factor after one);
+// Round 5: what does not feed the factor is off the chain.  Until round 4 every workgroup (four waves) loaded its four
+// 64 x 64 blocks, applied the previous strip to D AND to its own rows (5.9k cycles), factored D (21k), solved its rows (3k)
+// and stored: 38k cycles per step plus the launch, one after the other.  Now
+//   * only D and the previous strip's rows of the diagonal block (P_t) are waited for and committed to LDS before the factor
+//     starts; the workgroup's own rows B and P_o are loaded by the worker waves, stay in their registers over the first
+//     tasks and are committed when those are done (they have landed by then);
+//   * wave 0 applies the previous strip to tile (0, 0) of D and starts the 16 x 16 factor chain; the other nine tiles of D
+//     are the first task queue (waves 1..7 pull them; wave w of the chain waits for its block row);
 //   * everything for the workgroup's own rows -- the left-looking update of B (16 tiles of 16 MFMAs), the updates with the
-//     columns solved so far and the four 16-wide solves -- is a list of 32 tasks in dependency order that the waves pull
-//     from an LDS counter once their part of the factor chain is done (wave 0 after one 16 x 16 factor, wave 1 after two ...):
-//     the work fills the time the waves used to idle in, and only the last 16-wide solve is left behind the factor.
+//     columns solved so far and the four 16-wide solves -- is a second queue of 32 tasks in dependency order, pulled from an
+//     LDS counter by the workers and by the chain waves once their part of the chain is done: the own-row work runs beside
+//     the factor, two waves to a SIMD (a lone wave issues one FP64 instruction per 8 cycles, the SIMD takes one per 4), and
+//     only the last 16-wide solve is left behind the factor.
 // Every tile sees the same operations in the same order as before (who computes it and when is all that changed; an MFMA chain
 // cut at a multiple of 4 k and resumed from the stored tile is the same chain): factors bit-identical to round 4's.
 __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* smem, const int bx, const int tb) {
@@ -447,13 +447,16 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     int& s_bad = s_int[0];
     int* s_abort = s_int + 1;
     int* s_flag = s_int + 2;        // [0]: 16 x 16 blocks factored, [1 + w]: columns solved by wave w, [5]: own-row column blocks solved
-    int* s_commit = s_int + 10;     // waves (of 1..3) that have committed their share of B / P_o
+    int* s_commit = s_int + 10;     // worker waves that have committed their share of B / P_o
     int* s_task = s_int + 11;       // next own-row task x 64 (every lane of a pulling wave adds one)
     int* s_udone = s_int + 12;      // [c]: tiles of column block c that have the previous strip applied
     int* s_mdone = s_int + 16;      // [c]: tiles of column block c that have the solved columns applied
+    int* s_dtask = s_int + 20;      // next tile of the update of D x 64
+    int* s_ddone = s_int + 21;      // [w]: tiles of block row w of D that have the previous strip applied (w = 1..3)
     if (*info != 0) return;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar: the wave's role decides its control flow)
-    const bool is_diag = bx == 0;
+    const bool is_diag = bx == 0, worker = w >= 4;
+    const int row = w;                              // chain waves: the block row of D they own
     const int64_t R = j0 + 64 * (int64_t)bx;
     const bool has_prev = j0 > K0;                 // false for the first strip of a segment
 #ifdef GPRY_PANEL_STAMPS
@@ -462,78 +465,91 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
 #endif
     PANEL_STAMP(0);
     if (t < 32) s_int[t] = 0;
-    // all four blocks unconditionally (the diagonal workgroup has R == j0 and the first step of a segment K0 == j0: those
-    // loads repeat D and are never committed): with the loads behind branches the register sets went through scratch memory
-    D8_FOR(D8_DECL)
-    B3_FOR(B3_DECL)
+    D4_FOR(D4_DECL)
+    B8_FOR(B8_DECL)
     {
         const double* __restrict__ gD_ = A + j0 * ld + j0;
         const double* __restrict__ gPt_ = A + j0 * ld + K0;
-        D8_FOR(D8_LOAD)
+        D4_FOR(D4_LOAD)
     }
     // (what the factor waits for goes out first: loads return in order, and the scheduler had put the own-row loads in front)
     __builtin_amdgcn_sched_barrier(0);
     {
         const double* __restrict__ gB_ = A + R * ld + j0;
         const double* __restrict__ gPo_ = A + R * ld + K0;
-        B3_FOR(B3_LOAD)
+        B8_FOR(B8_LOAD)
     }
-    D8_FOR(D8_COMMIT)
+    D4_FOR(D4_COMMIT)
     __syncthreads();
-    if (t == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 256) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (a worker: wave 0 starts the chain)
     PANEL_STAMP(1);
     PANEL_PROGRESS(1);
-    // ---- the previous strip onto block row w of D (only the tiles on and below the diagonal are ever read)
+    // ---- the previous strip onto D (only the ten tiles on and below the diagonal are ever read): tile (0, 0) by wave 0,
+    // which starts the chain; the other nine from a queue (waves 1..3 and 5..7; block row 1 first)
     if (has_prev) {
-#pragma unroll 1
-        for (int n = 0; n <= w; n++) {
-            double* T = sD + (w * 16) * PLD + n * 16;
-            v4d acc = tile_load(T, lane);
-            acc = mfma_nt16<true>(acc, sPt + (w * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
-            tile_store(T, acc, lane);
+        if (w == 0) {
+            v4d acc = tile_load(sD, lane);
+            acc = mfma_nt16<true>(acc, sPt, sPt, 64, lane);
+            tile_store(sD, acc, lane);
+            wave_fence();
+        } else if (w != 4 || (pa.flags & 1)) {       // (wave 4 is the partner of wave 0, which is on the chain from the first cycle)
+            for (;;) {
+                const int dt = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_fetch_add(s_dtask, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 6;
+                if (dt >= 9) break;
+                const int rw = dt < 2 ? 1 : dt < 5 ? 2 : 3;
+                const int n = dt - (rw == 1 ? 0 : rw == 2 ? 2 : 5);
+                double* T = sD + (rw * 16) * PLD + n * 16;
+                v4d acc = tile_load(T, lane);
+                acc = mfma_nt16<true>(acc, sPt + (rw * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+                tile_store(T, acc, lane);
+                wave_fence();
+                lds_count(&s_ddone[rw], lane);
+            }
         }
-        wave_fence();
     }
-    if (!is_diag && w != 0) {       // (wave 0 is on the factor chain first: it holds none of B / P_o)
-        B3_FOR(B3_COMMIT)
+    if (!is_diag && worker) {
+        B8_FOR(B8_COMMIT)
         wave_fence();
         lds_count(s_commit, lane);
     }
     PANEL_STAMP(2);
     PANEL_PROGRESS(2);
-    // ---- Cholesky of the 64x64 diagonal block, blocked by 16, as a dataflow between the four waves
-    // (wave w owns block row w) instead of three workgroup barriers per block column:
-    //   for cb < w:  wait chol(cb);  T(w,cb): D[w][cb] <- D[w][cb] L[cb][cb]^-T;  publish;
-    //                for cc in cb+1..w: (cc < w: wait T(cc,cb))  D[w][cc] -= D[w][cb] D[cc][cb]^T
-    //   chol(w); publish.
-    // Wave cb+1 starts chol(cb+1) as soon as ITS row is done, while the rows below still work on block
-    // column cb: the chain is 4 chol16 + 3 (solve + one tile update).
-    // Flags are LDS words written by lane 0 after a wave fence (LDS requests of a wave retire in order).
-    for (int cb = 0; cb < w; cb++) {
-        PANEL_PROGRESS(10 + cb);
-        lds_wait_ge(&s_flag[0], cb + 1, s_abort, 1);
-        PANEL_PROGRESS(14 + cb);
-        trsm16_rows(sD + (w * 16) * PLD + cb * 16, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
-        wave_fence();
-        lds_publish(&s_flag[1 + w], cb + 1, lane);
-        for (int cc = cb + 1; cc <= w; cc++) {
-            if (cc < w) lds_wait_ge(&s_flag[1 + cc], cb + 1, s_abort, 2);
-            double* T = sD + (w * 16) * PLD + cc * 16;
-            v4d acc = tile_load(T, lane);
-            acc = mfma_nt16<true>(acc, sD + (w * 16) * PLD + cb * 16, sD + (cc * 16) * PLD + cb * 16, 16, lane);
-            tile_store(T, acc, lane);
+    if (!worker) {
+        // ---- Cholesky of the 64x64 diagonal block, blocked by 16, as a dataflow between the four chain waves
+        // (wave w owns block row w) instead of three workgroup barriers per block column:
+        // (block row w below = `row`)
+        //   for cb < w:  wait chol(cb);  T(w,cb): D[w][cb] <- D[w][cb] L[cb][cb]^-T;  publish;
+        //                for cc in cb+1..w: (cc < w: wait T(cc,cb))  D[w][cc] -= D[w][cb] D[cc][cb]^T
+        //   chol(w); publish.
+        // Wave cb+1 starts chol(cb+1) as soon as ITS row is done, while the rows below still work on block
+        // column cb: the chain is 4 chol16 + 3 (solve + one tile update).
+        // Flags are LDS words written by lane 0 after a wave fence (LDS requests of a wave retire in order).
+        if (has_prev && row > 0) lds_wait_ge(&s_ddone[row], row + 1, s_abort, 10);
+        for (int cb = 0; cb < row; cb++) {
+            PANEL_PROGRESS(10 + cb);
+            lds_wait_ge(&s_flag[0], cb + 1, s_abort, 1);
+            PANEL_PROGRESS(14 + cb);
+            trsm16_rows(sD + (row * 16) * PLD + cb * 16, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
+            wave_fence();
+            lds_publish(&s_flag[1 + row], cb + 1, lane);
+            for (int cc = cb + 1; cc <= row; cc++) {
+                if (cc < row) lds_wait_ge(&s_flag[1 + cc], cb + 1, s_abort, 2);
+                double* T = sD + (row * 16) * PLD + cc * 16;
+                v4d acc = tile_load(T, lane);
+                acc = mfma_nt16<true>(acc, sD + (row * 16) * PLD + cb * 16, sD + (cc * 16) * PLD + cb * 16, 16, lane);
+                tile_store(T, acc, lane);
+            }
+            wave_fence();
         }
-        wave_fence();
-    }
-    {
         // a failed pivot (not positive definite) still publishes: nobody may wait forever; the first
         // failing column wins (the chol16 calls are ordered by the chain itself)
         PANEL_PROGRESS(20);
-        const int bad = chol16_wave(sD + (w * 16) * PLD + w * 16, sRd + w * 16, lane);
+        const int bad = chol16_wave(sD + (row * 16) * PLD + row * 16, sRd + row * 16, lane);
         PANEL_PROGRESS(21);
-        if (bad && lane == 0 && s_bad == 0) s_bad = w * 16 + bad;
+        if (bad && lane == 0 && s_bad == 0) s_bad = row * 16 + bad;
         wave_fence();
-        lds_publish(&s_flag[0], w + 1, lane);
+        lds_publish(&s_flag[0], row + 1, lane);
     }
     PANEL_STAMP(3);
     PANEL_PROGRESS(22);
@@ -544,11 +560,13 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
         //                    T(c): the 16-wide solve of all 64 rows, one row per lane           [M(., c), chol(c)]
         // pulled from s_task by whichever wave is free.  A wave that waits for a dependency waits for a task pulled earlier
         // or for the factor chain, which waits for none of this: no deadlock.
-        lds_wait_ge(s_commit, 3, s_abort, 3);
+        lds_wait_ge(s_commit, 4, s_abort, 3);
         PANEL_ACC_DECL
         for (;;) {
+            if (worker && !(pa.flags & 1)) worker_yield(&s_flag[0], w, s_abort);
             // every lane adds one (the compiler folds that into ONE ds_add of 64 and a per-lane offset): no value flows out
-            // of an `if (lane == 0)` -- with the pull under such a branch the loop was compiled into the nest above
+            // of an `if (lane == 0)` -- with the pull under such a branch the loop was compiled into a nest of exec-masked
+            // loops that re-ran a pulled task without pulling the next one
             const int task = __builtin_amdgcn_readfirstlane(
                 __hip_atomic_fetch_add(s_task, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 6;
             PANEL_PROGRESS(100 + task);
@@ -627,10 +645,11 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
 
 // ---------------------------------------------------------------------------------------------
 // One 64 x 64 tile of a trailing update, C -= A_r P^T with the 128 columns of one panel: both operand
-// images (64 rows x 128 k, row stride 130 doubles: conflict-free fragment reads) sit in LDS at once, each
-// wave owns a 32 x 32 quadrant (2 x 2 MFMA tiles, 32 k-steps).  Per element the same MFMA sequence from a
+// images (64 rows x 128 k, row stride 130 doubles: conflict-free fragment reads) sit in LDS at once; the eight waves
+// (round 5; four until then, a 32 x 32 quadrant each) own a 16 x 32 piece each (1 x 2 MFMA tiles, 32 k-steps): two waves to
+// a SIMD, one's fragment reads under the other's MFMAs.  Per element the same MFMA sequence from a
 // zero accumulator and the same single rounding of C - acc as the 128 x 128 SYRK tile of the separate
-// trailing launches: bit-identical.  Small on purpose: ~10 us, shorter than a panel step, so that tiles
+// trailing launches: bit-identical.  Small on purpose: shorter than a panel step, so that tiles
 // riding in a panel launch never set its length (a lone 128 x 128 x 128 tile takes 32-36 us).
 #define S64 130
 // n consecutive panels (128 columns apart) in one visit, then (half != 0) the 64 columns at ha_off / hb_off: the first
@@ -644,15 +663,13 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const bool diag = it.a_off == it.b_off;
     const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
-    // C/D fragment: row = g + 4q, col = r.  The 16 old values of this lane stay in registers over the visit.
-    double* cbase = A + it.c_off + (int64_t)(wr * 32 + g) * ld + wc * 32 + r;
-    double val[2][2][4];
+    // C/D fragment: row = g + 4q, col = r.  The 8 old values of this lane stay in registers over the visit.
+    double* cbase = A + it.c_off + (int64_t)(wr * 16 + g) * ld + wc * 32 + r;
+    double val[2][4];
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++)
+    for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) val[mi][ni][q] = cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16];
+        for (int q = 0; q < 4; q++) val[ni][q] = cbase[(int64_t)(4 * q) * ld + ni * 16];
     if (diag) sB = sA;
     // A lagging tile takes several pending panels in one visit: each one accumulated from zero and subtracted
     // with one rounding, in order -- the values a store / reload between them would give.
@@ -665,61 +682,53 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
         const int kd = half ? 64 : 128;
         if (u) __syncthreads();                 // everybody has read the previous panel's images
         // LDS-DMA: one wave instruction moves one 1-KiB row (128 k) of an operand straight into its padded LDS
-        // row -- no staging registers, all 16 (+16) rows of a wave in flight at once (a half row: lanes 0-31)
+        // row -- no staging registers, all 8 (+8) rows of a wave in flight at once (a half row: lanes 0-31)
         if (!half || lane < 32) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int row = w * 16 + i;
+            for (int i = 0; i < 8; i++) {
+                const int row = w * 8 + i;
                 gd_dma16(Ag + (int64_t)row * ld + 2 * lane, sA + row * S64);
             }
             if (!diag) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int row = w * 16 + i;
+                for (int i = 0; i < 8; i++) {
+                    const int row = w * 8 + i;
                     gd_dma16(Bg + (int64_t)row * ld + 2 * lane, sB + row * S64);
                 }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        v4d acc[2][2];
+        v4d acc[2];
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++) acc[mi][ni] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const double* pa = sA + (wr * 32 + r) * S64 + g;
+        for (int ni = 0; ni < 2; ni++) acc[ni] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const double* pa = sA + (wr * 16 + r) * S64 + g;
         const double* pb = sB + (wc * 32 + r) * S64 + g;
 #pragma unroll 1
         for (int kh = 0; kh < kd; kh += 64) {       // k ascending, 64 at a time (one or two passes)
-#pragma unroll 4
+#pragma unroll 8
             for (int k0 = kh; k0 < kh + 64; k0 += 4) {
-                const double a0 = pa[k0], a1 = pa[16 * S64 + k0], b0 = pb[k0], b1 = pb[16 * S64 + k0];
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                const double a0 = pa[k0], b0 = pb[k0], b1 = pb[16 * S64 + k0];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) val[mi][ni][q] = val[mi][ni][q] - acc[mi][ni][q];
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
         for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) cbase[(int64_t)(mi * 16 + 4 * q) * ld + ni * 16] = val[mi][ni][q];
+            for (int q = 0; q < 4; q++) val[ni][q] = val[ni][q] - acc[ni][q];
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) cbase[(int64_t)(4 * q) * ld + ni * 16] = val[ni][q];
 }
 
 // Fused step: the first P workgroups are the panel step, the others each take one 64 x 64 tile of an
 // EARLIER panel's trailing update.  The panel chain is one workgroup's latency and leaves most of the GPU
 // idle; the tiles fill it.  In-order launches on one stream: no cross-stream events, and a panel workgroup
 // (135 KB of LDS) never waits behind tile workgroups for a CU because it comes first in the dispatch order.
-__global__ __launch_bounds__(256) void chol_fused_kernel(PanelArgs pa, const TileItem* __restrict__ items, int P) {
+__global__ __launch_bounds__(512) void chol_fused_kernel(PanelArgs pa, const TileItem* __restrict__ items, int P) {
     __shared__ __attribute__((aligned(16))) double smem[PANEL_SMEM_DOUBLES];
     const int bx = (int)blockIdx.x;
     const int tb = (int)blockIdx.z;             // theta of a batched launch (gpry_ctx::bn)
@@ -763,8 +772,9 @@ static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, in
                         const TileItem* items, int n_items) {
     const int P = (int)((n - j0) / 64);
     cs.arrivals += P;
-    PanelArgs pa = {A, ld, j0, Kfrom, ctx->N, col0, ctx->dinfo, ctx->dinfo + 2, cs.arrivals, ctx->bstride};
-    hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + n_items), 1, (unsigned)ctx->bn), dim3(256), 0, ctx->stream, pa, items, P);
+    static const int panel_flags = getenv("GPRY_PANEL_FLAGS") ? atoi(getenv("GPRY_PANEL_FLAGS")) : 0;
+    PanelArgs pa = {A, ld, j0, Kfrom, ctx->N, col0, ctx->dinfo, ctx->dinfo + 2, cs.arrivals, ctx->bstride, panel_flags};
+    hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + n_items), 1, (unsigned)ctx->bn), dim3(512), 0, ctx->stream, pa, items, P);
     return trtri_pipeline_step(ctx, (int)((col0 + j0) / 64) + 1);
 }
 

@@ -18,7 +18,7 @@ prog = lib.gpry_debug_progress_buffer()
 import threading
 def watchdog():
     time.sleep(8)
-    a = np.ctypeslib.as_array(prog, shape=(16, 4, 4))
+    a = np.ctypeslib.as_array(prog, shape=(16, 4, 8))
     print("HANG? progress codes [step][workgroup][wave]:", flush=True)
     for st in range(4):
         print("  step", st, a[st].tolist(), flush=True)

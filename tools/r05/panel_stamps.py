@@ -20,21 +20,21 @@ for _ in range(3):
     assert dev.factorize() == 0
 lib = _lib.load_library()
 STEPS, SLOTS = 160, 8
-buf = np.zeros(STEPS * 3 * 4 * SLOTS, dtype=np.int64)
+buf = np.zeros(STEPS * 3 * 8 * SLOTS, dtype=np.int64)
 lib.gpry_debug_panel_stamps.restype = C.c_int
 lib.gpry_debug_panel_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.gpry_debug_panel_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
-s = buf.reshape(STEPS, 3, 4, SLOTS)
-abuf = np.zeros(STEPS * 3 * 4 * 4, dtype=np.int64)
+s = buf.reshape(STEPS, 3, 8, SLOTS)
+abuf = np.zeros(STEPS * 3 * 8 * 4, dtype=np.int64)
 lib.gpry_debug_panel_acc.restype = C.c_int
 lib.gpry_debug_panel_acc.argtypes = [C.c_void_p, C.c_int]
 assert lib.gpry_debug_panel_acc(abuf.ctypes.data_as(C.c_void_p), abuf.size) == 0
-acc = abuf.reshape(STEPS, 3, 4, 4)
+acc = abuf.reshape(STEPS, 3, 8, 4)
 nsteps = (N + 127) // 128 * 128 // 64
-names = ["start->D,Pt in LDS", "update of D (own block row)", "factor dataflow up to own chol16", "own-row tasks", "wait at barrier", "store"]
+names = ["start->D,Pt in LDS", "update of D / commit", "factor chain up to own chol16", "own-row tasks", "wait at barrier", "store"]
 for wg, wname in enumerate(["diagonal workgroup", "first off-diagonal", "workgroup 8"]):
     print(wname)
-    for w in range(4):
+    for w in range(8):
         rows = []
         for st in range(1, nsteps - (0 if wg == 0 else 1 if wg == 1 else 8)):
             v = s[st, wg, w]
@@ -45,11 +45,11 @@ for wg, wname in enumerate(["diagonal workgroup", "first off-diagonal", "workgro
             continue
         m = np.mean(np.array(rows), axis=0)
         tot = m.sum()
-        print(f"  wave {w}: " + ", ".join(f"{n} {x:.0f}" for n, x in zip(names, m)) + f"; total {tot:.0f} cycles ({len(rows)} steps)")
+        print(f"  wave {w} ({['row 0', 'row 1', 'row 2', 'row 3', 'worker', 'worker', 'worker', 'worker'][w]}): " + ", ".join(f"{n} {x:.0f}" for n, x in zip(names, m)) + f"; total {tot:.0f} cycles ({len(rows)} steps)")
     if wg > 0:
         sel = [st for st in range(1, nsteps - 8) if s[st, wg, 0, 0]]
         a = acc[sel, wg].mean(axis=0)
-        print("  own-row tasks per wave [cycles in U, M, T, tasks pulled]: " + "; ".join(f"w{w}: {a[w, 0]:.0f} {a[w, 1]:.0f} {a[w, 2]:.0f} {a[w, 3]:.1f}" for w in range(4)))
+        print("  own-row tasks per wave [cycles in U, M, T, tasks pulled]: " + "; ".join(f"w{w}: {a[w, 0]:.0f} {a[w, 1]:.0f} {a[w, 2]:.0f} {a[w, 3]:.1f}" for w in range(8)))
     # chain view: start of step to the end of wave 3's chol16 (the factor's end), and to the store's end
     ends = [(s[st, wg, 3, 3] - s[st, wg, 0, 0], s[st, wg, 0, 6] - s[st, wg, 0, 0]) for st in range(1, nsteps - 8) if s[st, wg, 0, 0] and s[st, wg, 3, 3]]
     if ends:
