@@ -216,26 +216,138 @@ class _GlooComm:
         self._dist.barrier()
 
 
+class _TcpStore:
+    """The rendezvous of an N-GPU run without torch: rank 0 listens next to ``MASTER_PORT`` on ``MASTER_ADDR``, every other
+    rank keeps ONE connection to it.  It carries the 128-byte RCCL id, the ranks' agreement on the transport and the
+    closing barriers -- a few hundred bytes per run; the shortlists travel over RCCL.  (Under ``torch.distributed.run``
+    the agent's own store sits on ``MASTER_PORT`` itself, hence the offset; a handshake word tells a rank that it has
+    reached this store and not some other service on a neighbouring port.)"""
+    MAGIC = b"gpry-bench-store-1"
+    PORT_OFFSETS = (1, 2, 3, 5, 8, 13, 21, 34)
+
+    def __init__(self, rank, world, addr=None, port=None, timeout=None):
+        import socket
+        import struct
+        self.rank, self.world, self._struct = rank, world, struct
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
+        timeout = float(timeout if timeout is not None else os.environ.get("GPRY_BENCH_STORE_TIMEOUT", "300"))
+        self._peers = {}
+        deadline = time.monotonic() + timeout
+        if rank == 0:
+            srv = None
+            for off in self.PORT_OFFSETS:
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr, port + off))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise RuntimeError(f"bench store: no free port next to {addr}:{port}")
+            srv.listen(world)
+            srv.settimeout(1.0)
+            while len(self._peers) < world - 1:
+                if time.monotonic() > deadline:
+                    raise RuntimeError(f"bench store: only {len(self._peers) + 1} of {world} ranks arrived within {timeout:.0f} s")
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                conn.settimeout(timeout)
+                hello = self._recv_from(conn)
+                if not hello.startswith(self.MAGIC):
+                    conn.close()
+                    continue
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self._peers[int(hello[len(self.MAGIC):])] = conn
+                self._send_to(conn, self.MAGIC)
+            srv.close()
+        else:
+            sock = None
+            while sock is None:
+                for off in self.PORT_OFFSETS:
+                    try:
+                        c = socket.create_connection((addr, port + off), timeout=2.0)
+                        c.settimeout(10.0)
+                        self._send_to(c, self.MAGIC + str(rank).encode())
+                        if self._recv_from(c) == self.MAGIC:
+                            sock = c
+                            break
+                        c.close()
+                    except OSError:
+                        pass
+                if sock is None:
+                    if time.monotonic() > deadline:
+                        raise RuntimeError(f"bench store: rank {rank} found no store next to {addr}:{port} within {timeout:.0f} s")
+                    time.sleep(0.2)
+            sock.settimeout(timeout)
+            sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self._peers[0] = sock
+
+    def _send_to(self, sock, payload):
+        sock.sendall(self._struct.pack("<I", len(payload)) + payload)
+
+    def _recv_from(self, sock):
+        def exactly(n):
+            buf = b""
+            while len(buf) < n:
+                part = sock.recv(n - len(buf))
+                if not part:
+                    raise RuntimeError("bench store: a peer closed its connection")
+                buf += part
+            return buf
+        return exactly(self._struct.unpack("<I", exactly(4))[0])
+
+    def broadcast(self, payload):
+        """bytes of rank 0 to every rank"""
+        if self.rank == 0:
+            for r in sorted(self._peers):
+                self._send_to(self._peers[r], payload)
+            return payload
+        return self._recv_from(self._peers[0])
+
+    def all_min(self, value):
+        """the smallest of the ranks' numbers, on every rank (gather at rank 0, answer to all)"""
+        if self.rank == 0:
+            vals = [float(value)] + [float(self._recv_from(self._peers[r]).decode()) for r in sorted(self._peers)]
+            return float(self.broadcast(repr(min(vals)).encode()).decode())
+        self._send_to(self._peers[0], repr(float(value)).encode())
+        return float(self.broadcast(b"").decode())
+
+    def barrier(self):
+        self.all_min(0.0)
+
+    def destroy_process_group(self):      # (the name the closing code calls on either kind of rendezvous object)
+        for c in self._peers.values():
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers = {}
+
+
 def connect(args, rank, world, dev):
-    """Rendezvous over gloo (CPU), data-path communicator over RCCL.  Returns (comm, dist, kind,
-    rccl_ranks).  A failed or hanging RCCL bootstrap ends the run with a non-zero exit code unless
-    ``--allow-gloo`` was given; the process never continues with a thread stuck inside RCCL."""
+    """Rendezvous over a small TCP store (no torch), data-path communicator over RCCL.  Returns (comm, rendezvous, kind,
+    rccl_ranks).  A failed or hanging RCCL bootstrap ends the run with a non-zero exit code unless ``--allow-gloo`` was
+    given -- only then is ``torch.distributed`` imported, for its gloo backend; the process never continues with a thread
+    stuck inside RCCL."""
     from gpry_amd import _lib
-    import torch
-    import torch.distributed as dist   # rendezvous only; the exchanged shortlists travel over RCCL
-    dist.init_process_group("gloo")
-    box = [None]
-    err = None
-    try:
-        box = [_lib.RcclComm.unique_id() if rank == 0 else None]
-    except Exception as e:
-        err = repr(e)
-    dist.broadcast_object_list(box, src=0)
+    store = _TcpStore(rank, world)
+    uid, err = b"", None
+    if rank == 0:
+        try:
+            uid = bytes(_lib.RcclComm.unique_id())
+        except Exception as e:
+            err = repr(e)
+    uid = store.broadcast(uid)
     made = {}
 
     def _connect():
         try:
-            c = _lib.RcclComm(dev, world, rank, box[0])
+            c = _lib.RcclComm(dev, world, rank, uid)
             got = c.allgather(np.array([rank], dtype=np.int64))
             if list(got.ravel()) != list(range(world)):
                 raise RuntimeError(f"allgather self-test returned {got.ravel()}")
@@ -243,7 +355,7 @@ def connect(args, rank, world, dev):
         except Exception as e:
             made["error"] = repr(e)
 
-    if box[0] is not None:
+    if uid:
         import threading
         th = threading.Thread(target=_connect, daemon=True)
         th.start()
@@ -253,21 +365,23 @@ def connect(args, rank, world, dev):
                   file=sys.stderr, flush=True)
             os._exit(4)      # a thread is stuck inside ncclCommInitRank: nothing sane can follow
         err = made.get("error")
-    ok = torch.tensor([1.0 if "comm" in made else 0.0])
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks must agree on the transport
-    if float(ok[0]) >= 1.0:
+    if store.all_min(1.0 if "comm" in made else 0.0) >= 1.0:          # all ranks must agree on the transport
         n_rccl = made["comm"].info()[0]
-        return made["comm"], dist, "rccl", n_rccl
+        return made["comm"], store, "rccl", n_rccl
     if "comm" in made:
         made["comm"].close()
     msg = f"bench.py[{rank}]: no RCCL communicator over {world} ranks ({err or 'a peer failed'})"
     if world > 1 and not args.allow_gloo:
         print(msg + "; exiting (pass --allow-gloo to exchange the shortlists over gloo instead)",
               file=sys.stderr, flush=True)
-        dist.barrier()
-        dist.destroy_process_group()
+        store.barrier()
+        store.destroy_process_group()
         sys.exit(3)
     print(msg + "; using gloo (--allow-gloo)", file=sys.stderr, flush=True)
+    store.barrier()
+    store.destroy_process_group()
+    import torch.distributed as dist   # --allow-gloo only: the shortlists over gloo (development boxes without RCCL)
+    dist.init_process_group("gloo")
     return _GlooComm(dist), dist, "gloo-fallback", 0
 
 
@@ -392,10 +506,16 @@ def small_n_extras():
             row.update({"fit_full_ms": best * 1e3, "fit_full_restarts": 10 + 2 * d, "fit_full_evals": int(nev),
                         "fit_full_groups": int(stats.get("contexts", 1)),
                         "fit_full_side_by_side": bool(stats.get("side_by_side")),
+                        "fit_full_side_by_side_why_not": stats.get("why", ""),
                         "fit_full_rounds": int(max(stats.get("evals_per_run", [0])))})
             del g2
         out[f"N{N}_d{d}"] = row
         del g
+    # which scipy drove the fits and whether its private L-BFGS-B routine passed the side-by-side gate (gpry_amd/lockstep.py)
+    import scipy
+    from gpry_amd import lockstep
+    out["scipy"] = {"version": scipy.__version__, "side_by_side_available": bool(lockstep.available()),
+                    "accepted_on": lockstep.how(), "refused_because": lockstep.why()}
     return out
 
 

@@ -173,10 +173,28 @@ static int lml_batch_general(gpry_ctx* ctx, const double* thetas, int64_t B, int
     // thetas per chain: the diagonal workgroup of a panel step waits for the other workgroups of ITS theta to have read the
     // block it overwrites -- only those wait, one per theta, so any number well below the GPU's workgroup slots is safe
     int64_t chunk = B < 96 ? B : 96;
-    const int64_t mem_cap = (ctx->opt_lml_batch_mb << 20) / (8 * L.stride);
+    int64_t mem_cap = (ctx->opt_lml_batch_mb << 20) / (8 * L.stride);
+    {
+        // ... and by what the device has free right now: a fit opens up to three such contexts per GPU beside the farm's,
+        // and "lml_batch_mb" is sized for an empty 288-GB part.  The arena may take what it already holds plus 70 % of
+        // the free memory.
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const int64_t room = ctx->barena_cap * 8 + (int64_t)((double)free_b * 0.7);
+            if (room / (8 * L.stride) < mem_cap) mem_cap = room / (8 * L.stride);
+        }
+    }
     if (chunk > mem_cap) chunk = mem_cap;
     if (chunk < 2) return 1;                // the caller evaluates them one after another
-    GPRY_TRY(ensure_batch_buffers(ctx, chunk * L.stride, (int64_t)sizeof(double) * chunk * (GPRY_BRES_STRIDE + 1 + GPRY_MAX_DIM)));
+    // a failed allocation (another context took the memory in between) halves the chunk; below two sets the thetas go
+    // through one after another instead of the fit failing
+    for (;;) {
+        const int rc = ensure_batch_buffers(ctx, chunk * L.stride, (int64_t)sizeof(double) * chunk * (GPRY_BRES_STRIDE + 1 + GPRY_MAX_DIM));
+        if (rc == 0) break;
+        (void)hipGetLastError();
+        chunk /= 2;
+        if (chunk < 2) return 1;
+    }
     double* hres = static_cast<double*>(ctx->hbres);
     double* hpar = hres + chunk * GPRY_BRES_STRIDE;         // [C, l_1 .. l_d] rows of a chunk, staged in the pinned buffer
     // the chain below is the code of a single evaluation: it finds the buffers of theta 0 where the context keeps its own
@@ -319,6 +337,7 @@ int gpry_factorize(gpry_ctx* ctx, int* info) {
     GPRY_TRY(solve_alpha(ctx, ctx->dV, ctx->dy, ctx->dvec, ctx->dalpha_, ctx->Np));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->factor_valid = true;
+    ctx->alpha_l2 = -1.0;
     return 0;
 }
 
@@ -425,7 +444,7 @@ int gpry_lml(gpry_ctx* ctx, const double* theta, int want_grad, double* lml, dou
 
 // B objective evaluations in one call: the optimiser runs of a multi-restart fit stepped side by side (gpry/gpr.py:883-994 runs
 // them one after another).  N <= 128, d <= 16: ONE launch, one workgroup per theta (lml_small.hip); up to Np = lml_batch
-// (default 2048): ONE chain of launches for all thetas (lml_batch_general) -- either way every theta gets the arithmetic of a
+// (default 4096): ONE chain of launches for all thetas (lml_batch_general) -- either way every theta gets the arithmetic of a
 // single gpry_lml call, hence the same bits; otherwise the thetas are evaluated one after another.
 int gpry_lml_batch(gpry_ctx* ctx, const double* thetas, int64_t B, int want_grad, double* lml, double* grad, int* info) {
     if (!ctx) return gpry_fail(nullptr, -1, "gpry_lml_batch: ctx is NULL");
@@ -620,7 +639,28 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
     // distances of the panel from the matrix pipe (cross_build_mfma_kernel; "cross_mfma" = 0: the difference form)
     // (not for Matern-1/2: exp(-r) has a cusp at r = 0, where the rounding noise e of the expanded r^2 becomes sqrt(e) in r --
     // 1e-7 in k for a candidate on a training point; the smoother kernels see e itself)
-    const bool fast_panel = ctx->opt_cross_mfma && !small_build && ctx->kernel_id != GPRY_MATERN12;
+    bool fast_panel = ctx->opt_cross_mfma && !small_build && ctx->kernel_id != GPRY_MATERN12;
+    if (fast_panel) {
+        // ... and not for a model whose weights would amplify that noise beyond the posterior tolerance.  The expanded form has
+        // |d r^2| <= 4 eps (|x - c|^2 + |y - c|^2) <= 8 eps S, S = sum_k 1 / l_k^2 (coordinates of the unit box), and
+        // |dk / d r^2| <= 1.5 C for the three smooth kernels: every entry of K* is off by at most e = 12 eps C S.  The mean
+        // sums N of them against alpha_: at worst e ||alpha_||_1; as rounding errors of different pairs are independent, in
+        // effect e ||alpha_||_2 -- which is what is held below 1e-9 (normalised y has unit variance; the parity contract is
+        // 1e-8 of the largest mean).  A nearly singular K (tiny noise, long length scales: large alpha_) takes the
+        // difference form, whose entries are good to 1e-15 C.
+        if (ctx->alpha_l2 < 0.0) {
+            std::vector<double> ha((size_t)ctx->N);
+            HIP_TRY(ctx, hipMemcpyAsync(ha.data(), ctx->dalpha_, sizeof(double) * ctx->N, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            double ss = 0.0;
+            for (double v : ha) ss += v * v;
+            ctx->alpha_l2 = sqrt(ss);
+        }
+        double S = 0.0;
+        for (int k = 0; k < ctx->d; k++) S += exp(-2.0 * ctx->theta[1 + k]);
+        const double e = 12.0 * 2.220446049250313e-16 * exp(ctx->theta[0]) * S;
+        if (!(e * ctx->alpha_l2 <= 1e-9)) fast_panel = false;
+    }
     if (fast_panel) GPRY_TRY(launch_cross_prepare(ctx));
     for (int64_t m0 = 0; m0 < M; m0 += chunk) {
         int64_t mc = (M - m0 < chunk) ? M - m0 : chunk;

@@ -241,6 +241,7 @@ extern "C" int gpry_append_rows(gpry_ctx* ctx, const double* Xnew_, const double
     }
     // alpha_ = V^T (V y) over the enlarged set
     GPRY_TRY(solve_alpha(ctx, ctx->dV, ctx->dy, ctx->dvec, ctx->dalpha_, ctx->Np));
+    ctx->alpha_l2 = -1.0;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -107,6 +107,7 @@ struct gpry_ctx {
     double xcenter[GPRY_MAX_DIM] = {0};    // mean of the training rows per dimension: the centre both sides are shifted by
     double xsum[GPRY_MAX_DIM] = {0};       // its running sums, in row order (set_train, append_rows)
     int opt_cross_mfma = 1;    // 1 (default): the sweep's cross-kernel panel takes its distances from the matrix pipe
+    double alpha_l2 = -1.0;    // ||alpha_||_2 of the prediction factor (fetched when the panel form is chosen; < 0: not yet)
     double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
     int64_t kst_cap = 0;       // doubles allocated
     double* dG = nullptr;      // Np x dpad: d k(x, X_j)/dx of the last gpry_predict_grad

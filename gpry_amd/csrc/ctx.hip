@@ -116,6 +116,13 @@ int ensure_capacity(gpry_ctx* ctx, int64_t N, int d) {
         if (ctx->dU) { GPRY_TRY(dev_free(ctx, ctx->dU)); ctx->dU = nullptr; }
         if (ctx->dXkb) { GPRY_TRY(dev_free(ctx, ctx->dXkb)); ctx->dXkb = nullptr; }
     }
+    // the scratch arena of the batched objective is sized for the padded size it was last used with: a smaller model gives
+    // the memory back (the next gpry_lml_batch allocates what it needs)
+    if (ctx->barena && Np < ctx->Np) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->barena);
+        ctx->barena = nullptr; ctx->barena_cap = 0;
+    }
     ctx->N = N; ctx->Np = Np; ctx->d = d; ctx->dpad = dpad;
     return 0;
 }

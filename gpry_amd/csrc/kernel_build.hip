@@ -316,10 +316,12 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
 // v_mfma_f64_16x16x4_f64 (d / 4 instructions per 16 x 16 block of pairs, issued beside the vector work of the other
 // waves): 3 vector instructions per pair instead of 2 d.  The expanded form cancels, so both sides are CENTRED first
 // (x - c, y - c with c = the mean of the training rows per dimension: distances do not change, the norms shrink to the
-// spread of the data): the absolute error of r^2 is ~4 eps (|x - c|^2 + |y - c|^2), i.e. 1e-14 ... 1e-12 relative in
-// C k(r) for length scales down to a hundredth of the box -- the posterior tolerances are 1e-8 (mean) and 1e-9 C
-// (variance).  The exact difference form stays for gpry_kernel_cross (K* itself is compared at 1e-13), the small
-// batches and the Kriging-believer registrations.
+// spread of the data): the absolute error of r^2 is <= 4 eps (|x - c|^2 + |y - c|^2) <= 8 eps sum_k 1 / l_k^2 in the unit
+// box, i.e. up to 12 eps C sum_k 1 / l_k^2 in an entry of K*: 1e-14 C at l = 0.3, d = 16, but 7e-11 C at l = 0.01 -- and
+// the posterior mean multiplies that by the weights alpha_.  The caller (api.hip, where the panel form is chosen) therefore takes this form
+// only while that product stays below the posterior tolerance (1e-9; the contract is 1e-8 for the mean and 1e-9 C for the
+// variance) and the difference form otherwise.  The exact difference form also stays for gpry_kernel_cross (K* itself is
+// compared at 1e-13), the small batches and the Kriging-believer registrations.
 // Workgroup = 128 training rows x 256 candidates as above; wave w owns candidates 64 w .. 64 w + 63 as four MFMA column
 // blocks; per 16 training rows (A operand from LDS) 4 x d/4 MFMAs give each lane 4 x 4 pairs: rows g + 4 q (g = lane >> 4),
 // candidate lane & 15 of each block, stored as 128-byte row segments.

@@ -199,7 +199,10 @@ class BatchOptimizer(GenericGPAcquisition):
         if np.iterable(gpr.noise_level) and getattr(self.acq_func, "sigma_n", None) is None:
             return False
         from gpry_amd import lockstep
-        return lockstep.available()
+        if lockstep.available():
+            return True
+        lockstep.warn_once("the acquisition optimiser's restarts")
+        return False
 
     def _optimize_side_by_side(self, gpr, n_runs, use_bounds, rng, proposal_X, acq_X):
         """The ``n_runs`` optimiser runs of one proposal with their posterior evaluations batched: the starting points are

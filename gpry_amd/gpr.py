@@ -38,24 +38,60 @@ except Exception:  # pragma: no cover
 
 # One process per GPU is announced differently by every launcher: torchrun sets WORLD_SIZE / LOCAL_RANK; the reference's
 # own parallel mode is mpi4py under mpirun / srun (gpry/mpi.py:18-28, gpry/run.py:1254-1275), which set these instead.
-_WORLD_SIZE_VARS = ("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS")
+# A world size alone does not make a process a rank: inside an `sbatch --ntasks=8` allocation a plain `python run.py`
+# (no srun) sees SLURM_NTASKS=8 as well and must keep all its GPUs -- the launcher's rank variable has to be there too.
+_LAUNCHERS = (("WORLD_SIZE", ("RANK", "LOCAL_RANK")),
+              ("OMPI_COMM_WORLD_SIZE", ("OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_LOCAL_RANK")),
+              ("PMI_SIZE", ("PMI_RANK", "MPI_LOCALRANKID")),
+              ("SLURM_NTASKS", ("SLURM_STEP_ID", "SLURM_STEPID")))      # set inside an srun step only, not in the batch script
+_WORLD_SIZE_VARS = tuple(v for v, _ in _LAUNCHERS)
 _LOCAL_RANK_VARS = ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID")
+_LAUNCH_NOTE = {"said": False}
 
 
 def multi_process_launch():
-    """True if this process is one rank of a multi-process launch (any launcher's world-size variable > 1, or an
-    initialised mpi4py world of more than one rank)."""
-    for var in _WORLD_SIZE_VARS:
+    """True if this process is one rank of a multi-process launch: a launcher's world-size variable > 1 TOGETHER WITH that
+    launcher's rank variable, or an initialised mpi4py world of more than one rank.  A world size without a rank (a
+    single process inside a multi-task allocation) is not one; that decision is logged once."""
+    for size_var, rank_vars in _LAUNCHERS:
         try:
-            if int(os.environ.get(var, "1")) > 1:
-                return True
+            many = int(os.environ.get(size_var, "1")) > 1
         except ValueError:
-            pass
+            many = False
+        if not many:
+            continue
+        if any(os.environ.get(v, "") != "" for v in rank_vars):
+            return True
+        if not _LAUNCH_NOTE["said"]:
+            _LAUNCH_NOTE["said"] = True
+            import logging
+            logging.getLogger("gpry_amd").info(
+                "%s=%s without %s: treated as ONE process that may use every visible GPU, not as a rank of a "
+                "multi-process launch", size_var, os.environ.get(size_var), " / ".join(rank_vars))
     mpi = sys.modules.get("mpi4py.MPI")
     try:
         return mpi is not None and mpi.Is_initialized() and mpi.COMM_WORLD.Get_size() > 1
     except Exception:
         return False
+
+
+# options of a device context that change the arithmetic or the limits of an objective evaluation: extra contexts of a fit
+# (thread farm, side-by-side groups) take the values of the model's own context, so that every context evaluates alike
+# whatever the caller has set ("same bits as the sequential loop")
+_FIT_CONTEXT_OPTIONS = ("chol", "chol_overlap", "factor_pipeline", "factor_pipeline_min", "gemm_dma", "gemm_streamk",
+                        "gemm_small", "lml_small", "lml_cache", "lml_batch", "lml_batch_mb")
+
+
+def copy_fit_options(src, dst):
+    if not (hasattr(src, "get_option") and hasattr(dst, "set_option")):
+        return
+    for key in _FIT_CONTEXT_OPTIONS:
+        try:
+            v = src.get_option(key)
+            if dst.get_option(key) != v:
+                dst.set_option(key, v)
+        except Exception:       # an option this build does not know
+            pass
 
 
 def default_device_index():
@@ -691,6 +727,7 @@ class GaussianProcessRegressor(_RM, _BE):
         self._rng = check_random_state(self.random_state)
         ctx_devs = (fit_context_devices(getattr(self.device, "device", 0), n_restarts, getattr(self, "fit_devices", None))
                     if self.optimizer == "fmin_l_bfgs_b" else [0])
+        self._side_by_side_why = ""
         side_by_side = n_restarts > 1 and self._can_step_restarts_together()
         if side_by_side or len(ctx_devs) > 1:
             # the optimiser never touches the RNG: drawing the start points up front gives the reference's
@@ -708,6 +745,13 @@ class GaussianProcessRegressor(_RM, _BE):
                 else:
                     theta0 = self._rng.uniform(hyperparameter_bounds[:, 0], hyperparameter_bounds[:, 1])
                 optima.append(self._constrained_optimization(obj_func, theta0, hyperparameter_bounds))
+            self.fit_stats = {"contexts": 1, "devices": [getattr(self.device, "device", 0)], "evals_per_context": None}
+        # how the restarts ran, for whoever wonders why a fit was slow: side by side (one batched objective per round) or
+        # one after another / farmed over contexts, and -- when scipy's private routine was the obstacle -- why
+        self.fit_stats = dict(getattr(self, "fit_stats", None) or {})
+        self.fit_stats["side_by_side"] = bool(side_by_side)
+        self.fit_stats["why"] = "" if side_by_side else (self._side_by_side_why or
+                                                         ("one restart" if n_restarts <= 1 else "not applicable to this model / optimizer"))
         values = [o[1] for o in optima]
         self.log_marginal_likelihood_value_ = -np.min(values)
         self.kernel_.theta = optima[int(np.argmin(values))][0]
@@ -731,7 +775,13 @@ class GaussianProcessRegressor(_RM, _BE):
         elif self.n > int(getattr(self.device, "lml_batch_max", 128)):
             return False
         from gpry_amd import lockstep
-        return lockstep.available()
+        if lockstep.available():
+            return True
+        # everything else allows the side-by-side form and scipy's routine does not: say so once (the fit below is 3-7x
+        # slower) and leave the reason where a caller can find it (fit_stats["why"])
+        lockstep.warn_once("multi-restart hyper-parameter fits")
+        self._side_by_side_why = lockstep.why()
+        return False
 
     def _restarts_side_by_side(self, starts, bounds):
         """The runs of a multi-restart fit stepped together (``gpry_amd.lockstep``: scipy's own L-BFGS-B routine, one
@@ -767,6 +817,7 @@ class GaussianProcessRegressor(_RM, _BE):
                     self._fit_devs.append(hit)
                 else:
                     spare.remove(hit)
+                copy_fit_options(dev, hit[1])
                 hit[1].set_train(self.X_train_, self.y_train_, self.alpha)
                 hit[1].set_theta(kid, theta_full0)
                 devs.append(hit[1])
@@ -870,6 +921,7 @@ class GaussianProcessRegressor(_RM, _BE):
             used.append(hit)
 
         def _replicate(dv):
+            copy_fit_options(self.device, dv)
             dv.set_train(self.X_train_, self.y_train_, self.alpha)
             dv.set_theta(kid, theta_full0)
 

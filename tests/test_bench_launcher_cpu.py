@@ -109,3 +109,80 @@ def test_more_gpus_than_visible_is_refused(monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "4"])
     assert e.value.code == 2
+
+
+def _store_world(world, port, occupy=None):
+    """the ranks of a ``bench._TcpStore`` as threads of this process: what every rank saw"""
+    import socket
+    import threading
+    import bench
+    foreign = None
+    if occupy is not None:          # some other service on the first candidate port: it answers, but not with the handshake word
+        foreign = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        foreign.bind(("127.0.0.1", port + occupy))
+        foreign.listen(8)
+
+        def chatter():
+            while True:
+                try:
+                    c, _ = foreign.accept()
+                except OSError:
+                    return
+                try:
+                    c.sendall(b"\x05\x00\x00\x00hello")
+                finally:
+                    c.close()
+        threading.Thread(target=chatter, daemon=True).start()
+    seen, errors = {}, []
+
+    def run(rank):
+        try:
+            st = bench._TcpStore(rank, world, addr="127.0.0.1", port=port, timeout=30)
+            uid = st.broadcast(bytes(range(128)) if rank == 0 else b"")
+            low = st.all_min(1.0 if rank != 1 else 0.0)          # rank 1 "has no communicator"
+            st.barrier()
+            high = st.all_min(5.0 + rank)
+            st.barrier()
+            st.destroy_process_group()
+            seen[rank] = (uid, low, high)
+        except Exception as e:      # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths[::-1]:             # the server last: the others retry until it listens
+        t.start()
+    for t in ths:
+        t.join(60)
+    if foreign is not None:
+        foreign.close()
+    assert not errors, errors
+    return seen
+
+
+def _free_port_block():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_the_tcp_store_of_the_rccl_rendezvous_needs_no_torch():
+    """the 128-byte RCCL id, the agreement on the transport and the barriers of ``bench.py --gpus N`` go
+    over a small TCP store next to MASTER_PORT -- no ``torch`` on the RCCL path (gloo only behind ``--allow-gloo``)."""
+    import bench
+    for world, occupy in ((3, None), (2, 1)):
+        seen = _store_world(world, _free_port_block(), occupy)
+        assert sorted(seen) == list(range(world))
+        for r in range(world):
+            uid, low, high = seen[r]
+            assert uid == bytes(range(128)) and low == (0.0 if world > 1 else 1.0) and high == 5.0
+    # the RCCL path of the bench imports no torch: `connect` reaches for it only behind --allow-gloo
+    import inspect
+    src = inspect.getsource(bench.connect)
+    assert src.count("import torch") == 1 and src.index("import torch") > src.index("using gloo (--allow-gloo)")
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "st = bench._TcpStore(0, 1, addr='127.0.0.1', port=%d, timeout=5); st.barrier(); st.destroy_process_group(); "
+            "assert 'torch' not in sys.modules, 'torch was imported'" % (ROOT, _free_port_block()))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]

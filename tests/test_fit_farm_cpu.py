@@ -164,20 +164,56 @@ def test_fit_contexts_are_dealt_out_over_the_devices_of_the_process(monkeypatch)
     monkeypatch.setenv("GPRY_HIP_DEVICES", "none")
     assert G.fit_context_devices(3, 32) == [3, 3]
     monkeypatch.delenv("GPRY_HIP_DEVICES")
+    for var in ("RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_STEP_ID", "SLURM_STEPID", "MPI_LOCALRANKID",
+                "OMPI_COMM_WORLD_LOCAL_RANK"):
+        monkeypatch.delenv(var, raising=False)
     monkeypatch.setenv("WORLD_SIZE", "8")                 # one process per GPU: the ranks farm among themselves
+    monkeypatch.setenv("RANK", "6")
     assert G.fit_context_devices(6, 32) == [6, 6]
     monkeypatch.delenv("WORLD_SIZE")
-    # the reference's own parallel mode is mpi4py under mpirun / srun: no WORLD_SIZE there
-    for var in ("OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"):
+    monkeypatch.delenv("RANK")
+    # the reference's own parallel mode is mpi4py under mpirun / srun: no WORLD_SIZE there; a world size
+    # WITHOUT the launcher's rank variable is a single process inside a multi-task allocation (`sbatch --ntasks=8` and no
+    # srun): it keeps every GPU
+    for var, rank_var in (("OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_RANK"), ("PMI_SIZE", "PMI_RANK"), ("SLURM_NTASKS", "SLURM_STEP_ID")):
         monkeypatch.setenv(var, "8")
+        assert not G.multi_process_launch()
+        assert G.fit_context_devices(6, 32)[:3] == [6, 0, 1]
+        monkeypatch.setenv(rank_var, "0")
+        assert G.multi_process_launch()
         assert G.fit_context_devices(6, 32) == [6, 6]
         monkeypatch.delenv(var)
+        monkeypatch.delenv(rank_var)
     monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "5")
     assert G.default_device_index() == 5
     monkeypatch.delenv("OMPI_COMM_WORLD_LOCAL_RANK")
     assert G.fit_context_devices(0, 32, spec=[0, 0, 1, 1, 1]) == [0, 0, 1, 1, 1]
     monkeypatch.setattr(_lib, "device_count", lambda: 1)
     assert G.fit_context_devices(0, 32) == [0, 0]
+
+
+def test_extra_fit_contexts_take_the_options_of_the_models_own_context():
+    """contexts created for a fit (thread farm, side-by-side groups) evaluate with the options of the model's
+    own context -- comparator factorisation, limits of the batched chain ... -- not with the defaults."""
+    from gpry_amd import gpr as G
+
+    class Ctx:
+        def __init__(self, **kw):
+            self.o = {k: 0 for k in G._FIT_CONTEXT_OPTIONS}
+            self.o.update(kw)
+            self.sets = []
+
+        def get_option(self, k):
+            return self.o[k]
+
+        def set_option(self, k, v):
+            self.o[k] = v
+            self.sets.append(k)
+
+    own, extra = Ctx(chol=1, lml_batch=2048, lml_batch_mb=512), Ctx(lml_batch=4096)
+    G.copy_fit_options(own, extra)
+    assert extra.o == own.o and sorted(extra.sets) == ["chol", "lml_batch", "lml_batch_mb"]
+    G.copy_fit_options(own, object())          # a device double without options: nothing to do
 
 
 @pytest.mark.parametrize("devices", [[0, 1], [0, 1, 2, 3, 4, 5, 6, 7], [0, 0, 1, 1, 2]])
@@ -602,20 +638,96 @@ def test_lockstep_driver_reproduces_fmin_l_bfgs_b():
     assert batches[0] == 9 and min(batches) < 9 and sum(batches) == nfev.sum()
 
 
-def test_lockstep_driver_refuses_a_scipy_it_was_not_tested_with(monkeypatch):
-    """The driver hard-codes the work-array sizes of scipy 1.15's ``setulb``: any other release is refused before the first
-    call into the private routine (VERDICT r03 #8), and the callers run the restarts one after another."""
-    import scipy
+def _fresh_lockstep_state(monkeypatch):
     from gpry_amd import lockstep
-    calls = []
-    from scipy.optimize import _lbfgsb
-    monkeypatch.setattr(_lbfgsb, "setulb", lambda *a, **k: calls.append(1))
+    monkeypatch.setattr(lockstep, "_STATE", {"checked": False, "ok": False, "why": "", "warned": False, "how": ""})
+    return lockstep
+
+
+def test_lockstep_gate_goes_by_introspection_not_by_version_alone(monkeypatch):
+    """``lockstep.available()``: the private routine is accepted when its argument list and the work arrays
+    scipy's own wrapper allocates for it are the ones the driver uses, and a dry run behind canary padding reproduces
+    ``fmin_l_bfgs_b`` -- whatever the version string says; it is refused, BEFORE the first call, when either differs."""
+    import inspect
+    import scipy
+    from scipy.optimize import _lbfgsb, _lbfgsb_py
+    # (a) a later release with the same routine: accepted (the version number alone used to refuse it)
+    lockstep = _fresh_lockstep_state(monkeypatch)
     for ver, ok in (("1.14.1", False), ("1.16.0", False), ("2.0.0", False), ("1.15.0rc1", True), ("weird", False)):
         monkeypatch.setattr(scipy, "__version__", ver)
         assert lockstep._scipy_version_ok()[0] is ok
     monkeypatch.setattr(scipy, "__version__", "1.16.2")
-    monkeypatch.setattr(lockstep, "_STATE", {"checked": False, "ok": False, "why": ""})
-    assert not lockstep.available() and "1.16.2" in lockstep._STATE["why"] and not calls
+    assert lockstep.available() and "1.16.2" in lockstep.how() and lockstep.why() == ""
+    # (b) another argument list: refused without a call
+    calls = []
+    real = _lbfgsb.setulb
+
+    def other_signature(*a, **k):
+        calls.append(1)
+    other_signature.__doc__ = "setulb(m,x,l,u,nbd,f,g,factr,pgtol,wa,iwa,task,iprint,csave,lsave,isave,dsave,maxls)"
+    lockstep = _fresh_lockstep_state(monkeypatch)
+    monkeypatch.setattr(_lbfgsb, "setulb", other_signature)
+    assert not lockstep.available() and "argument list" in lockstep.why() and not calls
+    monkeypatch.setattr(_lbfgsb, "setulb", real)
+    # (c) scipy's wrapper allocates larger work arrays: refused without a call
+    lockstep = _fresh_lockstep_state(monkeypatch)
+    src = inspect.getsource(_lbfgsb_py._minimize_lbfgsb).replace("isave = zeros(44", "isave = zeros(48")
+    monkeypatch.setattr(inspect, "getsource", lambda f: src)
+    spy = []
+    monkeypatch.setattr(_lbfgsb, "setulb", lambda *a, **k: spy.append(1))
+    assert not lockstep.available() and "isave" in lockstep.why() and not spy
+    monkeypatch.undo()
+
+
+def test_lockstep_dry_run_catches_a_routine_that_writes_past_its_work_arrays(monkeypatch):
+    """The self-check runs behind canary padding: a routine that writes beyond ``wa`` (larger work arrays than scipy
+    1.15's) is caught by the dry run and refused."""
+    from scipy.optimize import _lbfgsb
+    lockstep = _fresh_lockstep_state(monkeypatch)
+    real = _lbfgsb.setulb
+
+    def overrunning(m, x, l, u, nbd, f, g, factr, pgtol, wa, iwa, *rest):
+        if wa.base is not None:
+            wa.base[wa.size + 3] = 1.0          # what a routine with a longer `wa` would do
+        return real(m, x, l, u, nbd, f, g, factr, pgtol, wa, iwa, *rest)
+    overrunning.__doc__ = real.__doc__
+    monkeypatch.setattr(_lbfgsb, "setulb", overrunning)
+    assert not lockstep.available() and "wrote past the end of `wa`" in lockstep.why()
+
+
+def test_a_fit_that_cannot_run_side_by_side_says_so(monkeypatch):
+    """When scipy's routine is refused, the multi-restart fit runs one restart after another, warns ONCE with the reason
+    and records it: ``fit_stats["side_by_side"]`` is False and ``fit_stats["why"]`` carries the reason; the result is
+    the side-by-side fit's."""
+    import warnings
+    from scipy.optimize import _lbfgsb
+    g = load_golden("fit")
+    p = "f6_k3_"
+    X, y = g[p + "X"], g[p + "y"]
+    monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+    monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", "1")
+    ref = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=4, random_state=7)
+    ref.append_to_data(X[:60], y[:60], fit_gpr=True)
+    assert ref.fit_stats["side_by_side"] and ref.fit_stats["why"] == ""
+    lockstep = _fresh_lockstep_state(monkeypatch)
+    real = _lbfgsb.setulb
+
+    def fake(*a, **k):          # (scipy's own fmin_l_bfgs_b keeps working: only the docstring the gate reads differs)
+        return real(*a, **k)
+    fake.__doc__ = "setulb(some,other,arguments)"
+    monkeypatch.setattr(_lbfgsb, "setulb", fake)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        gpr = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=4, random_state=7)
+        gpr.append_to_data(X[:60], y[:60], fit_gpr=True)
+        gpr2 = make_gpr(g[p + "bounds"], 3, n_restarts_optimizer=4, random_state=7)
+        gpr2.append_to_data(X[:60], y[:60], fit_gpr=True)
+    said = [w for w in rec if "one restart after another" in str(w.message)]
+    assert len(said) == 1 and "argument list" in str(said[0].message)          # once per process, with the reason
+    for m in (gpr, gpr2):
+        assert m.fit_stats["side_by_side"] is False and "argument list" in m.fit_stats["why"]
+    np.testing.assert_array_equal(gpr.kernel_.theta, ref.kernel_.theta)
+    assert gpr.log_marginal_likelihood_value_ == ref.log_marginal_likelihood_value_
 
 
 def test_proposers_draw_in_the_reference_order():
