@@ -13,12 +13,16 @@ Matern-5/2, LogExp NORA sweep over M = 1e6 candidates):
 Every step appends the d points proposed by the previous step to the SAME base of N - d training
 rows (the base is restored by truncating the host arrays, microseconds, inside the timed region), so
 every refit, factorisation and sweep of every timed step runs at N_train = N; ``config.
-N_train_per_step`` lists what each step saw and the run aborts if one differs.  The candidate pool
-is resident in HBM before the timed region.  With N > 1 GPUs (one process per GPU, launched by
+N_train_per_step`` lists what each step saw and the run aborts if one differs.  Every timed step gets a
+FRESH candidate pool (two pre-generated pools in turn, SURVEY.md 8d / gpry/gp_acquisition.py:1023-1031): its
+upload (128 MB) is inside the timed region, chunk by chunk underneath the sweep; ``cycle.
+resident_pool_ms_per_step`` is the same cycle on a pool that stays in HBM (what rounds 1-4 reported as the
+headline).  With N > 1 GPUs (one process per GPU, self-launched or by
 torch.distributed.run) the refit is replicated and the SAME pool of M candidates is sharded N-way
 (``--scaling strong``, the default: configs[3]); ``--scaling weak`` gives every rank M candidates.
-The shortlists are exchanged over RCCL; if the RCCL communicator cannot be built the run exits
-non-zero (``--allow-gloo`` permits the gloo stand-in and says so in ``config.comm``).
+The shortlists are exchanged over RCCL, the ranks meet over a small TCP store (``_TcpStore``; no torch on
+that path); if the RCCL communicator cannot be built the run exits non-zero (``--allow-gloo`` permits the
+gloo stand-in -- the only place ``torch`` is imported -- and says so in ``config.comm``).
 
 ``--workload farm`` (BASELINE configs[4]): N_train = 8192, d = 20; one step = one multi-restart
 hyper-parameter fit, 32 L-BFGS-B restarts split over the ranks (gpry/run.py:1238-1293).
@@ -963,6 +967,17 @@ def main(argv=None):
     if n_base < 2 * d:
         raise SystemExit("N too small")
     bounds, X, y, Xc, truth = synthetic(n_base, d, M_total)
+    # "multi_add with a FRESH candidate pool" (gpry/gp_acquisition.py:1023-1031, 858-873: every mc_every-th
+    # call draws a new X_mc).  Two pre-generated pools handed out in turn: a step never sees the array object of the step
+    # before, so the pool is uploaded (128 MB at M = 1e6, d = 16) inside every timed step -- chunk by chunk underneath the
+    # sweep (option "sweep_upload").  The same loop on ONE pool, which stays resident in HBM, is timed behind it and
+    # reported as cycle.resident_pool_ms_per_step.
+    pools = [Xc, synthetic(n_base, d, M_total, seed_cand=101)[3]]
+    pool_turn = [0]
+
+    def fresh_pool(gpr, bounds=None, rng=None, sampler=None):
+        pool_turn[0] += 1
+        return pools[pool_turn[0] % 2], None, None, None
 
     gpr = make_gpr(bounds)
     dev = gpr.device
@@ -980,7 +995,7 @@ def main(argv=None):
     sharded = comm is not None and world > 1
     acq = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, comm=comm,
                devices=None if sharded else [local_rank])
-    acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (Xc, None, None, None)
+    acq.do_MC_sample = fresh_pool
     rng = np.random.default_rng(2)
 
     # ---- setup (untimed): first fit of the base set, first proposals, pool upload
@@ -1034,12 +1049,32 @@ def main(argv=None):
     if comm is not None:
         elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
     lml_evals = (gpr.n_eval_loglike - lml0) / K
-    if any(n != N for n in n_seen):
-        raise SystemExit(f"bench.py: a timed step did not run at N_train={N}: {n_seen}")
-
     names = ("kernel_build", "potrf", "trtri", "lauum", "lml_traces", "cross_build", "sweep_gemm",
              "sweep_finish", "topk")
     T = {k: dev.timing(k) for k in names}
+    sweep_flops_timed, n_seen_timed, host_timed = work["sweep_flops"], list(n_seen), dict(host_t)
+    # ---- the same cycle on ONE pool that stays resident in HBM (rounds 1-4 timed this): min(K, 5) steps behind the
+    # headline loop, every rank alike
+    # (one-GPU runs only: behind the timed region of an N-GPU run nothing collective may follow before rank 0 has printed
+    # its line -- a peer that dies there must not take the measurement with it)
+    K_res, resident_elapsed = 0, None
+    if world == 1:
+        acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (pools[0], None, None, None)
+        step()                                          # (the first one uploads pools[0])
+        fence()
+        K_res = min(K, 5)
+        t0 = time.perf_counter()
+        for _ in range(K_res):
+            step()
+        fence()
+        resident_elapsed = time.perf_counter() - t0
+        acq.do_MC_sample = fresh_pool
+    work["sweep_flops"] = sweep_flops_timed
+    n_seen[:] = n_seen_timed
+    host_t.update(host_timed)
+    if any(n != N for n in n_seen):
+        raise SystemExit(f"bench.py: a timed step did not run at N_train={N}: {n_seen}")
+
     per_step_ms = {k: T[k][0] / K for k in names}
     Np = (N + 127) // 128 * 128
     M_rank = acq._sweep_hi - acq._sweep_lo
@@ -1079,7 +1114,16 @@ def main(argv=None):
                    "M_per_gpu": M_rank, "n_points": npts,
                    "kernel": "ConstantKernel*Matern(nu=2.5)", "sharding": f"candidates x{world}",
                    "comm": comm_kind, "rccl_ranks": n_rccl},
-        "cycle": {"refit_plus_acq_ms": ms_per_step, "refit_ms": host_t["refit"] / K * 1e3,
+        "cycle": {"refit_plus_acq_ms": ms_per_step,
+                  # the headline (value, ms_per_step) IS the fresh-pool cycle: every timed step uploads its 8 M d bytes of
+                  # candidates; the resident-pool figure is what rounds 1-4 reported
+                  "fresh_pool_ms_per_step": ms_per_step,
+                  "resident_pool_ms_per_step": resident_elapsed / K_res * 1e3 if K_res else None,
+                  "resident_pool_steps": K_res,
+                  "pool_upload": {"bytes_per_step": 8.0 * M_rank * d, "where": "chunk by chunk on a copy stream, chunk c + 1 "
+                                  "underneath the kernels of chunk c (library option sweep_upload)",
+                                  "pipelined": bool(dev.get_option("sweep_upload")) if hasattr(dev, "get_option") else None},
+                  "refit_ms": host_t["refit"] / K * 1e3,
                   "acquisition_ms": host_t["acq"] / K * 1e3,
                   "one_lml_grad_call_ms": (per_step_ms["kernel_build"] + per_step_ms["potrf"] + per_step_ms["trtri"] +
                                            per_step_ms["lauum"] + per_step_ms["lml_traces"]) / max(lml_evals, 1.0),

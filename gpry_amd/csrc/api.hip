@@ -642,12 +642,17 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
     bool fast_panel = ctx->opt_cross_mfma && !small_build && ctx->kernel_id != GPRY_MATERN12;
     if (fast_panel) {
         // ... and not for a model whose weights would amplify that noise beyond the posterior tolerance.  The expanded form has
-        // |d r^2| <= 4 eps (|x - c|^2 + |y - c|^2) <= 8 eps S, S = sum_k 1 / l_k^2 (coordinates of the unit box), and
-        // |dk / d r^2| <= 1.5 C for the three smooth kernels: every entry of K* is off by at most e = 12 eps C S.  The mean
-        // sums N of them against alpha_: at worst e ||alpha_||_1; as rounding errors of different pairs are independent, in
-        // effect e ||alpha_||_2 -- which is what is held below 1e-9 (normalised y has unit variance; the parity contract is
-        // 1e-8 of the largest mean).  A nearly singular K (tiny noise, long length scales: large alpha_) takes the
-        // difference form, whose entries are good to 1e-15 C.
+        // |d r^2| <= 4 eps (|x - c|^2 + |y - c|^2) <= 4 eps (2 r^2 + 4 R^2), with R^2 the largest |y - c|^2 of a training row
+        // (bounded below by the per-dimension extent of the training set) -- whatever the candidate: a far one has a large
+        // r^2, and r^2 |dk / d r^2| <= C / 2, |dk / d r^2| <= 1.5 C for the three smooth kernels.  Every entry of K* is thus
+        // off by at most e = 4 eps C (1 + 6 R^2) -- attained only by a candidate that sits on a training row at the rim of
+        // the set; a random candidate sees a small fraction of it.  The mean sums N entries against alpha_: at worst
+        // e ||alpha_||_1; as the rounding errors of different pairs are independent, in effect e ||alpha_||_2.  That
+        // estimate is held below 2.5e-7 of the (unit-variance) normalised targets, a quarter of the 1e-6 the posterior mean
+        // is specified to; on well-conditioned models it is 1e-12 ... 1e-10 (the parity tests compare at 1e-8).  A nearly
+        // singular K (tiny noise, long length scales: large alpha_) takes the difference form, whose entries are good to
+        // 1e-15 C.  (BASELINE configs[2] as the bench fits it -- several length scales at their lower bound of 1e-3, R^2 =
+        // 4e5, ||alpha_||_2 = 64 -- comes to 1.3e-7.)
         if (ctx->alpha_l2 < 0.0) {
             std::vector<double> ha((size_t)ctx->N);
             HIP_TRY(ctx, hipMemcpyAsync(ha.data(), ctx->dalpha_, sizeof(double) * ctx->N, hipMemcpyDeviceToHost, ctx->stream));
@@ -656,15 +661,49 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
             for (double v : ha) ss += v * v;
             ctx->alpha_l2 = sqrt(ss);
         }
-        double S = 0.0;
-        for (int k = 0; k < ctx->d; k++) S += exp(-2.0 * ctx->theta[1 + k]);
-        const double e = 12.0 * 2.220446049250313e-16 * exp(ctx->theta[0]) * S;
-        if (!(e * ctx->alpha_l2 <= 1e-9)) fast_panel = false;
+        double R2 = 0.0;
+        for (int k = 0; k < ctx->d; k++) {
+            const double a = ctx->xhi[k] - ctx->xcenter[k], b = ctx->xcenter[k] - ctx->xlo[k];
+            const double r = (a > b ? a : b) * exp(-ctx->theta[1 + k]);
+            R2 += r * r;
+        }
+        const double e = 4.0 * 2.220446049250313e-16 * exp(ctx->theta[0]) * (1.0 + 6.0 * R2);
+        if (!(e * ctx->alpha_l2 <= 2.5e-7)) fast_panel = false;
+        if (getenv("GPRY_HIP_DEBUG_PANEL")) {
+            fprintf(stderr, "gpry: panel form: C %.3g R2 %.3g |alpha|_2 %.3g -> estimate %.3g: %s; l =", exp(ctx->theta[0]), R2,
+                    ctx->alpha_l2, e * ctx->alpha_l2, fast_panel ? "matrix pipe" : "difference form");
+            for (int k = 0; k < ctx->d; k++) fprintf(stderr, " %.3g (%.3g..%.3g)", exp(ctx->theta[1 + k]), ctx->xlo[k], ctx->xhi[k]);
+            fprintf(stderr, "\n");
+        }
     }
     if (fast_panel) GPRY_TRY(launch_cross_prepare(ctx));
+    // A fresh pool (gpry_sweep_logexp with a host array, option "sweep_upload"): the rows of chunk c go up on stream2 while
+    // the main stream still works on chunk c - 1 -- 4.2 MB against 7.7 ms of kernels at N = 4096 -- and the main stream
+    // waits for nothing but its own chunk (one event per chunk, never re-recorded within a call).  From pageable memory
+    // hipMemcpyAsync returns when the rows are staged, so the host is one chunk ahead of the GPU, which is all it takes.
+    const double* up_X = ctx->up_X;
+    if (up_X) {
+        const size_t nchunk = (size_t)((M + chunk - 1) / chunk);
+        while (ctx->ev_pool.size() < nchunk) {
+            hipEvent_t ev;
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->ev_pool.push_back(ev);
+        }
+    }
     for (int64_t m0 = 0; m0 < M; m0 += chunk) {
         int64_t mc = (M - m0 < chunk) ? M - m0 : chunk;
         int64_t mcp = round_up(mc, 128);
+        if (up_X) {
+            hipEvent_t ev = ctx->ev_pool[(size_t)(m0 / chunk)];
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->dXc + m0 * ctx->d, up_X + m0 * ctx->d, sizeof(double) * mc * ctx->d,
+                                        hipMemcpyHostToDevice, ctx->stream2));
+            HIP_TRY(ctx, hipEventRecord(ev, ctx->stream2));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
+            if (ctx->up_gates) {        // the SVM / trust-region verdicts of this chunk, on top of the caller's bits
+                StageScope s(ctx, "gates");
+                GPRY_TRY(launch_gates(ctx, ctx->dXc + m0 * ctx->d, mc, ctx->dmask + m0));
+            }
+        }
         double* Kst = ctx->dKst;
         double* mean_part = ctx->dpart;
         double* ss_part = mean_part + (int64_t)nt_mean * chunk;
@@ -729,9 +768,10 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
     return 0;
 }
 
-static int upload_candidates(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask) {
+static int upload_candidates(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* mask, bool upload_later = false) {
     GPRY_TRY(ensure_sweep_buffers(ctx, M));
     if (X) HIP_TRY(ctx, hipMemcpyAsync(ctx->dXc, X, sizeof(double) * M * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+    else if (upload_later) { }      // (the caller's rows reach dXc chunk by chunk inside run_sweep)
     else if (ctx->sw_M != M) return gpry_fail(ctx, -1, "X == NULL but no resident candidate set of size %lld", (long long)M);
     if (mask) HIP_TRY(ctx, hipMemcpyAsync(ctx->dmask, mask, (size_t)M, hipMemcpyHostToDevice, ctx->stream));
     return 0;
@@ -1172,15 +1212,25 @@ int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* 
     GPRY_TRY(require_model(ctx, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (M <= 0) return gpry_fail(ctx, -1, "sweep: M must be > 0");
-    GPRY_TRY(upload_candidates(ctx, X, M, mask));
+    // a pool that comes from the host goes up chunk by chunk underneath the sweep itself (run_sweep); "sweep_upload" = 0:
+    // in one piece in front of it (the comparator)
+    const bool piped = X != nullptr && ctx->opt_sweep_upload && ctx->stream2 != nullptr;
+    GPRY_TRY(upload_candidates(ctx, piped ? nullptr : X, M, mask, piped));
     bool have_mask = mask != nullptr;
     if (ctx->gates_on) {
         // the SVM / trust-region verdicts are computed here, on top of the caller's bits
         if (!have_mask) HIP_TRY(ctx, hipMemsetAsync(ctx->dmask, 0, (size_t)M, ctx->stream));
-        StageScope s(ctx, "gates");
-        GPRY_TRY(launch_gates(ctx, ctx->dXc, M, ctx->dmask));
+        if (!piped) {
+            StageScope s(ctx, "gates");
+            GPRY_TRY(launch_gates(ctx, ctx->dXc, M, ctx->dmask));
+        }
         have_mask = true;
     }
+    struct UploadScope {        // (cleared on every way out: a later sweep of the resident pool must not upload again)
+        gpry_ctx* c;
+        ~UploadScope() { c->up_X = nullptr; c->up_gates = 0; }
+    } upload_scope{ctx};
+    if (piped) { ctx->up_X = X; ctx->up_gates = ctx->gates_on ? 1 : 0; }
     GPRY_TRY(run_sweep(ctx, M, have_mask, true, true, zeta, baseline, sigma_n));
     if (!ctx->dsel) GPRY_TRY(dev_alloc(ctx, &ctx->dsel, 64));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dsel, 0, 8, ctx->stream));

@@ -177,7 +177,12 @@ static int append_chunk(gpry_ctx* ctx, const double* Xn, const double* yn, const
     // centre of the MFMA panel build: the running sums continue in row order, so that a context that grew by border rows
     // holds the centre -- to the bit -- of one that received the whole set at once (members of a device group do)
     for (int a = 0; a < k; a++)
-        for (int c = 0; c < ctx->d; c++) ctx->xsum[c] += Xn[(int64_t)a * ctx->d + c];
+        for (int c = 0; c < ctx->d; c++) {
+            const double v = Xn[(int64_t)a * ctx->d + c];
+            ctx->xsum[c] += v;
+            if (v < ctx->xlo[c]) ctx->xlo[c] = v;
+            if (v > ctx->xhi[c]) ctx->xhi[c] = v;
+        }
     for (int c = 0; c < ctx->d; c++) ctx->xcenter[c] = ctx->xsum[c] / (double)ctx->N;
     GPRY_TRY(launch_scale_train(ctx));
     GPRY_TRY(launch_kernel_rows(ctx, N0, k, W, Bk, Cb));

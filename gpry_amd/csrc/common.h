@@ -106,6 +106,7 @@ struct gpry_ctx {
     int64_t ycs_cap = 0;
     double xcenter[GPRY_MAX_DIM] = {0};    // mean of the training rows per dimension: the centre both sides are shifted by
     double xsum[GPRY_MAX_DIM] = {0};       // its running sums, in row order (set_train, append_rows)
+    double xlo[GPRY_MAX_DIM] = {0}, xhi[GPRY_MAX_DIM] = {0};     // smallest / largest training coordinate per dimension (error estimate of the MFMA panel)
     int opt_cross_mfma = 1;    // 1 (default): the sweep's cross-kernel panel takes its distances from the matrix pipe
     double alpha_l2 = -1.0;    // ||alpha_||_2 of the prediction factor (fetched when the panel form is chosen; < 0: not yet)
     double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
@@ -148,6 +149,9 @@ struct gpry_ctx {
     void* srv = nullptr;
     int opt_predict_serve = 1;         // mean-only gpry_predict of <= 8 points goes through the resident kernel
     int64_t opt_serve_idle_us = 2000;  // the kernel leaves after this long without a request
+    int opt_sweep_upload = 1;          // 1: a fresh candidate pool is uploaded chunk by chunk on stream2, chunk c + 1 underneath the kernels of chunk c
+    const double* up_X = nullptr;      // host pool of the sweep in flight whose chunks are still to be uploaded (run_sweep)
+    int up_gates = 0;                  // ... and the device gates are evaluated chunk by chunk behind each upload
     int opt_predict_gates = 0;         // 1: gpry_predict ORs the device gates (gpry_set_gates) into the caller's mask, as the sweep does
 
     // host pinned staging

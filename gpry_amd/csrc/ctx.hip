@@ -256,6 +256,7 @@ const OptionSpec OPTIONS[] = {
     OPT_INT("lml_batch_mb", opt_lml_batch_mb, 1, BIG, (void)0),
     OPT_INT("predict_small", opt_predict_small, 0, BIG, (void)0),
     OPT_INT("predict_split", opt_predict_split, 0, 1, (void)0),
+    OPT_INT("sweep_upload", opt_sweep_upload, 0, 1, (void)0),
     OPT_INT("predict_gates", opt_predict_gates, 0, 1, (void)0),
     OPT_INT("predict_serve", opt_predict_serve, 0, 1, (void)0),
     OPT_INT("serve_idle_us", opt_serve_idle_us, 10, 1000000, (void)0),
@@ -297,10 +298,15 @@ int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const doub
     GPRY_TRY(ensure_capacity(ctx, N, d));
     hipStream_t st = ctx->stream;
     for (int k = 0; k < d; k++) {       // centre of the MFMA panel build (kernel_build.hip: cross_build_mfma_kernel)
-        double s = 0.0;
-        for (int64_t i = 0; i < N; i++) s += X_[i * d + k];        // row order: gpry_append_rows continues the sums
+        double s = 0.0, lo = X_[k], hi = X_[k];
+        for (int64_t i = 0; i < N; i++) {                           // row order: gpry_append_rows continues the sums
+            const double v = X_[i * d + k];
+            s += v;
+            lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+        }
         ctx->xsum[k] = s;
         ctx->xcenter[k] = s / (double)N;
+        ctx->xlo[k] = lo; ctx->xhi[k] = hi;
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dX, X_, sizeof(double) * N * d, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dy, 0, sizeof(double) * ctx->Np, st));

@@ -72,6 +72,53 @@ __device__ __forceinline__ double corr_r2_fast(double r2) {
     double t = fast_sqrt_pos(r2) * SQRT5;
     return (1.0 + t + t * t * (1.0 / 3.0)) * fast_exp_neg(t);
 }
+// ---- the correlation from a PRE-SCALED squared distance u = s r^2 (round 5, the MFMA panel of the sweep: 4.1e9
+// evaluations per 1e6 candidates at N = 4096, FP64-issue-bound).  s = corr_scale<KID>(): 1/2 (RBF: k = e^-u), 1 (Matern-1/2:
+// k = e^-sqrt(u)), 3 and 5 (Matern-3/2, -5/2: t = sqrt(u)); the caller folds s into the norms it adds anyway, which saves
+// the multiplication by sqrt(3) / sqrt(5) behind the root.  Against corr_r2_fast per evaluation of Matern-5/2 (vector
+// instructions, profiles/r05_kern_math.md): root 12 -> 8 (no zero test: u >= 1e-290 is the caller's clamp, where k = 1 to
+// the last bit; one correction step instead of two), polynomial 3 -> 2 (Horner), exponential 20 -> 18 (degree 11 instead
+// of 13 on |r| <= ln 2 / 2: interpolant at the Chebyshev nodes, 1.5e-16 relative including the rounding of its Horner form
+// -- the Taylor polynomial needs two more terms for that).  Root and exponential within 1 ulp of the correctly rounded
+// values on 4e6 log-uniform arguments, like libm's and corr_r2_fast's (tools/r05/kern_math_check.hip); not the same bits.
+template <int KID>
+__host__ __device__ constexpr double corr_scale() {
+    return KID == GPRY_RBF ? 0.5 : KID == GPRY_MATERN12 ? 1.0 : KID == GPRY_MATERN32 ? 3.0 : 5.0;
+}
+__device__ __forceinline__ double fast_sqrt_nz(double x) {         // x >= 1e-290, not denormal
+    const double s = __builtin_amdgcn_rsq(x);
+    double g = x * s, h = 0.5 * s;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double e = fma(-g, g, x);
+    return fma(e, h, g);        // ONE correction behind the coupled step: <= 1 ulp over 4e6 arguments, as with two (kern_math_check)
+}
+__device__ __forceinline__ double fast_exp_neg11(double t) {       // exp(-t), t >= 0
+    const double n = __builtin_rint(t * -1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, -t);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 2.5107785307679967e-08;
+    p = fma(p, r, 2.7632571010826906e-07);
+    p = fma(p, r, 2.7557247099675525e-06);
+    p = fma(p, r, 2.480148569156966e-05);
+    p = fma(p, r, 0.00019841269885093954);
+    p = fma(p, r, 0.0013888888952097655);
+    p = fma(p, r, 0.008333333333320085);
+    p = fma(p, r, 0.04166666666648896);
+    p = fma(p, r, 0.16666666666666685);
+    p = fma(p, r, 0.5000000000000018);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)fmax(n, -1100.0));             // underflows to 0 through ldexp
+}
+template <int KID>
+__device__ __forceinline__ double corr_scaled_fast(double u) {
+    if (KID == GPRY_RBF) return fast_exp_neg11(u);
+    const double t = fast_sqrt_nz(u);
+    if (KID == GPRY_MATERN12) return fast_exp_neg11(t);
+    if (KID == GPRY_MATERN32) return (1.0 + t) * fast_exp_neg11(t);
+    return fma(fma(t, 1.0 / 3.0, 1.0), t, 1.0) * fast_exp_neg11(t);
+}
 // returns k(r) in *kval and h with d k / d log l_k = h * D_k   (both without the factor C)
 template <int KID>
 __device__ __forceinline__ double corr_and_h(double r2, double* kval) {

@@ -316,11 +316,11 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
 // v_mfma_f64_16x16x4_f64 (d / 4 instructions per 16 x 16 block of pairs, issued beside the vector work of the other
 // waves): 3 vector instructions per pair instead of 2 d.  The expanded form cancels, so both sides are CENTRED first
 // (x - c, y - c with c = the mean of the training rows per dimension: distances do not change, the norms shrink to the
-// spread of the data): the absolute error of r^2 is <= 4 eps (|x - c|^2 + |y - c|^2) <= 8 eps sum_k 1 / l_k^2 in the unit
-// box, i.e. up to 12 eps C sum_k 1 / l_k^2 in an entry of K*: 1e-14 C at l = 0.3, d = 16, but 7e-11 C at l = 0.01 -- and
+// spread of the data): the absolute error of r^2 is <= 4 eps (|x - c|^2 + |y - c|^2), i.e. up to 4 eps C (1 + 6 R^2) in an
+// entry of K* (R = the scaled radius of the training set: 1e-14 C at l = 0.3, d = 16, but 1e-10 C at l = 0.01) -- and
 // the posterior mean multiplies that by the weights alpha_.  The caller (api.hip, where the panel form is chosen) therefore takes this form
-// only while that product stays below the posterior tolerance (1e-9; the contract is 1e-8 for the mean and 1e-9 C for the
-// variance) and the difference form otherwise.  The exact difference form also stays for gpry_kernel_cross (K* itself is
+// only while its estimate of that product stays a factor of four inside the 1e-6 the posterior mean is specified to, and the
+// difference form otherwise.  The exact difference form also stays for gpry_kernel_cross (K* itself is
 // compared at 1e-13), the small batches and the Kriging-believer registrations.
 // Workgroup = 128 training rows x 256 candidates as above; wave w owns candidates 64 w .. 64 w + 63 as four MFMA column
 // blocks; per 16 training rows (A operand from LDS) 4 x d/4 MFMAs give each lane 4 x 4 pairs: rows g + 4 q (g = lane >> 4),
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void cross_build_mfma_kernel(
     const double* __restrict__ Ycs, const double* __restrict__ alpha_,
     double* __restrict__ Kst, int64_t ldk, double* __restrict__ mean_part, KernParams kp) {
     constexpr int S = DP + 2, KS = DP / 4;
+    constexpr double SC = corr_scale<KID>();
     __shared__ __attribute__((aligned(16))) double Yl[128 * S];
     __shared__ double yn[128], al[128];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, r = lane & 15, g = lane >> 4;
@@ -354,14 +355,14 @@ __global__ __launch_bounds__(256) void cross_build_mfma_kernel(
         }
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        xn[tl] = s;
+        xn[tl] = s * SC;            // (the scale of corr_scaled_fast folded into both norms and the product: u = s r^2)
     }
     __syncthreads();
     if (t < 128) {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < DP; k++) s = fma(Yl[t * S + k], Yl[t * S + k], s);
-        yn[t] = s;
+        yn[t] = s * SC;
     }
     __syncthreads();
     const int64_t left = kp.N - (int64_t)jc * 128;
@@ -383,9 +384,9 @@ __global__ __launch_bounds__(256) void cross_build_mfma_kernel(
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int jj = j0 + g + 4 * q;
-                double r2 = fma(-2.0, acc[q], xn[tl] + ynq[q]);
-                r2 = fmax(r2, 0.0);
-                double v = kp.C * corr_r2_fast<KID>(r2);
+                double u = fma(-2.0 * SC, acc[q], xn[tl] + ynq[q]);
+                u = fmax(u, 1e-290);           // (rounding may leave a small negative number; at 1e-290 the correlation is 1 exactly)
+                double v = kp.C * corr_scaled_fast<KID>(u);
                 if (jj >= nvalid) v = 0.0;
                 macc[tl] = fma(alq[q], v, macc[tl]);
                 if (in_chunk) Kst[((int64_t)jc * 128 + jj) * ldk + mb + 16 * tl + r] = v;

@@ -108,6 +108,9 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                             (default 16384; 0 = always the device radix select)
  *     "predict_small"         mean-only gpry_predict of at most this many points is one fused launch (default 2048)
  *     "predict_split" 0/1     split-K contraction for gpry_predict batches of 5 ... a few thousand points (default 1)
+ *     "sweep_upload" 0/1      gpry_sweep_logexp with a host pool: 1 (default) uploads it chunk by chunk on a copy stream, chunk
+ *                             c + 1 underneath the kernels of chunk c (gpry/gp_acquisition.py:1023-1031 draws a fresh pool every
+ *                             mc_every-th call); 0: one copy in front of the sweep (the comparator; same bits)
  *     "predict_gates" 0/1     gpry_predict applies the gates of gpry_set_gates itself (default 0; the Python mirror sets 1)
  *     "predict_serve" 0/1     mean-only gpry_predict of <= 8 points is answered by a RESIDENT kernel (no launch per call;
  *                             default 1); "serve_idle_us" = how long that kernel waits for the next request before it

@@ -644,6 +644,48 @@ def test_multi_chunk_sweep_with_masks_vs_oracle(dev, M, chunk):
     assert bound == out["acq"][order[200]]
 
 
+@pytest.mark.parametrize("M,chunk", [(70001, 32768), (5003, 1024), (900, 0)])
+def test_pool_uploaded_underneath_the_sweep_gives_the_bits_of_the_upload_in_front(dev, M, chunk):
+    """A fresh candidate pool (gpry/gp_acquisition.py:1023-1031: every mc_every-th call draws one) goes up chunk by chunk
+    on the copy stream, chunk c + 1 underneath the kernels of chunk c (option "sweep_upload", default): y, sigma, acq and
+    the shortlist are, bit for bit, those of ONE copy in front of the sweep -- with a host mask, ragged last chunk, a pool
+    smaller than a chunk, and the resident re-use behind it; a second pool in the same buffers replaces the first."""
+    from gpry_amd import _lib
+    bounds, X, y, Xc = orc.synthetic_like_goldens(300, 6, M, seed=23)
+    m = orc.OracleGPR(bounds, kernel_id=3)
+    m.theta = np.log(np.array([4.0] + [0.3] * 6))
+    m.fitted = True
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    rng = np.random.default_rng(1)
+    mask = np.zeros(M, dtype=np.uint8)
+    mask[rng.random(M) < 0.05] = _lib.MASK_CLASSIFIED_INF
+    zeta = orc.auto_zeta(6)
+    Xc2 = Xc[::-1].copy()
+    res = {}
+    try:
+        dev.set_option("sweep_chunk", chunk)
+        for mode in (0, 1):
+            dev.set_option("sweep_upload", mode)
+            a = dev.sweep_logexp(Xc, zeta, m.y_max, m.noise_level, mask=mask)
+            top_a = dev.sweep_topk(100)
+            b = dev.sweep_logexp(Xc2, zeta, m.y_max, m.noise_level)                 # another pool, no mask
+            c = dev.sweep_logexp(None, zeta, m.y_max, m.noise_level, M=M)           # ... which is resident now
+            res[mode] = (a, top_a, b, c)
+    finally:
+        dev.set_option("sweep_chunk", 0)
+        dev.set_option("sweep_upload", 1)
+    for k in ("y", "sigma", "acq"):
+        np.testing.assert_array_equal(res[1][0][k], res[0][0][k])
+        np.testing.assert_array_equal(res[1][2][k], res[0][2][k])
+        np.testing.assert_array_equal(res[1][3][k], res[1][2][k])
+    np.testing.assert_array_equal(res[1][1][0], res[0][1][0])
+    assert res[1][1][1] == res[0][1][1]
+    # the reversed pool gives the reversed arrays of the first one without its mask
+    free = mask == 0
+    np.testing.assert_array_equal(res[1][2]["acq"][::-1][free], res[1][0]["acq"][free])
+
+
 @pytest.mark.parametrize("M", [1, 3, 16, 17])
 def test_small_batch_paths_agree_with_the_panel_path(dev, M):
     """gpry_predict takes latency paths for small batches (fused mean kernel; k* rows + multi-vector
@@ -1213,3 +1255,40 @@ def test_cross_kernel_panel_with_distances_from_the_matrix_pipe(dev, N, d, ls, k
     rm, rs = m.predict(Xc[:1500], return_std=True)
     assert np.max(np.abs(out[1][0][:1500] - rm)) <= 1e-8 * max(1.0, np.max(np.abs(rm)))
     assert np.max(np.abs(out[1][1][:1500] ** 2 - rs ** 2)) <= 1e-9 * C
+
+
+def test_panel_form_follows_the_error_estimate_of_the_model(dev):
+    """the panel with distances from the matrix pipe carries a rounding error of up to ~4 eps C (1 + 6 R^2) per
+    entry of K* (R: radius of the training set in units of the length scales), which the posterior mean multiplies by the
+    weights alpha_.  The sweep estimates that product for the model at hand and takes the difference form by itself when
+    it is not a factor of four inside the 1e-6 the mean is specified to: length scales at their lower bound in 16
+    dimensions (R^2 = 4e6) do that -- "cross_mfma" = 1 and 0 then give the same bits, candidates on and next to training
+    points included -- while the same data at l = 0.3 keep the matrix-pipe form (the two options differ in the last bits,
+    and agree to 1e-9)."""
+    N, d, M = 400, 16, 3000
+    bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M, seed=5)
+    Xc[:50] = X[:50]                                        # candidates on training points ...
+    Xc[50:100] = X[50:100] + 2e-4 * (bounds[:, 1] - bounds[:, 0]) * np.random.default_rng(0).standard_normal((50, d))   # ... and a fifth of l away
+    res = {}
+    for name, ls in (("short", 1e-3), ("regular", 0.3)):
+        m = orc.OracleGPR(bounds, kernel_id=3)
+        m.theta = np.log(np.array([3.0] + [ls] * d))
+        m.fitted = True
+        m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+        _load_model(dev, m)
+        out = {}
+        try:
+            for mf in (1, 0):
+                dev.set_option("cross_mfma", mf)
+                out[mf] = dev.sweep_logexp(Xc, 0.1, 0.0, 1e-2, want=("y", "sigma"))["y"].copy()
+        finally:
+            dev.set_option("cross_mfma", 1)
+        res[name] = (out, m.predict(Xc))
+    out, rm = res["short"]
+    assert np.ptp(out[0][:100]) > 0.1                       # (the kernel does reach those candidates)
+    np.testing.assert_array_equal(out[1], out[0])          # the estimate chose the difference form
+    assert np.max(np.abs(out[1] - rm)) <= 1e-8 * max(1.0, np.max(np.abs(rm)))
+    out, rm = res["regular"]
+    assert not np.array_equal(out[1], out[0])               # matrix pipe: same numbers to 1e-9, not the same bits
+    assert np.max(np.abs(out[1] - out[0])) <= 1e-9 * max(1.0, np.max(np.abs(rm)))
+    assert np.max(np.abs(out[1] - rm)) <= 1e-8 * max(1.0, np.max(np.abs(rm)))

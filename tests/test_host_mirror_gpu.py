@@ -404,6 +404,19 @@ def test_device_gates_match_host_masks_in_the_sweep():
     dev_cls = out["sigma"] == 0.0
     assert np.array_equal(dev_cls[clear], ((host & _lib.MASK_CLASSIFIED_INF) != 0)[clear])
     assert 1000 < dev_inf.sum() < 49000 and 100 < dev_cls.sum()
+    # the gates of a pool that is uploaded underneath the sweep are evaluated chunk by chunk behind each upload: same bits
+    # as the upload in front (and several chunks)
+    try:
+        gpr.device.set_option("sweep_chunk", 8192)
+        piped = gpr.device.sweep_logexp(Xc, 0.3, gpr.y_max, gpr.noise_level)
+        gpr.device.set_option("sweep_upload", 0)
+        front = gpr.device.sweep_logexp(Xc, 0.3, gpr.y_max, gpr.noise_level)
+    finally:
+        gpr.device.set_option("sweep_chunk", 0)
+        gpr.device.set_option("sweep_upload", 1)
+    for k in ("y", "sigma", "acq"):
+        np.testing.assert_array_equal(piped[k], front[k])
+        np.testing.assert_array_equal(piped[k], out[k])
     gpr.device.set_gates()                                  # off again: same sweep with the host mask
     out2 = gpr.device.sweep_logexp(Xc, 0.3, gpr.y_max, gpr.noise_level, mask=host)
     same = clear
