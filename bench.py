@@ -194,6 +194,26 @@ def cpu_baseline(N, d, M, lml_evals, cache_models):
     }
 
 
+def measured_traffic(which, Np, M_launch_total):
+    """HBM-side bytes per launch of the sweep contraction, from the PMC counters of THIS round's build
+    (profiles/r05_traffic.json, written from tools/r05/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns (bytes or None, note): the figure is
+    a measurement of the profiled run of that workload shape, not of this process; it is carried only when the shape of
+    this run (padded training size, candidates per launch) is the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r05_traffic.json")
+    if not os.path.exists(path):
+        return None, "no PMC measurement of this round's build (profiles/r05_traffic.json)"
+    rec = json.load(open(path)).get(which)
+    if not rec:
+        return None, f"profiles/r05_traffic.json has no entry {which!r}"
+    if int(rec.get("Np", -1)) != int(Np):
+        return None, f"measured at Np={rec.get('Np')}, this run has Np={Np}"
+    note = (f"{rec['hbm_bytes_per_launch'] / 1e9:.2f} GB per launch of {rec['candidates_per_launch']} candidates = "
+            f"{rec['hbm_bytes_per_launch'] / rec['algorithmic_bytes_per_launch']:.2f} x the {rec['algorithmic_bytes_per_launch'] / 1e9:.3f} GB "
+            f"of operands ({rec['source']})")
+    return rec["hbm_bytes_per_launch"], note
+
+
 class _GlooComm:
     """Same interface as gpry_amd._lib.RcclComm over torch.distributed/gloo: used by the bench only
     with ``--allow-gloo`` when the RCCL communicator cannot be created."""
@@ -696,7 +716,8 @@ def run_config1(args):
         "results_equal_predict": same, "predict_through_host_boundary_ms": predict_host_ms,
         "roofline": {"kernel": "sweep contraction (V lower-triangular x K*^T panel, sum-of-squares epilogue)", "bound": "mfma",
                      "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "avg_launch_ms": per(gemm_key), "launches": launches, "flops_per_launch": flops_launch},
+                     "traffic": measured_traffic("config1", Np, M)[0], "traffic_note": measured_traffic("config1", Np, M)[1],
+                     "avg_launch_ms": per(gemm_key), "launches": launches, "flops_per_launch": flops_launch},
         "kernel_build": {"bound": "hbm", "achieved": kb_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": kb_gbps / HBM_PEAK_GBPS,
                          "avg_launch_ms": per("kernel_build"), "launches": T["kernel_build"][1], "bytes_per_launch": kb_bytes},
         "factor": {"bound": "mfma", "achieved": fac_flops / (fac_ms * 1e-3) / 1e12 if fac_ms else 0.0, "peak": F64_MFMA_PEAK_TFLOPS,
@@ -1084,10 +1105,7 @@ def main(argv=None):
     gemm_ms, gemm_n = T["sweep_gemm"]
     flops_launch = work["sweep_flops"] / max(gemm_n, 1)
     achieved = work["sweep_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get("sweep_gemm_hbm_bytes_per_launch")
+    traffic, traffic_note = measured_traffic("config2", Np, M_rank)
     kb_ms, kb_n = T["kernel_build"]
     kb_bytes = 8.0 * N * N + 8.0 * N * d          # every launch ran at N (checked above)
     kb_gbps = kb_bytes / (kb_ms / max(kb_n, 1) * 1e-3) / 1e9 if kb_ms else 0.0
@@ -1136,6 +1154,7 @@ def main(argv=None):
         "roofline": {"kernel": "sweep_gemm_dma_sp_kernel (V lower-triangular x K*^T panel, sum-of-squares epilogue)",
                      "bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_note": traffic_note,
                      "avg_launch_ms": gemm_ms / max(gemm_n, 1), "launches": gemm_n,
                      "flops_per_launch": flops_launch},
         "kernel_build": {"bound": "hbm", "achieved": kb_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
