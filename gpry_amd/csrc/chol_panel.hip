@@ -705,19 +705,14 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
         const double* pa = sA + (wr * 16 + r) * S64 + g;
         const double* pb = sB + (wc * 32 + r) * S64 + g;
 #pragma unroll 1
-        for (int kh = 0; kh < kd; kh += 32) {       // k ascending, 32 at a time: the 24 fragment reads of a pass are issued before
-                                                    // its first MFMA (left to itself the scheduler puts a full s_waitcnt lgkmcnt(0)
-                                                    // in front of every other MFMA, as in mfma_nt16)
-            double fa[8], fb0[8], fb1[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { fa[u] = pa[kh + 4 * u]; fb0[u] = pb[kh + 4 * u]; fb1[u] = pb[16 * S64 + kh + 4 * u]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u], fb0[u], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u], fb1[u], acc[1], 0, 0, 0);
+        for (int kh = 0; kh < kd; kh += 64) {       // k ascending, 64 at a time (one or two passes).  (All fragment reads of a pass
+                                                    // in front of its MFMAs, as in mfma_nt16: 1415 instead of 1382 us at N = 4096.)
+#pragma unroll 8
+            for (int k0 = kh; k0 < kh + 64; k0 += 4) {
+                const double a0 = pa[k0], b0 = pb[k0], b1 = pb[16 * S64 + k0];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int ni = 0; ni < 2; ni++)
