@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256) void cross_build_kernel(
 // difference form otherwise.  The exact difference form also stays for gpry_kernel_cross (K* itself is
 // compared at 1e-13), the small batches and the Kriging-believer registrations.
 // Workgroup = 128 training rows x 256 candidates as above; wave w owns candidates 64 w .. 64 w + 63 as four MFMA column
-// blocks; per 16 training rows (A operand from LDS) 4 x d/4 MFMAs give each lane 4 x 4 pairs: rows g + 4 q (g = lane >> 4),
-// candidate lane & 15 of each block, stored as 128-byte row segments.
+// blocks in two pairs; per 16 training rows (A operand from LDS) 4 x d/4 MFMAs give each lane 4 x 4 pairs: rows g + 4 q
+// (g = lane >> 4), two neighbouring candidates per block pair, stored as 16-byte pieces of 256-byte row segments.
 // Ycs: Np x DP centred scaled training rows (zero rows for the padding), row-major; Xcs: DP x ldm centred scaled candidates.
 template <int DP, int KID>
 __global__ __launch_bounds__(256) void cross_build_mfma_kernel(
@@ -343,19 +343,25 @@ __global__ __launch_bounds__(256) void cross_build_mfma_kernel(
         *reinterpret_cast<double2*>(Yl + row * S + k2) = *reinterpret_cast<const double2*>(Ycs + ((int64_t)jc * 128 + row) * DP + k2);
     }
     if (t < 128) al[t] = alpha_ ? alpha_[jc * 128 + t] : 0.0;
-    // B operands: coordinate 4 kk + g of candidate r of block tl; |x - c|^2 of that candidate
+    // B operands: coordinate 4 kk + g of the candidate of lane r in block tl; |x - c|^2 of that candidate.  The blocks come in
+    // pairs over 32 candidates: lane r holds candidate 2 r in the even block and 2 r + 1 in the odd one (one 16-byte load
+    // gives both), so that a lane ends up with the values of two NEIGHBOURING candidates for every training row and stores
+    // them as one 16-byte piece -- 256 contiguous bytes per row and instruction.  (Round 4 had candidate r / 16 + r in the
+    // blocks and 8-byte stores: the kernel ran at 3.9 TB/s of panel writes whatever its instruction count, the rate of 8-byte
+    // stores on this part -- MI355X_MICROARCH.md: 0.54-0.70 of the 16-byte rate.)
     double xb[4][KS], xn[4];
 #pragma unroll
-    for (int tl = 0; tl < 4; tl++) {
-        double s = 0.0;
+    for (int tp = 0; tp < 2; tp++) {
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) {
-            xb[tl][kk] = Xcs[(int64_t)(4 * kk + g) * ldm + mb + 16 * tl + r];
-            s = fma(xb[tl][kk], xb[tl][kk], s);
+            const double2 v = *reinterpret_cast<const double2*>(Xcs + (int64_t)(4 * kk + g) * ldm + mb + 32 * tp + 2 * r);
+            xb[2 * tp][kk] = v.x; xb[2 * tp + 1][kk] = v.y;
+            s0 = fma(v.x, v.x, s0); s1 = fma(v.y, v.y, s1);
         }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        xn[tl] = s * SC;            // (the scale of corr_scaled_fast folded into both norms and the product: u = s r^2)
+        s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        xn[2 * tp] = s0 * SC; xn[2 * tp + 1] = s1 * SC;     // (the scale of corr_scaled_fast folded into both norms and the product: u = s r^2)
     }
     __syncthreads();
     if (t < 128) {
@@ -376,20 +382,27 @@ __global__ __launch_bounds__(256) void cross_build_mfma_kernel(
 #pragma unroll
         for (int q = 0; q < 4; q++) { ynq[q] = yn[j0 + g + 4 * q]; alq[q] = al[j0 + g + 4 * q]; }
 #pragma unroll
-        for (int tl = 0; tl < 4; tl++) {
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
+        for (int tp = 0; tp < 2; tp++) {
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], xb[tl][kk], acc, 0, 0, 0);
-            const bool in_chunk = mb + 16 * tl + r < mc;
+            for (int kk = 0; kk < KS; kk++) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], xb[2 * tp][kk], acc0, 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], xb[2 * tp + 1][kk], acc1, 0, 0, 0);
+            const int64_t mloc = mb + 32 * tp + 2 * r;      // this lane's pair of candidates (mc is a multiple of 128: both or neither)
+            const bool in_chunk = mloc < mc;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int jj = j0 + g + 4 * q;
-                double u = fma(-2.0 * SC, acc[q], xn[tl] + ynq[q]);
-                u = fmax(u, 1e-290);           // (rounding may leave a small negative number; at 1e-290 the correlation is 1 exactly)
-                double v = kp.C * corr_scaled_fast<KID>(u);
-                if (jj >= nvalid) v = 0.0;
-                macc[tl] = fma(alq[q], v, macc[tl]);
-                if (in_chunk) Kst[((int64_t)jc * 128 + jj) * ldk + mb + 16 * tl + r] = v;
+                double u0 = fma(-2.0 * SC, acc0[q], xn[2 * tp] + ynq[q]);
+                double u1 = fma(-2.0 * SC, acc1[q], xn[2 * tp + 1] + ynq[q]);
+                u0 = fmax(u0, 1e-290);         // (rounding may leave a small negative number; at 1e-290 the correlation is 1 exactly)
+                u1 = fmax(u1, 1e-290);
+                double v0 = kp.C * corr_scaled_fast<KID>(u0);
+                double v1 = kp.C * corr_scaled_fast<KID>(u1);
+                if (jj >= nvalid) { v0 = 0.0; v1 = 0.0; }
+                macc[2 * tp] = fma(alq[q], v0, macc[2 * tp]);
+                macc[2 * tp + 1] = fma(alq[q], v1, macc[2 * tp + 1]);
+                if (in_chunk) *reinterpret_cast<double2*>(Kst + ((int64_t)jc * 128 + jj) * ldk + mloc) = make_double2(v0, v1);
             }
         }
     }
@@ -399,7 +412,8 @@ __global__ __launch_bounds__(256) void cross_build_mfma_kernel(
             double s = macc[tl];
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
-            if (g == 0 && mb + 16 * tl + r < mc) mean_part[(int64_t)jc * mc + mb + 16 * tl + r] = s;
+            const int64_t ml = mb + 32 * (tl >> 1) + 2 * r + (tl & 1);
+            if (g == 0 && ml < mc) mean_part[(int64_t)jc * mc + ml] = s;
         }
     }
 }
