@@ -324,7 +324,7 @@ struct PanelArgs {
     int64_t col0;           // A is the trailing submatrix from column col0 of the whole matrix on (tail of the large schedule)
     int* info; int* arrive; int target;
     int64_t bstride;        // batched launch (gpry_ctx::bn): A, info and arrive of theta blockIdx.z lie this many doubles further on
-    int flags;              // experiments (GPRY_PANEL_FLAGS): 1: the workers do not yield to their SIMD partners
+    int flags;              // experiments (GPRY_PANEL_FLAGS): 1: the workers do not yield to their SIMD partners; 16 / 32 (host): the compact / the roomy step for every launch
 };
 #define PANEL_SMEM_DOUBLES (4 * 64 * PLD + 64 + 16)
 
@@ -725,6 +725,325 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
         for (int q = 0; q < 4; q++) cbase[(int64_t)(4 * q) * ld + ni * 16] = val[ni][q];
 }
 
+// Loads of the COMPACT panel step (512 threads, below).  D and P_t (what the factor waits for) go to LDS through all eight
+// waves as in the step above (D4_*).  The workgroup's own rows never pass through LDS on their way in: worker i (wave 4 + i) takes
+// row tile i of P_o straight into the A-operand layout of the MFMA (lane (r, g): P_o[16 i + r][4 u + g], u = 0..15) and row
+// tile i of B into the accumulator layout of its four column tiles (lane (r, g): B[16 i + g + 4 q][16 c + r]) -- named
+// registers, not arrays: arrays that live across other work were left in scratch memory by the compiler.
+#define U16_FOR(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define PO_DECL(u) double po##u = 0.0;
+#define PO_LOAD(u) po##u = gPo_[4 * u];
+#define PT_DECL(u) double pt##u;
+#define PT_READ(u) pt##u = ptc_[4 * u];
+#define U_MFMA(u) acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(-po##u, pt##u, acc_, 0, 0, 0);
+#define PANEL_COMPACT_SMEM_DOUBLES (2 * 64 * PLD + 64 + 16)
+
+// THE COMPACT FORM of the panel step (batched evaluations; the single evaluation keeps panel_step_body above).  One panel step
+// for the 64-row block `bx` of the panel: the strip before its own (columns [K0, j0), 64 of them) is applied
+// first (left-looking), then the 64 x 64 factor and the row solves.  Workgroups of EIGHT waves: 0..3 are the factor chain
+// (wave w owns block row w of D), 4..7 are workers (worker i owns row tile i of the workgroup's own rows).  68 KB of LDS.
+//
+// Round 5: what does not feed the factor is off the chain, and the step no longer needs a CU to itself.  Until round 4
+// every workgroup (four waves, 135 KB of LDS) loaded its four 64 x 64 blocks, applied the previous strip to D AND to its own
+// rows (5.9k cycles), factored D (21k), solved its rows (3k) and stored: 38k cycles per step plus the launch, one after the other.
+// Now
+//   * only D and the previous strip's rows of the diagonal block (P_t) go to LDS and are waited for before the factor starts;
+//   * wave w of the chain applies the previous strip to ITS block row of D (w + 1 tiles; wave 0 starts the 16 x 16 factor
+//     chain behind one);
+//   * the workgroup's own rows B and P_o stay in the registers of the workers in MFMA operand layout: worker i applies the
+//     previous strip to its row tile (64 MFMAs, A operand from registers, B operand = P_t from LDS) beside the factor, and
+//     writes the result to LDS only when nobody reads P_t any more -- INTO the space of P_t.  Two blocks of LDS instead of
+//     four: a panel workgroup fits beside a GEMM workgroup of another stream on the same CU (or beside a second panel
+//     workgroup), so that work overlapped with the chain no longer starves it of whole CUs;
+//   * what then remains for the own rows -- the updates with the columns solved so far (M) and the four 16-wide solves (T),
+//     16 tasks in dependency order -- is pulled from an LDS counter by the workers and by the chain waves once their block
+//     row is factored; only the last solve is left behind the factor.
+// Every tile sees the same operations in the same order as before (who computes it, from where and when is all that changed; an
+// MFMA chain cut at a multiple of 4 k and resumed from the stored tile is the same chain): factors bit-identical to round 4's.
+__device__ __forceinline__ void panel_step_compact(const PanelArgs& pa, double* smem, const int bx, const int tb) {
+    double* __restrict__ A = bset(pa.A, tb, pa.bstride);
+    const int64_t ld = pa.ld, j0 = pa.j0, K0 = pa.K0, n_real = pa.n_real;
+    int* info = bset(pa.info, tb, pa.bstride); int* arrive = bset(pa.arrive, tb, pa.bstride); const int target = pa.target;
+    double* sD = smem;
+    double* sPt = sD + 64 * PLD;
+    double* sB = sPt;               // the own rows, with the previous strip applied, once P_t is dead (s_ptdone)
+    double* sRd = sPt + 64 * PLD;
+    int* s_int = reinterpret_cast<int*>(sRd + 64);
+    int& s_bad = s_int[0];
+    int* s_abort = s_int + 1;
+    int* s_flag = s_int + 2;        // [0]: 16 x 16 blocks factored, [1 + w]: columns solved by wave w, [5]: own-row column blocks solved
+    int* s_ptdone = s_int + 10;     // waves that will not read P_t again (8: the space becomes B)
+    int* s_task = s_int + 11;       // next own-row task x 64 (every lane of a pulling wave adds one)
+    int* s_bdone = s_int + 12;      // workers that have written their row tile of B to LDS
+    int* s_mdone = s_int + 16;      // [c]: tiles of column block c that have the solved columns applied
+    if (*info != 0) return;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar: the wave's role decides its control flow)
+    const bool is_diag = bx == 0, worker = w >= 4;
+    const int row = w & 3;          // chain waves: the block row of D they own; workers: the row tile of the own rows
+    const int64_t R = j0 + 64 * (int64_t)bx;
+    const bool has_prev = j0 > K0;                 // false for the first strip of a segment
+    const int r = lane & 15, g = lane >> 4;
+#ifdef GPRY_PANEL_STAMPS
+    const int stamp_step = (int)((pa.col0 + j0) / 64) < STAMP_STEPS ? (int)((pa.col0 + j0) / 64) : STAMP_STEPS - 1;
+    const int stamp_wg = (tb == 0) ? (bx == 0 ? 0 : bx == 1 ? 1 : bx == 8 ? 2 : -1) : -1;
+#endif
+    PANEL_STAMP(0);
+    if (t < 32) s_int[t] = 0;
+    if (pa.flags & 2) { if (worker) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3); }   // experiment: panel waves above the tile waves they share a CU with
+    D4_FOR(D4_DECL)
+    {
+        const double* __restrict__ gD_ = A + j0 * ld + j0;
+        const double* __restrict__ gPt_ = A + j0 * ld + K0;
+        D4_FOR(D4_LOAD)
+    }
+    // (what the factor waits for goes out first: loads return in order, and the scheduler had put the own-row loads in front)
+    __builtin_amdgcn_sched_barrier(0);
+    U16_FOR(PO_DECL)
+    v4d bt0 = {0.0, 0.0, 0.0, 0.0}, bt1 = bt0, bt2 = bt0, bt3 = bt0;
+    if (worker && !is_diag) {
+        const double* __restrict__ gPo_ = A + (R + 16 * row + r) * ld + K0 + g;
+        if (has_prev) { U16_FOR(PO_LOAD) }
+        const double* __restrict__ gB_ = A + (R + 16 * row + g) * ld + j0 + r;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bt0[q] = gB_[(int64_t)(4 * q) * ld]; bt1[q] = gB_[(int64_t)(4 * q) * ld + 16];
+            bt2[q] = gB_[(int64_t)(4 * q) * ld + 32]; bt3[q] = gB_[(int64_t)(4 * q) * ld + 48];
+        }
+    }
+    D4_FOR(D4_COMMIT)
+    __syncthreads();
+    if (t == 256) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (a worker: wave 0 starts the chain)
+    PANEL_STAMP(1);
+    PANEL_PROGRESS(1);
+    if (!worker) {
+        // ---- the previous strip onto block row `row` of D (only the tiles on and below the diagonal are ever read)
+        if (has_prev) {
+#pragma unroll 1
+            for (int n = 0; n <= row; n++) {
+                double* T = sD + (row * 16) * PLD + n * 16;
+                v4d acc = tile_load(T, lane);
+                acc = mfma_nt16<true>(acc, sPt + (row * 16) * PLD, sPt + (n * 16) * PLD, 64, lane);
+                tile_store(T, acc, lane);
+            }
+            wave_fence();
+        }
+        lds_count(s_ptdone, lane);
+        PANEL_STAMP(2);
+        PANEL_PROGRESS(2);
+        // ---- Cholesky of the 64x64 diagonal block, blocked by 16, as a dataflow between the four chain waves
+        // (wave w owns block row w = `row`) instead of three workgroup barriers per block column:
+        //   for cb < w:  wait chol(cb);  T(w,cb): D[w][cb] <- D[w][cb] L[cb][cb]^-T;  publish;
+        //                for cc in cb+1..w: (cc < w: wait T(cc,cb))  D[w][cc] -= D[w][cb] D[cc][cb]^T
+        //   chol(w); publish.
+        // Wave cb+1 starts chol(cb+1) as soon as ITS row is done, while the rows below still work on block
+        // column cb: the chain is 4 chol16 + 3 (solve + one tile update).
+        // Flags are LDS words written by lane 0 after a wave fence (LDS requests of a wave retire in order).
+        for (int cb = 0; cb < row; cb++) {
+            PANEL_PROGRESS(10 + cb);
+            lds_wait_ge(&s_flag[0], cb + 1, s_abort, 1);
+            PANEL_PROGRESS(14 + cb);
+            trsm16_rows(sD + (row * 16) * PLD + cb * 16, sD + (cb * 16) * PLD + cb * 16, sRd + cb * 16, lane);
+            wave_fence();
+            lds_publish(&s_flag[1 + row], cb + 1, lane);
+            for (int cc = cb + 1; cc <= row; cc++) {
+                if (cc < row) lds_wait_ge(&s_flag[1 + cc], cb + 1, s_abort, 2);
+                double* T = sD + (row * 16) * PLD + cc * 16;
+                v4d acc = tile_load(T, lane);
+                acc = mfma_nt16<true>(acc, sD + (row * 16) * PLD + cb * 16, sD + (cc * 16) * PLD + cb * 16, 16, lane);
+                tile_store(T, acc, lane);
+            }
+            wave_fence();
+        }
+        // a failed pivot (not positive definite) still publishes: nobody may wait forever; the first
+        // failing column wins (the chol16 calls are ordered by the chain itself)
+        PANEL_PROGRESS(20);
+        const int bad = chol16_wave(sD + (row * 16) * PLD + row * 16, sRd + row * 16, lane);
+        PANEL_PROGRESS(21);
+        if (bad && lane == 0 && s_bad == 0) s_bad = row * 16 + bad;
+        wave_fence();
+        lds_publish(&s_flag[0], row + 1, lane);
+    } else if (!is_diag) {
+        // ---- worker `row`: the previous strip onto row tile `row` of the own rows, B(row, c) -= P_o(row) P_t(c)^T for the four
+        // column tiles: 16 MFMAs each, k ascending, A operand from registers, B operand from LDS -- the chain of round 4's
+        // U tiles.  (The partner of wave 0 waits for the first 16 x 16 factor: FP64 MFMAs of one wave of a SIMD hold up the
+        // FP64 vector instructions of the other.)
+        if (has_prev) {
+            if (w == 4 && !(pa.flags & 1)) lds_wait_ge(&s_flag[0], 1, s_abort, 12);
+#define U_TILE(c, BT) { const double* ptc_ = sPt + ((c) * 16 + r) * PLD + g; U16_FOR(PT_DECL) U16_FOR(PT_READ)               \
+                        __builtin_amdgcn_sched_barrier(0); v4d acc_ = BT; U16_FOR(U_MFMA) BT = acc_; __builtin_amdgcn_sched_barrier(0); }
+            U_TILE(0, bt0) U_TILE(1, bt1) U_TILE(2, bt2) U_TILE(3, bt3)
+#undef U_TILE
+            wave_fence();
+        }
+        lds_count(s_ptdone, lane);
+        PANEL_STAMP(2);
+        lds_wait_ge(s_ptdone, 8, s_abort, 13);          // nobody reads P_t any more: its space takes the updated own rows
+        tile_store(sB + (row * 16) * PLD, bt0, lane);
+        tile_store(sB + (row * 16) * PLD + 16, bt1, lane);
+        tile_store(sB + (row * 16) * PLD + 32, bt2, lane);
+        tile_store(sB + (row * 16) * PLD + 48, bt3, lane);
+        wave_fence();
+        lds_count(s_bdone, lane);
+    }
+    PANEL_STAMP(3);
+    PANEL_PROGRESS(22);
+    if (!is_diag) {
+        // ---- the workgroup's own rows: X = B' Lkk^-T (B' = B - P_o P_t^T, above), 16 columns at a time.  Tasks in dependency
+        // order, column block c:  M(rt, c), rt = 0..3 (c > 0): the solved columns onto tile (rt, c)  [the solves < c, row c of the factor]
+        //                         T(c): the 16-wide solve of all 64 rows, one row per lane           [M(., c), chol(c)]
+        // pulled from s_task by whichever wave is free.  A wave that waits for a dependency waits for a task pulled earlier
+        // or for the factor chain, which waits for none of this: no deadlock.
+        lds_wait_ge(s_bdone, 4, s_abort, 3);
+        PANEL_ACC_DECL
+        for (;;) {
+            if (worker && !(pa.flags & 1)) worker_yield(&s_flag[0], w, s_abort);
+            // every lane adds one (the compiler folds that into ONE ds_add of 64 and a per-lane offset): no value flows out
+            // of an `if (lane == 0)` -- with the pull under such a branch the loop was compiled into a nest of exec-masked
+            // loops that re-ran a pulled task without pulling the next one
+            const int task = __builtin_amdgcn_readfirstlane(
+                __hip_atomic_fetch_add(s_task, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 6;
+            PANEL_PROGRESS(100 + task);
+            if (task >= 16) break;
+            // task 0: T(0); column block c > 0: 1 + 5 (c - 1) .. (4 M, T)
+            const int c = task < 1 ? 0 : 1 + (task - 1) / 5;
+            const int k = task < 1 ? 4 : (task - 1) % 5;
+            PANEL_ACC_BEGIN;
+            if (k < 4) {                                    // M(k, c)
+                const int rt = k;
+                lds_wait_ge(&s_flag[5], c, s_abort, 5);                // X[:, 0 .. 16 c) final
+                lds_wait_ge(&s_flag[1 + c], c, s_abort, 6);            // L[c][0 .. c) final
+                double* T = sB + (rt * 16) * PLD + c * 16;
+                v4d acc = tile_load(T, lane);
+                acc = mfma_nt16<true>(acc, sB + (rt * 16) * PLD, sD + (c * 16) * PLD, c * 16, lane);
+                tile_store(T, acc, lane);
+                wave_fence();
+                lds_count(&s_mdone[c], lane);
+                PANEL_ACC_END(1);
+            } else {                                        // T(c)
+                if (c > 0) lds_wait_ge(&s_mdone[c], 4, s_abort, 7);
+                lds_wait_ge(&s_flag[0], c + 1, s_abort, 9);
+                trsm16_rows<64>(sB + c * 16, sD + (c * 16) * PLD + c * 16, sRd + c * 16, lane);
+                wave_fence();
+                lds_publish(&s_flag[5], c + 1, lane);
+                PANEL_ACC_END(2);
+            }
+        }
+        PANEL_ACC_FLUSH;
+    }
+    PANEL_STAMP(4);
+    PANEL_PROGRESS(40);
+    __syncthreads();
+    PANEL_STAMP(5);
+    PANEL_PROGRESS(41);
+    if (*s_abort != 0) {            // a bounded wait ran out (never seen; kept so that a protocol error cannot hang the GPU)
+        if (t == 0) { atomicCAS(info, 0, (int)(pa.col0 + j0 + 1 <= n_real ? pa.col0 + j0 + 1 : n_real)); info[3] = 0x5A00 + *s_abort; }
+        return;
+    }
+    if (s_bad) {
+        if (is_diag && t == 0) {
+            int64_t col = pa.col0 + j0 + s_bad;             // 1-based failing column of the whole matrix
+            atomicCAS(info, 0, (int)(col <= n_real ? col : n_real));
+        }
+        return;
+    }
+    if (is_diag) {
+        if (t == 0) {
+            int n = 0;
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++n > PANEL_SPIN_CAP) { atomicCAS(info, 0, (int)(pa.col0 + j0 + 1 <= n_real ? pa.col0 + j0 + 1 : n_real)); info[3] = 0x5AFF; break; }
+            }
+        }
+        __syncthreads();
+        store_block(A + j0 * ld + j0, ld, sD, t, true);
+        PANEL_STAMP(6);
+        PANEL_PROGRESS(60);
+        return;
+    }
+    store_block(A + R * ld + j0, ld, sB, t, false);
+    PANEL_STAMP(6);
+    PANEL_PROGRESS(61);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same tile for the compact launches, 64 k at a time: the operand images
+// (64 rows x 64 k each, row stride 66 doubles: conflict-free fragment reads) take 68 KB of LDS, so TWO tile workgroups share a
+// CU and one's LDS-DMA runs under the other's MFMAs (until round 4 both operands of all 128 k sat in LDS at once, 133 KB: one
+// workgroup per CU, which waited for its own DMA).  The eight waves own a 16 x 32 piece each (1 x 2 MFMA tiles).  Per element
+// the same MFMA sequence from a zero accumulator (k ascending over both halves) and the same single rounding of C - acc as the
+// 128 x 128 SYRK tile of the separate trailing launches: bit-identical.
+#define S64C 66
+__device__ __forceinline__ void syrk64_tile_compact(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
+                                                 const int* info) {
+    if (*info != 0) return;
+    double* sA = smem;
+    double* sB = smem + 64 * S64C;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const bool diag = it.a_off == it.b_off;
+    const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
+    // C/D fragment: row = g + 4q, col = r.  The 8 old values of this lane stay in registers over the visit.
+    double* cbase = A + it.c_off + (int64_t)(wr * 16 + g) * ld + wc * 32 + r;
+    double val[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) val[ni][q] = cbase[(int64_t)(4 * q) * ld + ni * 16];
+    if (diag) sB = sA;
+    const double* pa = sA + (wr * 16 + r) * S64C + g;
+    const double* pb = sB + (wc * 32 + r) * S64C + g;
+    // A lagging tile takes several pending panels in one visit: each one accumulated from zero and subtracted
+    // with one rounding, in order -- the values a store / reload between them would give.
+    const int nvisit = (int)it.n + (it.half ? 1 : 0);
+    bool first = true;
+#pragma unroll 1
+    for (int u = 0; u < nvisit; u++) {
+        const bool half = u >= (int)it.n;       // the last visit of a tile with `half`: 64 k instead of 128
+        const double* Ag = half ? A + it.ha_off : A + it.a_off + (int64_t)u * 128;
+        const double* Bg = half ? A + it.hb_off : A + it.b_off + (int64_t)u * 128;
+        const int kd = half ? 64 : 128;
+        v4d acc[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) acc[ni] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int kc = 0; kc < kd; kc += 64) {       // k ascending, 64 at a time
+            if (!first) __syncthreads();        // everybody has read the previous images
+            first = false;
+            // LDS-DMA: the lower half of a wave moves one 512-byte row (64 k) of an operand straight into its padded LDS row;
+            // the 8 (+8) rows of a wave are in flight at once
+            if (lane < 32) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int rw = w * 8 + i;
+                    gd_dma16(Ag + (int64_t)rw * ld + kc + 2 * lane, sA + rw * S64C);
+                }
+                if (!diag) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int rw = w * 8 + i;
+                        gd_dma16(Bg + (int64_t)rw * ld + kc + 2 * lane, sB + rw * S64C);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll 8
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const double a0 = pa[k0], b0 = pb[k0], b1 = pb[16 * S64C + k0];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) val[ni][q] = val[ni][q] - acc[ni][q];
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) cbase[(int64_t)(4 * q) * ld + ni * 16] = val[ni][q];
+}
+
 // Fused step: the first P workgroups are the panel step, the others each take one 64 x 64 tile of an
 // EARLIER panel's trailing update.  The panel chain is one workgroup's latency and leaves most of the GPU
 // idle; the tiles fill it.  In-order launches on one stream: no cross-stream events, and a panel workgroup
@@ -737,6 +1056,18 @@ __global__ __launch_bounds__(512) void chol_fused_kernel(PanelArgs pa, const Til
         panel_step_body(pa, smem, bx, tb);
     } else {
         syrk64_tile_body(bset(pa.A, tb, pa.bstride), pa.ld, items[bx - P], smem, bset(pa.info, tb, pa.bstride));
+    }
+}
+
+// The compact form of the same launch (batched evaluations): 68 KB of LDS and 110 VGPRs, two workgroups per CU.
+__global__ __launch_bounds__(512) void chol_fused_compact_kernel(PanelArgs pa, const TileItem* __restrict__ items, int P) {
+    __shared__ __attribute__((aligned(16))) double smem[PANEL_COMPACT_SMEM_DOUBLES];
+    const int bx = (int)blockIdx.x;
+    const int tb = (int)blockIdx.z;             // theta of a batched launch (gpry_ctx::bn)
+    if (bx < P) {
+        panel_step_compact(pa, smem, bx, tb);
+    } else {
+        syrk64_tile_compact(bset(pa.A, tb, pa.bstride), pa.ld, items[bx - P], smem, bset(pa.info, tb, pa.bstride));
     }
 }
 
@@ -775,7 +1106,18 @@ static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, in
     cs.arrivals += P;
     static const int panel_flags = getenv("GPRY_PANEL_FLAGS") ? atoi(getenv("GPRY_PANEL_FLAGS")) : 0;
     PanelArgs pa = {A, ld, j0, Kfrom, ctx->N, col0, ctx->dinfo, ctx->dinfo + 2, cs.arrivals, ctx->bstride, panel_flags};
-    hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + n_items), 1, (unsigned)ctx->bn), dim3(512), 0, ctx->stream, pa, items, P);
+    // Two forms of the step, the same operations on every tile in the same order (bit-identical factors; every theta of a
+    // batch is compared with a single evaluation in tests/test_lml_batch_gpu.py).  A single evaluation takes the one whose
+    // workgroups have a CU to themselves (135 KB of LDS): beside a second workgroup -- riding tiles of the same launch, GEMMs
+    // of the side stream -- the FP64 vector instructions of the chain queue behind the other's FP64 MFMAs (the compact form
+    // alone: potrf + 1-2 %, the pipelined chain + 4 %).  A batched evaluation (thetas x panel rows workgroups per step)
+    // takes the compact one, two workgroups per CU: 32 thetas at N = 1024 1.99 -> 1.86 ms, N = 2048 10.35 -> 9.72 ms
+    // (profiles/r05_potrf.md).  GPRY_PANEL_FLAGS bit 4 / bit 5: the compact / the roomy form for everything (experiments).
+    const bool compact = (panel_flags & 16) ? true : (panel_flags & 32) ? false : ctx->bn > 1;
+    if (compact)
+        hipLaunchKernelGGL(chol_fused_compact_kernel, dim3((unsigned)(P + n_items), 1, (unsigned)ctx->bn), dim3(512), 0, ctx->stream, pa, items, P);
+    else
+        hipLaunchKernelGGL(chol_fused_kernel, dim3((unsigned)(P + n_items), 1, (unsigned)ctx->bn), dim3(512), 0, ctx->stream, pa, items, P);
     return trtri_pipeline_step(ctx, (int)((col0 + j0) / 64) + 1);
 }
 
