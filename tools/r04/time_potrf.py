@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from gpry_amd import _lib
 dev = _lib.Device(0)
 dev.set_option("factor_pipeline", 0)
+for kv in filter(None, os.environ.get("GPRY_SET", "").split(",")):       # e.g. GPRY_SET=chol_lookahead=0
+    dev.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 out = []
 for N in [int(a) for a in (sys.argv[1:] or ["512", "1024", "2048", "4096", "6144", "7168"])]:
     d = 8 if N < 4096 else 16
