@@ -1062,12 +1062,20 @@ __global__ __launch_bounds__(512) void chol_fused_kernel(PanelArgs pa, const Til
 // The compact form of the same launch (batched evaluations): 68 KB of LDS and 110 VGPRs, two workgroups per CU.
 __global__ __launch_bounds__(512) void chol_fused_compact_kernel(PanelArgs pa, const TileItem* __restrict__ items, int P) {
     __shared__ __attribute__((aligned(16))) double smem[PANEL_COMPACT_SMEM_DOUBLES];
-    const int bx = (int)blockIdx.x;
-    const int tb = (int)blockIdx.z;             // theta of a batched launch (gpry_ctx::bn)
-    if (bx < P) {
-        panel_step_compact(pa, smem, bx, tb);
+    // Workgroups are dispatched in the order of their index, x first, then z.  With the thetas in z the panel workgroups of the last
+    // thetas came behind all tiles of the thetas before them -- six rounds of the GPU's workgroup slots in a step of 32 thetas with
+    // 81 tiles each -- and a launch lasted its tiles PLUS one panel latency (32 thetas at N = 1024: 24 + 1.05 us per tile and theta,
+    // tools/r05/gpu_trace_batch.sh).  The index is therefore taken apart again: first the panel workgroups of all thetas (one
+    // workgroup's latency each, and everything else waits for them), then the tiles, item by item for all thetas (the plan has
+    // the longest visits first).  32 thetas: 1.88 -> 1.80 ms at N = 1024, 6.04 -> 5.83 at 1600, 9.78 -> 9.45 at 2048.
+    const int bn = (int)gridDim.z;
+    const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.z;
+    if (lin < P * bn) {
+        const int tb = lin / P;                 // theta of a batched launch (gpry_ctx::bn)
+        panel_step_compact(pa, smem, lin - tb * P, tb);
     } else {
-        syrk64_tile_compact(bset(pa.A, tb, pa.bstride), pa.ld, items[bx - P], smem, bset(pa.info, tb, pa.bstride));
+        const int k = lin - P * bn, ii = k / bn, tb = k - ii * bn;
+        syrk64_tile_compact(bset(pa.A, tb, pa.bstride), pa.ld, items[ii], smem, bset(pa.info, tb, pa.bstride));
     }
 }
 

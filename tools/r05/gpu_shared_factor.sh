@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 5: the 64 x 64 factor of a batched panel step shared between the workgroups of a theta -- sanity, bit-identity, A / B
+mkdir -p gpurun_out/r05
+timeout 120 python3 tools/r04/prof_lml_batch.py 256 4 4 2 2>&1 | tail -2 | tee gpurun_out/r05/sf_sanity.log
+grep -q "ms per call" gpurun_out/r05/sf_sanity.log || { echo "sanity run failed: stopping"; exit 1; }
+timeout 900 python -m pytest tests/test_lml_batch_gpu.py -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/r05/sf_tests.log
+for fl in 0 128; do
+  for shape in "1024 8 32" "1024 8 64" "1600 8 32" "2048 16 32" "400 6 22"; do
+    echo "flags=$fl: $(GPRY_PANEL_FLAGS=$fl timeout 300 python3 tools/r04/prof_lml_batch.py $shape 10 2>&1 | tail -1)" | tee -a gpurun_out/r05/sf_ab.log
+  done
+done
