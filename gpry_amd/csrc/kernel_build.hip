@@ -639,59 +639,95 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
     double g[DP + 1];
 #pragma unroll
     for (int k = 0; k <= DP; k++) g[k] = 0.0;
-#pragma unroll 1
-    for (int a = 0; a < 4; a++) {
-        const int il = ty * 4 + a;
-        const int64_t i = (int64_t)bi * 64 + il;
-        double r2[4] = {0.0, 0.0, 0.0, 0.0};
-        // The column coordinates do not depend on `a`: the offset is laundered per iteration so that the
-        // compiler does not keep 4 DP of them in registers across this loop (with the second pass below:
-        // 256 VGPRs + AGPRs at DP >= 16, one wave per SIMD, where the FP64 vector pipe runs at a third of
-        // its rate).
-        int cj = tx * 4;
-        asm volatile("" : "+v"(cj));
+    // A thread owns 4 x 4 pairs: rows ty * 4 + a of the i block, rows tx * 4 + b of the j block.  Round 5: the coordinate loop is
+    // the OUTER one -- per coordinate four 16-byte LDS reads feed all sixteen pairs (until then each of the four a re-read its
+    // coordinate and all four of the j side: twelve reads per coordinate, the kernel waited for LDS at a third of the FP64
+    // vector rate: 79 us at N = 4096).  Every sum runs in the order it had: r2 over k ascending, g[0] and g[1 + k] over
+    // (a, b) with a outer -- the same bits.
+    double r2[4][4];
 #pragma unroll
-        for (int k = 0; k < DP; k++) {
-            double xi = Xi[k * 64 + il];
-            const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + cj);
-            double2 j0 = pj[0], j1 = pj[1];
-            double xj[4] = {j0.x, j0.y, j1.x, j1.y};
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) { double df = xi - xj[b]; r2[b] = fma(df, df, r2[b]); }
-            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // no more than 4 coordinates' loads in flight
+        for (int b = 0; b < 4; b++) r2[a][b] = 0.0;
+    int ci = ty * 4, cj = tx * 4;
+    // K^-1 of the sixteen pairs, on its way while the distances are summed (Kinv holds the lower triangle; off the diagonal
+    // blocks a thread's four columns are 32 contiguous, aligned bytes of one row)
+    double kin[4][4];
+    if (bi != bj) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const double2* pk = reinterpret_cast<const double2*>(Kinv + ((int64_t)bi * 64 + ci + a) * ld + (int64_t)bj * 64 + cj);
+            const double2 k0 = pk[0], k1 = pk[1];
+            kin[a][0] = k0.x; kin[a][1] = k0.y; kin[a][2] = k1.x; kin[a][3] = k1.y;
         }
-        double wh[4];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int64_t i = (int64_t)bi * 64 + ci + a, j = (int64_t)bj * 64 + cj + b;
+                kin[a][b] = Kinv[(i > j ? i : j) * ld + (i > j ? j : i)];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < DP; k++) {
+        // (two coordinates' reads in flight: the offsets are laundered per pair of coordinates and the scheduler is fenced
+        // behind it -- left alone, the compiler issues all 4 DP reads of a pass first and spills them, 64 DP bytes per lane)
+        if ((k & 1) == 0) asm volatile("" : "+v"(ci), "+v"(cj));
+        const double2* pi = reinterpret_cast<const double2*>(Xi + k * 64 + ci);
+        const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + cj);
+        const double2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
+        const double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) { const double df = xi[a] - xj[b]; r2[a][b] = fma(df, df, r2[a][b]); }
+        if (k & 1) {
+            // (... and the sums pass through an empty asm: the multiply-adds of this pair of coordinates stay in front of it --
+            // pure arithmetic is otherwise placed behind ALL reads of the unrolled loop)
+            asm volatile("" : "+v"(r2[0][0]), "+v"(r2[0][1]), "+v"(r2[0][2]), "+v"(r2[0][3]), "+v"(r2[1][0]), "+v"(r2[1][1]), "+v"(r2[1][2]), "+v"(r2[1][3]),
+                              "+v"(r2[2][0]), "+v"(r2[2][1]), "+v"(r2[2][2]), "+v"(r2[2][3]), "+v"(r2[3][0]), "+v"(r2[3][1]), "+v"(r2[3][2]), "+v"(r2[3][3]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // r2 becomes w C h (what the second pass weighs the squared differences with)
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int il = ci + a;
+        const int64_t i = (int64_t)bi * 64 + il;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int jl = tx * 4 + b;
+            const int jl = cj + b;
             const int64_t j = (int64_t)bj * 64 + jl;
-            // branch-free (the buffers are padded to Np, padding rows are zero): behind a branch the
-            // distance arithmetic sinks into it and every coordinate read above stays live until here
-            const int64_t hi = i > j ? i : j, lo = i > j ? j : i;
-            double w = ai[il] * aj[jl] - Kinv[hi * ld + lo];
+            double w = ai[il] * aj[jl] - kin[a][b];          // (the buffers are padded to Np, padding rows are zero)
             double kv;
-            const double h = corr_and_h<KID>(r2[b], &kv);
+            const double h = corr_and_h<KID>(r2[a][b], &kv);
             if (i == j) kv = 1.0;
             if (i >= kp.N || j >= kp.N) w = 0.0;
             g[0] = fma(w, kp.C * kv, g[0]);
-            wh[b] = w * kp.C * h;
+            r2[a][b] = w * kp.C * h;
         }
-        // second pass over the coordinates: laundered again, or the values of the first pass (5 DP
-        // doubles) stay live across the kernel evaluation to be reused here
-        int ci = il;
-        asm volatile("" : "+v"(cj), "+v"(ci));
+        __builtin_amdgcn_sched_barrier(0);      // four kernel evaluations in flight, not sixteen (their temporaries: 256 VGPRs)
+    }
+    // (the offsets are laundered: otherwise the 8 DP coordinates of the first pass stay live across the kernel evaluations to be
+    // reused here -- 256 VGPRs, one wave per SIMD)
+    asm volatile("" : "+v"(ci), "+v"(cj));
 #pragma unroll
-        for (int k = 0; k < DP; k++) {
-            double xi = Xi[k * 64 + ci];
-            const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + cj);
-            double2 j0 = pj[0], j1 = pj[1];
-            double xj[4] = {j0.x, j0.y, j1.x, j1.y};
+    for (int k = 0; k < DP; k++) {
+        // (two coordinates' reads in flight: the offsets are laundered per pair of coordinates and the scheduler is fenced
+        // behind it -- left alone, the compiler issues all 4 DP reads of a pass first and spills them, 64 DP bytes per lane)
+        if ((k & 1) == 0) asm volatile("" : "+v"(ci), "+v"(cj));
+        const double2* pi = reinterpret_cast<const double2*>(Xi + k * 64 + ci);
+        const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + cj);
+        const double2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
+        const double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                double df = xi - xj[b];
-                g[1 + k] = fma(wh[b], df * df, g[1 + k]);
-            }
-            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) { const double df = xi[a] - xj[b]; g[1 + k] = fma(r2[a][b], df * df, g[1 + k]); }
+        if (k & 1) {
+            asm volatile("" : "+v"(g[k]), "+v"(g[1 + k]));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     const int lane = t & 63, wave = t >> 6;
