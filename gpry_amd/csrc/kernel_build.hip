@@ -619,8 +619,12 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
     const double* __restrict__ alpha = bset(alpha_, (int)blockIdx.z, bstride);
     double* __restrict__ part = bset(part_, (int)blockIdx.z, bstride);
     if (bpar) kp.C = bset(bpar, (int)blockIdx.z, bstride)[0];
-    __shared__ __attribute__((aligned(16))) double Xi[DP * 64];
-    __shared__ __attribute__((aligned(16))) double Xj[DP * 64];
+    // coordinates of the 64 rows and the 64 columns, [k][row] with a row stride of 66 doubles: with 64 the sixteen k of a row --
+    // neighbouring lanes of the staging loop -- fell into ONE pair of LDS banks (a 16-way conflict on every write, in a prologue
+    // that all resident workgroups run at the same time); 66 spreads them over 32 banks and keeps the 16-byte reads aligned
+    constexpr int XLD = 66;
+    __shared__ __attribute__((aligned(16))) double Xi[DP * XLD];
+    __shared__ __attribute__((aligned(16))) double Xj[DP * XLD];
     __shared__ double ai[64], aj[64];
     __shared__ double red[4][DP + 1];
     int bi, bj; tri_decode(blockIdx.x, &bi, &bj);
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
             vi = Xs[((int64_t)bi * 64 + row) * kp.dpad + k];
             vj = Xs[((int64_t)bj * 64 + row) * kp.dpad + k];
         }
-        Xi[k * 64 + row] = vi; Xj[k * 64 + row] = vj;
+        Xi[k * XLD + row] = vi; Xj[k * XLD + row] = vj;
     }
     if (t < 64) { ai[t] = alpha[bi * 64 + t]; aj[t] = alpha[bj * 64 + t]; }
     __syncthreads();
@@ -674,8 +678,8 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
         // (two coordinates' reads in flight: the offsets are laundered per pair of coordinates and the scheduler is fenced
         // behind it -- left alone, the compiler issues all 4 DP reads of a pass first and spills them, 64 DP bytes per lane)
         if ((k & 1) == 0) asm volatile("" : "+v"(ci), "+v"(cj));
-        const double2* pi = reinterpret_cast<const double2*>(Xi + k * 64 + ci);
-        const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + cj);
+        const double2* pi = reinterpret_cast<const double2*>(Xi + k * XLD + ci);
+        const double2* pj = reinterpret_cast<const double2*>(Xj + k * XLD + cj);
         const double2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
         const double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
@@ -717,8 +721,8 @@ __global__ __launch_bounds__(256) void lml_traces_kernel(
         // (two coordinates' reads in flight: the offsets are laundered per pair of coordinates and the scheduler is fenced
         // behind it -- left alone, the compiler issues all 4 DP reads of a pass first and spills them, 64 DP bytes per lane)
         if ((k & 1) == 0) asm volatile("" : "+v"(ci), "+v"(cj));
-        const double2* pi = reinterpret_cast<const double2*>(Xi + k * 64 + ci);
-        const double2* pj = reinterpret_cast<const double2*>(Xj + k * 64 + cj);
+        const double2* pi = reinterpret_cast<const double2*>(Xi + k * XLD + ci);
+        const double2* pj = reinterpret_cast<const double2*>(Xj + k * XLD + cj);
         const double2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
         const double xi[4] = {i0.x, i0.y, i1.x, i1.y}, xj[4] = {j0.x, j0.y, j1.x, j1.y};
 #pragma unroll
