@@ -12,6 +12,7 @@
 #define TS_NP 128
 #define TS_LD 130
 #define TS_NB 8
+#define TS_CLEAR 8      // workgroups that clear the rows of a block right of it (clear_right)
 
 __global__ __launch_bounds__(512) void trtri_diag128_kernel(const double* __restrict__ L_, double* __restrict__ V_,
                                                             int64_t ld, const int* info, int clear_right, int64_t bstride) {
@@ -21,15 +22,22 @@ __global__ __launch_bounds__(512) void trtri_diag128_kernel(const double* __rest
     const double* __restrict__ L = bset(L_, tb, bstride);
     double* __restrict__ V = bset(V_, tb, bstride);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int64_t b0 = (int64_t)blockIdx.x * TS_NP;
-    if (clear_right) {      // rows of this block, columns right of it: stands in for a memset of V (ld = the matrix dimension)
-        const int64_t ncol2 = (ld - (b0 + TS_NP)) >> 1;
+    const int nblk = (int)(ld / TS_NP);
+    if ((int)blockIdx.x >= nblk) {
+        // The rows of a block, columns right of it: stands in for a memset of V (ld = the matrix dimension).  Workgroups of
+        // their own, sixteen rows each, beside the ones that invert (until round 5 the inverting workgroup cleared its 128 rows
+        // first: 0.9 MB through ONE workgroup at N = 1024 -- 25 of the launch's 37 us on the critical path of every evaluation).
+        const int id = (int)blockIdx.x - nblk, b = id / TS_CLEAR, sl = id - b * TS_CLEAR;
+        const int64_t c0 = (int64_t)(b + 1) * TS_NP, r0 = (int64_t)b * TS_NP + sl * (TS_NP / TS_CLEAR);
+        const int64_t ncol2 = (ld - c0) >> 1;
         const double2 zero2 = make_double2(0.0, 0.0);
-        for (int64_t e = t; e < TS_NP * ncol2; e += 512) {
+        for (int64_t e = t; e < (TS_NP / TS_CLEAR) * ncol2; e += 512) {
             const int64_t i = e / ncol2, j2 = e - i * ncol2;
-            *reinterpret_cast<double2*>(V + (b0 + i) * ld + b0 + TS_NP + 2 * j2) = zero2;
+            *reinterpret_cast<double2*>(V + (r0 + i) * ld + c0 + 2 * j2) = zero2;
         }
+        return;
     }
+    const int64_t b0 = (int64_t)blockIdx.x * TS_NP;
     for (int e = t; e < TS_NP * (TS_NP / 2); e += 512) {
         const int i = e >> 6, j = (e & 63) * 2;
         const double2 v = *reinterpret_cast<const double2*>(L + (b0 + i) * ld + b0 + j);
@@ -100,7 +108,8 @@ __global__ __launch_bounds__(512) void trtri_diag128_kernel(const double* __rest
 }
 
 int launch_trtri_diag128(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool clear_right) {
-    hipLaunchKernelGGL(trtri_diag128_kernel, dim3((unsigned)(Np / TS_NP), 1, (unsigned)ctx->bn), dim3(512), 0, st, L, V, Np, ctx->dinfo,
+    const unsigned nblk = (unsigned)(Np / TS_NP);
+    hipLaunchKernelGGL(trtri_diag128_kernel, dim3(clear_right ? nblk * (1 + TS_CLEAR) : nblk, 1, (unsigned)ctx->bn), dim3(512), 0, st, L, V, Np, ctx->dinfo,
                        clear_right ? 1 : 0, ctx->bstride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
