@@ -65,20 +65,36 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
         } guard{ctx};
         // (a batched evaluation has thetas enough to fill the GPU: its V = L^-1 stays behind potrf on the main stream;
         // the two schedules give the same bits)
-        if (ctx->opt_factor_pipeline && ctx->opt_chol == 0 && ctx->Np >= ctx->opt_factor_pipeline_min && ctx->bn == 1) {
+        if (ctx->opt_factor_pipeline && ctx->opt_chol == 0 && ctx->Np >= ctx->opt_factor_pipeline_min && ctx->bn == 1 &&
+            !potrf_stacked_usable(ctx, ctx->Np)) {
             const int rc = trtri_pipeline_begin(ctx, A, V, T, ctx->Np);
             if (rc < 0) return rc;
             piped = rc == 0;
             guard.armed = piped;
         }
-        {
+        // Up to Np = "chol_stacked" the inverse factor comes out of the Cholesky launches themselves (potrf_stacked, chol_panel.hip):
+        // T takes the identity and comes back as L^-T, which is transposed into V.
+        bool stacked = !piped && potrf_stacked_usable(ctx, ctx->Np);
+        if (stacked) {
             StageScope s(ctx, "potrf");
-            GPRY_TRY(ctx->opt_chol_overlap ? potrf_lower_overlap(ctx, A, ctx->Np) : potrf_lower_fused(ctx, A, ctx->Np));
+            GPRY_TRY(set_identity_launch(ctx, T, ctx->Np));
+            const int rc = potrf_stacked(ctx, A, T, ctx->Np);
+            if (rc < 0) return rc;
+            stacked = rc == 0;      // (1: no plan for this size)
         }
-        {
+        if (stacked) {
             StageScope s(ctx, "trtri");
-            if (piped) { GPRY_TRY(trtri_pipeline_finish(ctx)); guard.armed = false; }
-            else GPRY_TRY(trtri_lower(ctx, A, V, T, ctx->Np));
+            GPRY_TRY(transpose_upper_launch(ctx, T, V, ctx->Np));
+        } else {
+            {
+                StageScope s(ctx, "potrf");
+                GPRY_TRY(ctx->opt_chol_overlap ? potrf_lower_overlap(ctx, A, ctx->Np) : potrf_lower_fused(ctx, A, ctx->Np));
+            }
+            {
+                StageScope s(ctx, "trtri");
+                if (piped) { GPRY_TRY(trtri_pipeline_finish(ctx)); guard.armed = false; }
+                else GPRY_TRY(trtri_lower(ctx, A, V, T, ctx->Np));
+            }
         }
     }
     ctx->info_cleared = false;

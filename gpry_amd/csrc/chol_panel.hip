@@ -325,6 +325,9 @@ struct PanelArgs {
     int* info; int* arrive; int target;
     int64_t bstride;        // batched launch (gpry_ctx::bn): A, info and arrive of theta blockIdx.z lie this many doubles further on
     int flags;              // experiments (GPRY_PANEL_FLAGS): 1: the workers do not yield to their SIMD partners; 16 / 32 (host): the compact / the roomy step for every launch
+    // THE INVERSE FACTOR AS EXTRA ROWS (potrf_stacked below): workgroups bx >= n_top own row block bx - n_top of a second matrix, the
+    // appended block, that lies aug_delta doubles behind A (same leading dimension); outside that schedule n_top is "all of them"
+    int n_top; int64_t aug_delta;
 };
 #define PANEL_SMEM_DOUBLES (4 * 64 * PLD + 64 + 16)
 
@@ -457,7 +460,10 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar: the wave's role decides its control flow)
     const bool is_diag = bx == 0, worker = w >= 4;
     const int row = w;                              // chain waves: the block row of D they own
-    const int64_t R = j0 + 64 * (int64_t)bx;
+    // the workgroup's own rows: block bx below the diagonal block -- or block bx - n_top of the appended matrix (Aown)
+    const bool appended = bx >= pa.n_top;
+    const int64_t R = appended ? 64 * (int64_t)(bx - pa.n_top) : j0 + 64 * (int64_t)bx;
+    double* __restrict__ Aown = appended ? A + pa.aug_delta : A;
     const bool has_prev = j0 > K0;                 // false for the first strip of a segment
 #ifdef GPRY_PANEL_STAMPS
     const int stamp_step = (int)((pa.col0 + j0) / 64) < STAMP_STEPS ? (int)((pa.col0 + j0) / 64) : STAMP_STEPS - 1;
@@ -475,8 +481,8 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     // (what the factor waits for goes out first: loads return in order, and the scheduler had put the own-row loads in front)
     __builtin_amdgcn_sched_barrier(0);
     {
-        const double* __restrict__ gB_ = A + R * ld + j0;
-        const double* __restrict__ gPo_ = A + R * ld + K0;
+        const double* __restrict__ gB_ = Aown + R * ld + j0;
+        const double* __restrict__ gPo_ = Aown + R * ld + K0;
         B8_FOR(B8_LOAD)
     }
     D4_FOR(D4_COMMIT)
@@ -638,7 +644,7 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
         PANEL_PROGRESS(60);
         return;
     }
-    store_block(A + R * ld + j0, ld, sB, t, false);
+    store_block(Aown + R * ld + j0, ld, sB, t, false);
     PANEL_STAMP(6);
     PANEL_PROGRESS(61);
 }
@@ -656,15 +662,19 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
 // half of the panel that has only just been completed (its second half is applied by the next panel step itself)
 struct TileItem { int64_t a_off, b_off, c_off, ha_off, hb_off; int32_t n, half; };
 __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
-                                                 const int* info) {
+                                                 const int* info, const int64_t aug_delta) {
     if (*info != 0) return;
     double* sA = smem;
     double* sB = smem + 64 * S64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const bool diag = it.a_off == it.b_off;
+    // (half: bit 0: the visit ends with the half panel; bit 1: the tile and its row operand lie in the appended matrix of
+    // potrf_stacked, aug_delta doubles behind A -- a_off, c_off and ha_off count from there)
+    const bool appended = (it.half & 2) != 0, with_half = (it.half & 1) != 0;
+    double* __restrict__ Ar = appended ? A + aug_delta : A;
+    const bool diag = !appended && it.a_off == it.b_off;
     const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
     // C/D fragment: row = g + 4q, col = r.  The 8 old values of this lane stay in registers over the visit.
-    double* cbase = A + it.c_off + (int64_t)(wr * 16 + g) * ld + wc * 32 + r;
+    double* cbase = Ar + it.c_off + (int64_t)(wr * 16 + g) * ld + wc * 32 + r;
     double val[2][4];
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
@@ -673,11 +683,11 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
     if (diag) sB = sA;
     // A lagging tile takes several pending panels in one visit: each one accumulated from zero and subtracted
     // with one rounding, in order -- the values a store / reload between them would give.
-    const int nvisit = (int)it.n + (it.half ? 1 : 0);
+    const int nvisit = (int)it.n + (with_half ? 1 : 0);
 #pragma unroll 1
     for (int u = 0; u < nvisit; u++) {
         const bool half = u >= (int)it.n;       // the last visit of a tile with `half`: 64 k instead of 128
-        const double* Ag = half ? A + it.ha_off : A + it.a_off + (int64_t)u * 128;
+        const double* Ag = half ? Ar + it.ha_off : Ar + it.a_off + (int64_t)u * 128;
         const double* Bg = half ? A + it.hb_off : A + it.b_off + (int64_t)u * 128;
         const int kd = half ? 64 : 128;
         if (u) __syncthreads();                 // everybody has read the previous panel's images
@@ -780,7 +790,9 @@ __device__ __forceinline__ void panel_step_compact(const PanelArgs& pa, double* 
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar: the wave's role decides its control flow)
     const bool is_diag = bx == 0, worker = w >= 4;
     const int row = w & 3;          // chain waves: the block row of D they own; workers: the row tile of the own rows
-    const int64_t R = j0 + 64 * (int64_t)bx;
+    const bool appended = bx >= pa.n_top;          // (the appended matrix of potrf_stacked: see PanelArgs)
+    const int64_t R = appended ? 64 * (int64_t)(bx - pa.n_top) : j0 + 64 * (int64_t)bx;
+    double* __restrict__ Aown = appended ? A + pa.aug_delta : A;
     const bool has_prev = j0 > K0;                 // false for the first strip of a segment
     const int r = lane & 15, g = lane >> 4;
 #ifdef GPRY_PANEL_STAMPS
@@ -801,9 +813,9 @@ __device__ __forceinline__ void panel_step_compact(const PanelArgs& pa, double* 
     U16_FOR(PO_DECL)
     v4d bt0 = {0.0, 0.0, 0.0, 0.0}, bt1 = bt0, bt2 = bt0, bt3 = bt0;
     if (worker && !is_diag) {
-        const double* __restrict__ gPo_ = A + (R + 16 * row + r) * ld + K0 + g;
+        const double* __restrict__ gPo_ = Aown + (R + 16 * row + r) * ld + K0 + g;
         if (has_prev) { U16_FOR(PO_LOAD) }
-        const double* __restrict__ gB_ = A + (R + 16 * row + g) * ld + j0 + r;
+        const double* __restrict__ gB_ = Aown + (R + 16 * row + g) * ld + j0 + r;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             bt0[q] = gB_[(int64_t)(4 * q) * ld]; bt1[q] = gB_[(int64_t)(4 * q) * ld + 16];
@@ -960,7 +972,7 @@ __device__ __forceinline__ void panel_step_compact(const PanelArgs& pa, double* 
         PANEL_PROGRESS(60);
         return;
     }
-    store_block(A + R * ld + j0, ld, sB, t, false);
+    store_block(Aown + R * ld + j0, ld, sB, t, false);
     PANEL_STAMP(6);
     PANEL_PROGRESS(61);
 }
@@ -974,15 +986,19 @@ __device__ __forceinline__ void panel_step_compact(const PanelArgs& pa, double* 
 // 128 x 128 SYRK tile of the separate trailing launches: bit-identical.
 #define S64C 66
 __device__ __forceinline__ void syrk64_tile_compact(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
-                                                 const int* info) {
+                                                 const int* info, const int64_t aug_delta) {
     if (*info != 0) return;
     double* sA = smem;
     double* sB = smem + 64 * S64C;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const bool diag = it.a_off == it.b_off;
+    // (half: bit 0: the visit ends with the half panel; bit 1: the tile and its row operand lie in the appended matrix of
+    // potrf_stacked, aug_delta doubles behind A -- a_off, c_off and ha_off count from there)
+    const bool appended = (it.half & 2) != 0, with_half = (it.half & 1) != 0;
+    double* __restrict__ Ar = appended ? A + aug_delta : A;
+    const bool diag = !appended && it.a_off == it.b_off;
     const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
     // C/D fragment: row = g + 4q, col = r.  The 8 old values of this lane stay in registers over the visit.
-    double* cbase = A + it.c_off + (int64_t)(wr * 16 + g) * ld + wc * 32 + r;
+    double* cbase = Ar + it.c_off + (int64_t)(wr * 16 + g) * ld + wc * 32 + r;
     double val[2][4];
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
@@ -993,12 +1009,12 @@ __device__ __forceinline__ void syrk64_tile_compact(double* __restrict__ A, int6
     const double* pb = sB + (wc * 32 + r) * S64C + g;
     // A lagging tile takes several pending panels in one visit: each one accumulated from zero and subtracted
     // with one rounding, in order -- the values a store / reload between them would give.
-    const int nvisit = (int)it.n + (it.half ? 1 : 0);
+    const int nvisit = (int)it.n + (with_half ? 1 : 0);
     bool first = true;
 #pragma unroll 1
     for (int u = 0; u < nvisit; u++) {
         const bool half = u >= (int)it.n;       // the last visit of a tile with `half`: 64 k instead of 128
-        const double* Ag = half ? A + it.ha_off : A + it.a_off + (int64_t)u * 128;
+        const double* Ag = half ? Ar + it.ha_off : Ar + it.a_off + (int64_t)u * 128;
         const double* Bg = half ? A + it.hb_off : A + it.b_off + (int64_t)u * 128;
         const int kd = half ? 64 : 128;
         v4d acc[2];
@@ -1055,7 +1071,7 @@ __global__ __launch_bounds__(512) void chol_fused_kernel(PanelArgs pa, const Til
     if (bx < P) {
         panel_step_body(pa, smem, bx, tb);
     } else {
-        syrk64_tile_body(bset(pa.A, tb, pa.bstride), pa.ld, items[bx - P], smem, bset(pa.info, tb, pa.bstride));
+        syrk64_tile_body(bset(pa.A, tb, pa.bstride), pa.ld, items[bx - P], smem, bset(pa.info, tb, pa.bstride), pa.aug_delta);
     }
 }
 
@@ -1075,7 +1091,7 @@ __global__ __launch_bounds__(512) void chol_fused_compact_kernel(PanelArgs pa, c
         panel_step_compact(pa, smem, lin - tb * P, tb);
     } else {
         const int k = lin - P * bn, ii = k / bn, tb = k - ii * bn;
-        syrk64_tile_compact(bset(pa.A, tb, pa.bstride), pa.ld, items[ii], smem, bset(pa.info, tb, pa.bstride));
+        syrk64_tile_compact(bset(pa.A, tb, pa.bstride), pa.ld, items[ii], smem, bset(pa.info, tb, pa.bstride), pa.aug_delta);
     }
 }
 
@@ -1108,12 +1124,15 @@ static int trailing_update(gpry_ctx* ctx, double* A, int64_t ld, int64_t n, int6
 }
 struct ChainState { int arrivals = 0; };
 // one panel step of the n x n block at A (columns col0.. of the whole matrix), tiles riding along
+// (n_aug > 0: the appended matrix of potrf_stacked at A + aug_delta contributes its first n_aug row blocks to this step)
 static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, int64_t n, int64_t col0, int64_t j0, int64_t Kfrom,
-                        const TileItem* items, int n_items) {
-    const int P = (int)((n - j0) / 64);
+                        const TileItem* items, int n_items, int n_aug = 0, int64_t aug_delta = 0) {
+    const int n_top = (int)((n - j0) / 64);
+    const int P = n_top + n_aug;
     cs.arrivals += P;
     static const int panel_flags = getenv("GPRY_PANEL_FLAGS") ? atoi(getenv("GPRY_PANEL_FLAGS")) : 0;
-    PanelArgs pa = {A, ld, j0, Kfrom, ctx->N, col0, ctx->dinfo, ctx->dinfo + 2, cs.arrivals, ctx->bstride, panel_flags};
+    PanelArgs pa = {A, ld, j0, Kfrom, ctx->N, col0, ctx->dinfo, ctx->dinfo + 2, cs.arrivals, ctx->bstride, panel_flags,
+                    n_aug > 0 ? n_top : (1 << 30), aug_delta};
     // Two forms of the step, the same operations on every tile in the same order (bit-identical factors; every theta of a
     // batch is compared with a single evaluation in tests/test_lml_batch_gpu.py).  A single evaluation takes the one whose
     // workgroups have a CU to themselves (135 KB of LDS): beside a second workgroup -- riding tiles of the same launch, GEMMs
@@ -1130,7 +1149,8 @@ static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, in
 }
 
 static const int64_t LARGE_TAIL = 3584, HEAD_BLOCK = 768;       // grid of both in profiles/r04_potrf.md
-struct Segment { int64_t K0; int nrows, ncols; int first_launch; };     // strips of 64; first_launch: index into the plan's per-launch lists
+struct Segment { int64_t K0; int nrows, ncols; int first_launch; int naug = 0; };     // strips of 64; first_launch: index into the plan's per-launch lists;
+                                                                                       // naug: row blocks of the appended matrix (potrf_stacked)
 static std::vector<Segment> segments_of(int64_t Np) {
     std::vector<Segment> seg;
     int64_t K0 = 0;
@@ -1209,28 +1229,41 @@ struct OverlapPlan {
     std::vector<Segment> seg;
     std::vector<int> first, count;      // per launch: slice of d_items
 };
+// two plans per context: [0] the factorisation alone, [1] with the inverse factor as appended rows (potrf_stacked)
+struct OverlapPlans { OverlapPlan p[2]; };
 void overlap_plan_free(gpry_ctx* ctx) {
-    OverlapPlan* pl = static_cast<OverlapPlan*>(ctx->chol_plan);
+    OverlapPlans* pl = static_cast<OverlapPlans*>(ctx->chol_plan);
     if (!pl) return;
-    if (pl->d_items) (void)hipFree(pl->d_items);
+    for (int i = 0; i < 2; i++) if (pl->p[i].d_items) (void)hipFree(pl->p[i].d_items);
     delete pl;
     ctx->chol_plan = nullptr;
 }
 // appends the launches of one segment; returns false if a deadline cannot be met
 static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<TileItem>& items, std::vector<int>& first, std::vector<int>& count) {
-    const int nrows = sg.nrows, ncols = sg.ncols;
+    // Rows nrows .. nrows + naug - 1 are the row blocks of the appended matrix (potrf_stacked: the identity, which the chain
+    // turns into L^-T).  Appended row block a is zero left of column block a: its tiles exist from column a on, the panels left
+    // of strip a leave them as they are (never visited), and its panel workgroup joins the chain at step a.
+    const int ntop = sg.nrows, naug = sg.naug, nrows = ntop + naug, ncols = sg.ncols;
     std::vector<int> done((size_t)nrows * ncols, 0), last((size_t)nrows * ncols, -1);
     std::vector<char> halfdone((size_t)nrows * ncols, 0);
+    for (int a = 0; a < naug; a++)
+        for (int c = a; c < ncols; c++) {
+            const int bc = c / 2, need = (c & 1) ? bc : bc - 1;
+            const int p0 = a / 2;            // whole panels that are all zero in row block a (a half-zero panel is applied: it adds exact zeros)
+            done[(size_t)(ntop + a) * ncols + c] = need < 0 ? 0 : p0 < need ? p0 : need;
+            if (!(c & 1) && c >= 2 && a >= c - 1) halfdone[(size_t)(ntop + a) * ncols + c] = 1;      // strip c - 2 is zero in this row block
+        }
     struct Cand { int slack, c, r, p, n, half; };
     std::vector<Cand> cand;
     auto item = [&](int r, int c, int p, int nn, int half) {
         TileItem it;
-        it.a_off = (int64_t)r * 64 * ld + (int64_t)p * 128;      // 64 rows from tile row r, the 128 columns of panel p
+        const int rr = r >= ntop ? r - ntop : r;                 // (appended rows count from the start of their own matrix: TileItem)
+        it.a_off = (int64_t)rr * 64 * ld + (int64_t)p * 128;     // 64 rows from tile row r, the 128 columns of panel p
         it.b_off = (int64_t)c * 64 * ld + (int64_t)p * 128;
-        it.c_off = (int64_t)r * 64 * ld + (int64_t)c * 64;
-        it.ha_off = (int64_t)r * 64 * ld + (int64_t)(c - 2) * 64;     // the 64 columns of strip c - 2
+        it.c_off = (int64_t)rr * 64 * ld + (int64_t)c * 64;
+        it.ha_off = (int64_t)rr * 64 * ld + (int64_t)(c - 2) * 64;    // the 64 columns of strip c - 2
         it.hb_off = (int64_t)c * 64 * ld + (int64_t)(c - 2) * 64;
-        it.n = nn; it.half = half;
+        it.n = nn; it.half = (half ? 1 : 0) | (r >= ntop ? 2 : 0);
         return it;
     };
     const int multi = 2;                         // panels per visit of a lagging tile
@@ -1238,7 +1271,7 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
     // (measured at N = 4096: 1570 us with 1 / 1, 1601 with 2 / 1, 1625 with 2 / 2, 1632 with 3 / 2; no difference up to 2048)
     for (int l = 0; l < ncols; l++) {
         const int b = l / 2;
-        const int P = nrows - l;
+        const int P = (ntop - l) + (naug > l + 1 ? l + 1 : naug);      // panel workgroups of launch l
         const int cap = ncu > P ? ncu - P : 0;
         cand.clear();
         // columns not yet factored: c >= 2b (+1 in the block's second launch: its first 64 columns are done)
@@ -1248,8 +1281,10 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
             // c even: the first half of panel bc - 1 (strip c - 2) rides in launch c - 1, behind the whole panels
             const bool half_now = !(c & 1) && l == c - 1;
             for (int r = c; r < nrows; r++) {
+                if (r >= ntop && r - ntop > c) continue;         // (zero tile of the appended matrix)
                 const int p = done[(size_t)r * ncols + c];
                 if (last[(size_t)r * ncols + c] >= l) continue;
+                if (half_now && halfdone[(size_t)r * ncols + c]) continue;       // (appended rows whose strip c - 2 is zero)
                 if (half_now) {
                     // everything this strip still waits for goes into ONE visit: the pending whole panels, then the half
                     const int nn = need - p;                     // (all of them are complete: p < need <= bc - 1 <= b)
@@ -1290,16 +1325,18 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
         const int cnext = l + 1;                                 // the 64-column strip factored next
         if (cnext >= 2 && cnext < ncols) {
             const int bc = cnext / 2, need = (cnext & 1) ? bc : bc - 1;
-            for (int r = cnext; r < nrows; r++)
+            for (int r = cnext; r < nrows; r++) {
+                if (r >= ntop && r - ntop > cnext) continue;
                 if (done[(size_t)r * ncols + cnext] != need || (!(cnext & 1) && !halfdone[(size_t)r * ncols + cnext])) return false;
+            }
         }
     }
     return true;
 }
 // returns 1 if no valid plan exists (the caller takes the schedule with separate trailing launches)
-static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
-    if (!ctx->chol_plan) ctx->chol_plan = new OverlapPlan();
-    OverlapPlan& pl = *static_cast<OverlapPlan*>(ctx->chol_plan);
+static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out, bool stacked = false) {
+    if (!ctx->chol_plan) ctx->chol_plan = new OverlapPlans();
+    OverlapPlan& pl = static_cast<OverlapPlans*>(ctx->chol_plan)->p[stacked ? 1 : 0];
     if (pl.Np == Np) { *out = &pl; return 0; }
     if (pl.d_items) { (void)hipFree(pl.d_items); pl.d_items = nullptr; }
     pl = OverlapPlan();
@@ -1307,6 +1344,10 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
     std::vector<TileItem> items;
     pl.seg = segments_of(Np);
+    if (stacked) {
+        if (pl.seg.size() != 1) { pl = OverlapPlan(); return 1; }      // (one segment: Np <= LARGE_TAIL)
+        pl.seg[0].naug = pl.seg[0].nrows;
+    }
     for (const Segment& sg : pl.seg)
         if (!plan_segment(sg, Np, ncu, items, pl.first, pl.count)) { pl = OverlapPlan(); return 1; }
     if (!items.empty()) {
@@ -1320,6 +1361,88 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out) {
     }
     pl.Np = Np;
     *out = &pl;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// THE INVERSE FACTOR AS EXTRA ROWS OF THE PANEL CHAIN (late in round 5; Np <= "chol_stacked").  The panel step solves
+// X L(j,j)^T = B for every row block below the diagonal block.  Append the identity to the matrix -- [K; I], 2 Np x Np -- and the
+// appended rows come out as U with U L^T = I: U = L^-T = V^T, the reference's own formulation of the inverse factor
+// (solve_triangular(L, I), gpry/gpr.py:1456-1457), computed by the launches of the factorisation itself: the same panel step,
+// the same riding tiles, the same deadline plan, batched launches included.  The recursive V = L^-1 behind potrf -- eleven
+// dependent launches at N = 1024, 0.13 of an evaluation's 0.49 ms; 0.26 of 0.83 ms at N = 2048 -- is gone; the extra N^3 / 6
+// multiply-adds ride in the four fifths of the GPU that the panel chain leaves idle.
+//   * The appended block is a matrix of its own (`U`, same leading dimension): PanelArgs::aug_delta / TileItem::half bit 1.
+//   * Its zero structure is used: row block a of I is zero left of column block a, so its panel workgroup joins the chain at
+//     step a and its tiles skip the panels left of strip a (plan_segment).  The caller has written the identity.
+//   * The caller transposes U into the lower-triangular V that every consumer reads (transpose_upper_launch below).
+// V differs from the recursive inverse by rounding (another summation order; the same in every schedule that takes this path:
+// single, batched).  L is the factor of the other schedules bit for bit.
+int potrf_stacked(gpry_ctx* ctx, double* A, double* U, int64_t Np) {
+    OverlapPlan* pl = nullptr;
+    const int prc = overlap_plan_get(ctx, Np, &pl, true);
+    if (prc) return prc;            // (1: no plan -- the caller takes the other path)
+    if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));
+    ctx->info_cleared = false;
+    ChainState cs;
+    const Segment& sg = pl->seg[0];
+    const int64_t n = (int64_t)sg.nrows * 64;
+    for (int c = 0; c < sg.ncols; c++) {
+        const int64_t j0 = (int64_t)c * 64;
+        GPRY_TRY(panel_launch(ctx, cs, A, Np, n, 0, j0, j0 >= 64 ? j0 - 64 : 0, pl->d_items + pl->first[c], pl->count[c],
+                              c + 1 < sg.naug ? c + 1 : sg.naug, (int64_t)(U - A)));
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+bool potrf_stacked_usable(const gpry_ctx* ctx, int64_t Np) {
+    return ctx->opt_chol == 0 && ctx->opt_chol_overlap && Np <= ctx->opt_chol_stacked && Np <= LARGE_TAIL && Np >= 128;
+}
+
+// U <- I (the appended matrix before potrf_stacked), and V <- U^T afterwards: V lower triangular with zeros above, as the
+// recursive inverse leaves it.  64 x 64 tiles through LDS; thetas of a batched launch in z.
+__global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ U_, int64_t ld, int64_t bstride) {
+    double* __restrict__ U = bset(U_, (int)blockIdx.z, bstride);
+    const int64_t i = blockIdx.x;
+    for (int64_t j2 = threadIdx.x; j2 < ld / 2; j2 += 256)
+        *reinterpret_cast<double2*>(U + i * ld + 2 * j2) = make_double2(2 * j2 == i ? 1.0 : 0.0, 2 * j2 + 1 == i ? 1.0 : 0.0);
+}
+__global__ __launch_bounds__(256) void transpose_upper_kernel(const double* __restrict__ U_, double* __restrict__ V_, int64_t ld, int64_t bstride) {
+    __shared__ double tile[64][65];
+    const double* __restrict__ U = bset(U_, (int)blockIdx.z, bstride);
+    double* __restrict__ V = bset(V_, (int)blockIdx.z, bstride);
+    const int nb = (int)(ld / 64);
+    const int bi = (int)blockIdx.x / nb, bj = (int)blockIdx.x - bi * nb;        // tile (bi, bj) of V
+    const int t = threadIdx.x;
+    if (bj > bi) {                                                             // above the diagonal: zeros
+        for (int e = t; e < 64 * 32; e += 256) {
+            const int i = e >> 5, j2 = e & 31;
+            *reinterpret_cast<double2*>(V + ((int64_t)bi * 64 + i) * ld + (int64_t)bj * 64 + 2 * j2) = make_double2(0.0, 0.0);
+        }
+        return;
+    }
+    for (int e = t; e < 64 * 32; e += 256) {                                   // tile (bj, bi) of U
+        const int i = e >> 5, j2 = e & 31;
+        const double2 v = *reinterpret_cast<const double2*>(U + ((int64_t)bj * 64 + i) * ld + (int64_t)bi * 64 + 2 * j2);
+        tile[i][2 * j2] = v.x; tile[i][2 * j2 + 1] = v.y;
+    }
+    __syncthreads();
+    for (int e = t; e < 64 * 32; e += 256) {
+        const int i = e >> 5, j2 = e & 31;
+        double a = tile[2 * j2][i], b = tile[2 * j2 + 1][i];
+        if (bi == bj) { if (2 * j2 > i) a = 0.0; if (2 * j2 + 1 > i) b = 0.0; }
+        *reinterpret_cast<double2*>(V + ((int64_t)bi * 64 + i) * ld + (int64_t)bj * 64 + 2 * j2) = make_double2(a, b);
+    }
+}
+int set_identity_launch(gpry_ctx* ctx, double* U, int64_t Np) {
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)Np, 1, (unsigned)ctx->bn), dim3(256), 0, ctx->stream, U, Np, ctx->bstride);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+int transpose_upper_launch(gpry_ctx* ctx, const double* U, double* V, int64_t Np) {
+    const unsigned nb = (unsigned)(Np / 64);
+    hipLaunchKernelGGL(transpose_upper_kernel, dim3(nb * nb, 1, (unsigned)ctx->bn), dim3(256), 0, ctx->stream, U, V, Np, ctx->bstride);
+    HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
@@ -1345,3 +1468,64 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+
+#ifdef GPRY_PROTOTYPES
+// PROTOTYPE (tools/r05/build_proto.sh; not part of the product library): the inverse factor as extra rows of the panel chain.
+// The stacked matrix [K; I] (2 Np x Np, one allocation) goes through ONE rectangular segment of the overlap schedule; its
+// bottom block comes out as U = L^-T.  No use of the zero structure of I (the appended rows are treated as dense: three times
+// the multiply-adds of a triangular inverse) -- this measures what the existing machinery gives, DESIGN.md section 7 (iii).
+extern "C" int gpry_proto_potrf_stacked(gpry_ctx* ctx, const double* K_host, int64_t Np, double* L_host, double* U_host, int reps,
+                                        double* ms_stacked, double* ms_square) {
+    if (Np % 64) return gpry_fail(ctx, -1, "prototype: Np must be a multiple of 64");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int nb = (int)(Np / 64);
+    double *dA = nullptr, *dIn = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&dA, sizeof(double) * 2 * Np * Np));
+    HIP_TRY(ctx, hipMalloc((void**)&dIn, sizeof(double) * 2 * Np * Np));
+    {
+        std::vector<double> h((size_t)(2 * Np * Np), 0.0);
+        memcpy(h.data(), K_host, sizeof(double) * Np * Np);
+        for (int64_t i = 0; i < Np; i++) h[(size_t)((Np + i) * Np + i)] = 1.0;
+        HIP_TRY(ctx, hipMemcpy(dIn, h.data(), sizeof(double) * 2 * Np * Np, hipMemcpyHostToDevice));
+    }
+    int ncu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1));
+    for (int form = 0; form < 2; form++) {           // 0: the stacked matrix, 1: the square one alone
+        Segment sg = {0, form == 0 ? 2 * nb : nb, nb, 0};
+        std::vector<TileItem> items; std::vector<int> first, count;
+        if (!plan_segment(sg, Np, ncu, items, first, count)) return gpry_fail(ctx, -1, "prototype: no plan");
+        TileItem* d_items = nullptr;
+        if (!items.empty()) {
+            HIP_TRY(ctx, hipMalloc((void**)&d_items, items.size() * sizeof(TileItem)));
+            HIP_TRY(ctx, hipMemcpy(d_items, items.data(), items.size() * sizeof(TileItem), hipMemcpyHostToDevice));
+        }
+        double total = 0.0;
+        for (int rep = 0; rep < reps + 1; rep++) {
+            HIP_TRY(ctx, hipMemcpyAsync(dA, dIn, sizeof(double) * 2 * Np * Np, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+            ChainState cs;
+            for (int c = 0; c < sg.ncols; c++) {
+                const int64_t j0 = (int64_t)c * 64;
+                GPRY_TRY(panel_launch(ctx, cs, dA, Np, (int64_t)sg.nrows * 64, 0, j0, j0 >= 64 ? j0 - 64 : 0, d_items + first[c], count[c]));
+            }
+            HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            float ms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0) total += ms;
+        }
+        *(form == 0 ? ms_stacked : ms_square) = total / reps;
+        if (form == 0) {
+            HIP_TRY(ctx, hipMemcpy(L_host, dA, sizeof(double) * Np * Np, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(U_host, dA + Np * Np, sizeof(double) * Np * Np, hipMemcpyDeviceToHost));
+        }
+        if (d_items) (void)hipFree(d_items);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(dA); (void)hipFree(dIn);
+    return 0;
+}
+#endif

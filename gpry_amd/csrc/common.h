@@ -149,6 +149,7 @@ struct gpry_ctx {
     void* srv = nullptr;
     int opt_predict_serve = 1;         // mean-only gpry_predict of <= 8 points goes through the resident kernel
     int64_t opt_serve_idle_us = 2000;  // the kernel leaves after this long without a request
+    int64_t opt_chol_stacked = 2048;   // up to this Np the inverse factor comes out of the Cholesky launches themselves (potrf_stacked, chol_panel.hip); 0: never
     int opt_sweep_upload = 1;          // 1: a fresh candidate pool is uploaded chunk by chunk on stream2, chunk c + 1 underneath the kernels of chunk c
     const double* up_X = nullptr;      // host pool of the sweep in flight whose chunks are still to be uploaded (run_sweep)
     int up_gates = 0;                  // ... and the device gates are evaluated chunk by chunk behind each upload
@@ -310,7 +311,11 @@ int launch_lml_traces(gpry_ctx* ctx, const double* Kinv, const double* alpha,
 
 // ---- chol.hip ----------------------------------------------------------------------
 int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // panel steps, every trailing update its own launch (comparator)
-int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);     // panel step + earlier trailing tiles in ONE launch; above Np = 3584 segment by segment (default)
+int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);
+int potrf_stacked(gpry_ctx* ctx, double* A, double* U, int64_t Np);      // A <- L, U <- L^-T (U: the identity on entry)
+bool potrf_stacked_usable(const gpry_ctx* ctx, int64_t Np);
+int set_identity_launch(gpry_ctx* ctx, double* U, int64_t Np);
+int transpose_upper_launch(gpry_ctx* ctx, const double* U, double* V, int64_t Np);     // panel step + earlier trailing tiles in ONE launch; above Np = 3584 segment by segment (default)
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
 // V = L^-1 queued phase by phase underneath potrf (chol.hip); begin returns 1 when the size is not cut
 int trtri_pipeline_begin(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);

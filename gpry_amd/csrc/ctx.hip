@@ -241,7 +241,7 @@ const int64_t BIG = (int64_t)1 << 40;
 const OptionSpec OPTIONS[] = {
     OPT_INT("timing", opt_timing, 0, 1, (void)0),
     OPT_INT("chol", opt_chol, 0, 1, c->lml_cache = false),
-    OPT_INT("chol_overlap", opt_chol_overlap, 0, 1, (void)0),
+    OPT_INT("chol_overlap", opt_chol_overlap, 0, 1, c->lml_cache = false),      // (the comparator takes the recursive inverse: other rounding)
     OPT_INT("factor_pipeline", opt_factor_pipeline, 0, 1, (void)0),
     OPT_INT("factor_pipeline_min", opt_factor_pipeline_min, 0, BIG, (void)0),
     OPT_INT("gemm_dma", opt_gemm_dma, 0, 1, (void)0),
@@ -257,6 +257,7 @@ const OptionSpec OPTIONS[] = {
     OPT_INT("predict_small", opt_predict_small, 0, BIG, (void)0),
     OPT_INT("predict_split", opt_predict_split, 0, 1, (void)0),
     OPT_INT("sweep_upload", opt_sweep_upload, 0, 1, (void)0),
+    OPT_INT("chol_stacked", opt_chol_stacked, 0, BIG, c->lml_cache = false),
     OPT_INT("predict_gates", opt_predict_gates, 0, 1, (void)0),
     OPT_INT("predict_serve", opt_predict_serve, 0, 1, (void)0),
     OPT_INT("serve_idle_us", opt_serve_idle_us, 10, 1000000, (void)0),

@@ -78,7 +78,7 @@ def multi_process_launch():
 # options of a device context that change the arithmetic or the limits of an objective evaluation: extra contexts of a fit
 # (thread farm, side-by-side groups) take the values of the model's own context, so that every context evaluates alike
 # whatever the caller has set ("same bits as the sequential loop")
-_FIT_CONTEXT_OPTIONS = ("chol", "chol_overlap", "factor_pipeline", "factor_pipeline_min", "gemm_dma", "gemm_streamk",
+_FIT_CONTEXT_OPTIONS = ("chol", "chol_overlap", "chol_stacked", "factor_pipeline", "factor_pipeline_min", "gemm_dma", "gemm_streamk",
                         "gemm_small", "lml_small", "lml_cache", "lml_batch", "lml_batch_mb")
 
 

@@ -111,6 +111,10 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *     "sweep_upload" 0/1      gpry_sweep_logexp with a host pool: 1 (default) uploads it chunk by chunk on a copy stream, chunk
  *                             c + 1 underneath the kernels of chunk c (gpry/gp_acquisition.py:1023-1031 draws a fresh pool every
  *                             mc_every-th call); 0: one copy in front of the sweep (the comparator; same bits)
+ *     "chol_stacked"          up to this padded training-set size (default 2048; at most 3584) the inverse factor V = L^-1 comes
+ *                             out of the launches of the Cholesky factorisation itself (the identity appended to the matrix as
+ *                             extra rows); 0: always the recursive inverse behind the factorisation.  Same L; V, and what is
+ *                             computed from it, agree to rounding
  *     "predict_gates" 0/1     gpry_predict applies the gates of gpry_set_gates itself (default 0; the Python mirror sets 1)
  *     "predict_serve" 0/1     mean-only gpry_predict of <= 8 points is answered by a RESIDENT kernel (no launch per call;
  *                             default 1); "serve_idle_us" = how long that kernel waits for the next request before it

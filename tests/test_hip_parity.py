@@ -985,6 +985,8 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
     theta = np.log(np.array([3.0, 0.4, 0.5, 0.6, 0.7]))
     dev.set_theta(3, theta)
     try:
+        # (the schedule that also delivers the inverse factor -- "chol_stacked", next test -- has no separate-launch twin)
+        dev.set_option("chol_stacked", 0)
         dev.set_option("chol_overlap", 0)           # every trailing update its own launch
         assert dev.factorize() == 0
         L0, V0, a0 = dev.get_factor()
@@ -1026,6 +1028,80 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
             assert infos[0] == infos[1] and 300 < infos[0] <= 701
     finally:
         dev.set_option("chol_overlap", 1)
+        dev.set_option("chol_stacked", 2048)
+
+
+@pytest.mark.parametrize("N", [130, 200, 500, 1000, 1100, 2048, 2100, 3100, 3584])
+def test_inverse_factor_from_the_rows_appended_to_the_cholesky(dev, N):
+    """Up to Np = "chol_stacked" (default 2048; here also forced above it, up to the largest single-segment size) the inverse
+    factor V = L^-1 (gpry/gpr.py:1456-1457: solve_triangular(L, I)) is not computed behind the Cholesky: the identity is appended
+    to the matrix as extra rows, [K; I], and the panel chain -- same step, same riding tiles -- leaves L^-T in their place
+    (potrf_stacked, csrc/chol_panel.hip), which is transposed into V.  L must be the factor of the other schedule bit for
+    bit; V the inverse of L to rounding (a different summation order than the recursive inverse), lower triangular with exact
+    zeros above the diagonal; alpha_, the LML and its gradient those of the recursive path to rounding and the oracle's within
+    the tolerances of the objective tests; repeated calls and the adoption of an objective evaluation's factor give the same
+    bits; a matrix that is not positive definite reports the same leading minor."""
+    d = 5
+    rng = np.random.default_rng(N + 3)
+    X = rng.uniform(0, 1, (N, d))
+    y = np.sin(3 * X).sum(1) + 0.05 * rng.standard_normal(N)
+    noise = np.full(N, 1e-5)
+    dev.set_affine()
+    dev.set_train(X, y, noise)
+    theta = np.log(np.array([3.0, 0.4, 0.5, 0.6, 0.7, 0.8]))
+    dev.set_theta(3, theta)
+    try:
+        dev.set_option("lml_cache", 0)
+        dev.set_option("chol_stacked", 0)
+        assert dev.factorize() == 0
+        L0, V0, a0 = dev.get_factor()
+        lml0 = dev.lml(theta, True)
+        dev.set_option("chol_stacked", 4096)
+        for _ in range(2):
+            assert dev.factorize() == 0
+            L1, V1, a1 = dev.get_factor()
+            if _ == 0:
+                first = (V1, a1)
+            assert np.array_equal(V1, first[0]) and np.array_equal(a1, first[1])
+        assert np.array_equal(L0, L1)
+        assert not np.triu(V1, 1).any()
+        Ld = np.tril(L1)
+        assert relmax(np.tril(V1) @ Ld, np.eye(N)) < 1e-9
+        assert relmax(V1, V0) < 1e-11 and relmax(a1, a0) < 1e-9
+        lml1 = dev.lml(theta, True)
+        assert abs(lml1[0] - lml0[0]) <= 1e-12 * max(1.0, abs(lml0[0]))
+        assert np.max(np.abs(lml1[1] - lml0[1])) <= 1e-9 * max(1.0, np.max(np.abs(lml0[1])))
+        if N <= 2100:
+            rl, rg = orc.log_marginal_likelihood(X, y, noise, theta, 3, eval_gradient=True)
+            assert abs(lml1[0] - rl) <= 1e-10 * max(1.0, abs(rl))
+            assert np.max(np.abs(lml1[1] - rg)) <= 1e-7 * max(1.0, np.max(np.abs(rg)))
+        # the factor of an objective evaluation, adopted by factorize: the same bits
+        dev.set_option("lml_cache", 1)
+        dev.lml(theta, True)
+        assert dev.factorize() == 0
+        L2, V2, a2 = dev.get_factor()
+        assert np.array_equal(L2, L1) and np.array_equal(V2, V1) and np.array_equal(a2, a1)
+        # a batch: every theta the bits of its single evaluation
+        thetas = theta + rng.uniform(-0.3, 0.3, (3, d + 1))
+        single = [dev.lml(th, True) for th in thetas]
+        lb, gb, ib = dev.lml_batch(thetas, True)
+        for b, (l1, g1, i1) in enumerate(single):
+            assert lb[b] == l1 and ib[b] == i1 == 0
+            np.testing.assert_array_equal(gb[b], g1)
+        # not positive definite: a duplicated row with negative noise
+        if N >= 300:
+            Xb = X.copy(); Xb[N - 7] = Xb[N // 3]
+            nb = noise.copy(); nb[N - 7] = nb[N // 3] = -1e-3
+            infos = []
+            for st in (0, 4096):
+                dev.set_option("chol_stacked", st)
+                dev.set_train(Xb, y, nb)
+                dev.set_theta(3, theta)
+                infos.append(dev.factorize())
+            assert infos[0] == infos[1] and infos[0] > 0
+    finally:
+        dev.set_option("chol_stacked", 2048)
+        dev.set_option("lml_cache", 1)
 
 
 @pytest.mark.parametrize("N", [1000, 1100, 1300, 1700, 2100, 4096, 5000, 6100, 7300])
@@ -1045,6 +1121,7 @@ def test_pipelined_factor_chain_is_bit_identical(dev, N):
     dev.set_theta(3, theta)
     try:
         dev.set_option("factor_pipeline_min", 0)        # default: from Np = 1280 on
+        dev.set_option("chol_stacked", 0)               # (where V comes out of the Cholesky launches there is nothing to pipeline)
         for overlap in (1, 0):
             dev.set_option("chol_overlap", overlap)
             dev.set_option("factor_pipeline", 0)
@@ -1076,6 +1153,7 @@ def test_pipelined_factor_chain_is_bit_identical(dev, N):
         dev.set_option("chol_overlap", 1)
         dev.set_option("factor_pipeline", 1)
         dev.set_option("factor_pipeline_min", 1280)
+        dev.set_option("chol_stacked", 2048)
 
 
 
