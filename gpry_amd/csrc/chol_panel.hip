@@ -1149,8 +1149,9 @@ static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, in
 }
 
 static const int64_t LARGE_TAIL = 3584, HEAD_BLOCK = 768;       // grid of both in profiles/r04_potrf.md
-struct Segment { int64_t K0; int nrows, ncols; int first_launch; int naug = 0; };     // strips of 64; first_launch: index into the plan's per-launch lists;
-                                                                                       // naug: row blocks of the appended matrix (potrf_stacked)
+struct Segment { int64_t K0; int nrows, ncols; int first_launch; int naug = 0; bool aug_dense = false; };     // strips of 64; first_launch: index into the plan's per-launch lists;
+                                                                                       // naug: row blocks of the appended matrix (potrf_stacked);
+                                                                                       // aug_dense: without use of their zero structure (the comparator)
 static std::vector<Segment> segments_of(int64_t Np) {
     std::vector<Segment> seg;
     int64_t K0 = 0;
@@ -1229,12 +1230,13 @@ struct OverlapPlan {
     std::vector<Segment> seg;
     std::vector<int> first, count;      // per launch: slice of d_items
 };
-// two plans per context: [0] the factorisation alone, [1] with the inverse factor as appended rows (potrf_stacked)
-struct OverlapPlans { OverlapPlan p[2]; };
+// plans per context: [0] the factorisation alone, [1] with the inverse factor as appended rows (potrf_stacked), [2] the same
+// without use of the zero structure of the appended rows (its comparator)
+struct OverlapPlans { OverlapPlan p[3]; };
 void overlap_plan_free(gpry_ctx* ctx) {
     OverlapPlans* pl = static_cast<OverlapPlans*>(ctx->chol_plan);
     if (!pl) return;
-    for (int i = 0; i < 2; i++) if (pl->p[i].d_items) (void)hipFree(pl->p[i].d_items);
+    for (int i = 0; i < 3; i++) if (pl->p[i].d_items) (void)hipFree(pl->p[i].d_items);
     delete pl;
     ctx->chol_plan = nullptr;
 }
@@ -1243,10 +1245,12 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
     // Rows nrows .. nrows + naug - 1 are the row blocks of the appended matrix (potrf_stacked: the identity, which the chain
     // turns into L^-T).  Appended row block a is zero left of column block a: its tiles exist from column a on, the panels left
     // of strip a leave them as they are (never visited), and its panel workgroup joins the chain at step a.
+    // (aug_dense: the appended rows as ordinary rows -- every panel, every step, zeros included: what the skipping is compared with)
     const int ntop = sg.nrows, naug = sg.naug, nrows = ntop + naug, ncols = sg.ncols;
+    const bool skip = !sg.aug_dense;
     std::vector<int> done((size_t)nrows * ncols, 0), last((size_t)nrows * ncols, -1);
     std::vector<char> halfdone((size_t)nrows * ncols, 0);
-    for (int a = 0; a < naug; a++)
+    for (int a = 0; skip && a < naug; a++)
         for (int c = a; c < ncols; c++) {
             const int bc = c / 2, need = (c & 1) ? bc : bc - 1;
             const int p0 = a / 2;            // whole panels that are all zero in row block a (a half-zero panel is applied: it adds exact zeros)
@@ -1271,7 +1275,7 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
     // (measured at N = 4096: 1570 us with 1 / 1, 1601 with 2 / 1, 1625 with 2 / 2, 1632 with 3 / 2; no difference up to 2048)
     for (int l = 0; l < ncols; l++) {
         const int b = l / 2;
-        const int P = (ntop - l) + (naug > l + 1 ? l + 1 : naug);      // panel workgroups of launch l
+        const int P = (ntop - l) + (skip && naug > l + 1 ? l + 1 : naug);      // panel workgroups of launch l
         const int cap = ncu > P ? ncu - P : 0;
         cand.clear();
         // columns not yet factored: c >= 2b (+1 in the block's second launch: its first 64 columns are done)
@@ -1281,7 +1285,7 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
             // c even: the first half of panel bc - 1 (strip c - 2) rides in launch c - 1, behind the whole panels
             const bool half_now = !(c & 1) && l == c - 1;
             for (int r = c; r < nrows; r++) {
-                if (r >= ntop && r - ntop > c) continue;         // (zero tile of the appended matrix)
+                if (skip && r >= ntop && r - ntop > c) continue;         // (zero tile of the appended matrix)
                 const int p = done[(size_t)r * ncols + c];
                 if (last[(size_t)r * ncols + c] >= l) continue;
                 if (half_now && halfdone[(size_t)r * ncols + c]) continue;       // (appended rows whose strip c - 2 is zero)
@@ -1326,7 +1330,7 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
         if (cnext >= 2 && cnext < ncols) {
             const int bc = cnext / 2, need = (cnext & 1) ? bc : bc - 1;
             for (int r = cnext; r < nrows; r++) {
-                if (r >= ntop && r - ntop > cnext) continue;
+                if (skip && r >= ntop && r - ntop > cnext) continue;
                 if (done[(size_t)r * ncols + cnext] != need || (!(cnext & 1) && !halfdone[(size_t)r * ncols + cnext])) return false;
             }
         }
@@ -1334,9 +1338,9 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
     return true;
 }
 // returns 1 if no valid plan exists (the caller takes the schedule with separate trailing launches)
-static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out, bool stacked = false) {
+static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out, int stacked = 0) {       // stacked: 0 no, 1 yes, 2 yes with dense appended rows
     if (!ctx->chol_plan) ctx->chol_plan = new OverlapPlans();
-    OverlapPlan& pl = static_cast<OverlapPlans*>(ctx->chol_plan)->p[stacked ? 1 : 0];
+    OverlapPlan& pl = static_cast<OverlapPlans*>(ctx->chol_plan)->p[stacked];
     if (pl.Np == Np) { *out = &pl; return 0; }
     if (pl.d_items) { (void)hipFree(pl.d_items); pl.d_items = nullptr; }
     pl = OverlapPlan();
@@ -1347,6 +1351,7 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out, bool s
     if (stacked) {
         if (pl.seg.size() != 1) { pl = OverlapPlan(); return 1; }      // (one segment: Np <= LARGE_TAIL)
         pl.seg[0].naug = pl.seg[0].nrows;
+        pl.seg[0].aug_dense = stacked == 2;
     }
     for (const Segment& sg : pl.seg)
         if (!plan_segment(sg, Np, ncu, items, pl.first, pl.count)) { pl = OverlapPlan(); return 1; }
@@ -1379,8 +1384,11 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out, bool s
 // V differs from the recursive inverse by rounding (another summation order; the same in every schedule that takes this path:
 // single, batched).  L is the factor of the other schedules bit for bit.
 int potrf_stacked(gpry_ctx* ctx, double* A, double* U, int64_t Np) {
+    // "chol_stacked_dense" = 1: the comparator -- the appended rows as ordinary rows (all of them in every step, every panel
+    // applied, zeros included).  Skipping exact zeros changes no bit: tests/test_hip_parity.py compares the two.
+    const bool dense = ctx->opt_chol_stacked_dense != 0;
     OverlapPlan* pl = nullptr;
-    const int prc = overlap_plan_get(ctx, Np, &pl, true);
+    const int prc = overlap_plan_get(ctx, Np, &pl, dense ? 2 : 1);
     if (prc) return prc;            // (1: no plan -- the caller takes the other path)
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));
     ctx->info_cleared = false;
@@ -1390,7 +1398,7 @@ int potrf_stacked(gpry_ctx* ctx, double* A, double* U, int64_t Np) {
     for (int c = 0; c < sg.ncols; c++) {
         const int64_t j0 = (int64_t)c * 64;
         GPRY_TRY(panel_launch(ctx, cs, A, Np, n, 0, j0, j0 >= 64 ? j0 - 64 : 0, pl->d_items + pl->first[c], pl->count[c],
-                              c + 1 < sg.naug ? c + 1 : sg.naug, (int64_t)(U - A)));
+                              !dense && c + 1 < sg.naug ? c + 1 : sg.naug, (int64_t)(U - A)));
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

@@ -258,6 +258,7 @@ const OptionSpec OPTIONS[] = {
     OPT_INT("predict_split", opt_predict_split, 0, 1, (void)0),
     OPT_INT("sweep_upload", opt_sweep_upload, 0, 1, (void)0),
     OPT_INT("chol_stacked", opt_chol_stacked, 0, BIG, c->lml_cache = false),
+    OPT_INT("chol_stacked_dense", opt_chol_stacked_dense, 0, 1, c->lml_cache = false),
     OPT_INT("predict_gates", opt_predict_gates, 0, 1, (void)0),
     OPT_INT("predict_serve", opt_predict_serve, 0, 1, (void)0),
     OPT_INT("serve_idle_us", opt_serve_idle_us, 10, 1000000, (void)0),

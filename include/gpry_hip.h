@@ -115,6 +115,8 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                             out of the launches of the Cholesky factorisation itself (the identity appended to the matrix as
  *                             extra rows); 0: always the recursive inverse behind the factorisation.  Same L; V, and what is
  *                             computed from it, agree to rounding
+ *     "chol_stacked_dense" 0/1  1: that schedule without use of the zero structure of the appended rows (every row block in
+ *                             every step, every panel applied to every tile: three times the work; the comparator, same bits)
  *     "predict_gates" 0/1     gpry_predict applies the gates of gpry_set_gates itself (default 0; the Python mirror sets 1)
  *     "predict_serve" 0/1     mean-only gpry_predict of <= 8 points is answered by a RESIDENT kernel (no launch per call;
  *                             default 1); "serve_idle_us" = how long that kernel waits for the next request before it

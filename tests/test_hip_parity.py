@@ -1075,6 +1075,14 @@ def test_inverse_factor_from_the_rows_appended_to_the_cholesky(dev, N):
             rl, rg = orc.log_marginal_likelihood(X, y, noise, theta, 3, eval_gradient=True)
             assert abs(lml1[0] - rl) <= 1e-10 * max(1.0, abs(rl))
             assert np.max(np.abs(lml1[1] - rg)) <= 1e-7 * max(1.0, np.max(np.abs(rg)))
+        # the comparator: the appended rows without use of their zeros (every row block in every step, every panel on every
+        # tile) -- skipping exact zeros changes no bit
+        if N <= 2100:
+            dev.set_option("chol_stacked_dense", 1)
+            assert dev.factorize() == 0
+            L3, V3, a3 = dev.get_factor()
+            dev.set_option("chol_stacked_dense", 0)
+            assert np.array_equal(L3, L1) and np.array_equal(V3, V1) and np.array_equal(a3, a1)
         # the factor of an objective evaluation, adopted by factorize: the same bits
         dev.set_option("lml_cache", 1)
         dev.lml(theta, True)
@@ -1101,6 +1109,7 @@ def test_inverse_factor_from_the_rows_appended_to_the_cholesky(dev, N):
             assert infos[0] == infos[1] and infos[0] > 0
     finally:
         dev.set_option("chol_stacked", 2048)
+        dev.set_option("chol_stacked_dense", 0)
         dev.set_option("lml_cache", 1)
 
 
