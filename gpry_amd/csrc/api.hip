@@ -48,9 +48,11 @@ static int copy_out_matrix(gpry_ctx* ctx, const double* dsrc, int64_t ld, int64_
 static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* info_host) {
     // A <- K + diag(alpha); A <- chol(A) (lower); V <- A^-1
     GPRY_TRY(launch_scale_train(ctx));      // X / l (N x d, microseconds)
+    // (where V comes out of the Cholesky launches -- potrf_stacked below -- T starts as the identity: written by the same kernel)
+    const bool want_stacked = ctx->opt_chol != 1 && potrf_stacked_usable(ctx, ctx->Np);
     {
         StageScope s(ctx, "kernel_build");   // the O(N^2 d) covariance build proper
-        GPRY_TRY(launch_kernel_train(ctx, A, 1));
+        GPRY_TRY(launch_kernel_train(ctx, A, 1, want_stacked ? T : nullptr));
     }
     if (ctx->opt_chol == 1) {
         StageScope s(ctx, "potrf");
@@ -74,10 +76,9 @@ static int build_factor(gpry_ctx* ctx, double* A, double* V, double* T, int* inf
         }
         // Up to Np = "chol_stacked" the inverse factor comes out of the Cholesky launches themselves (potrf_stacked, chol_panel.hip):
         // T takes the identity and comes back as L^-T, which is transposed into V.
-        bool stacked = !piped && potrf_stacked_usable(ctx, ctx->Np);
+        bool stacked = !piped && want_stacked;
         if (stacked) {
             StageScope s(ctx, "potrf");
-            GPRY_TRY(set_identity_launch(ctx, T, ctx->Np));
             const int rc = potrf_stacked(ctx, A, T, ctx->Np);
             if (rc < 0) return rc;
             stacked = rc == 0;      // (1: no plan for this size)

@@ -1379,7 +1379,8 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out, int st
 // multiply-adds ride in the four fifths of the GPU that the panel chain leaves idle.
 //   * The appended block is a matrix of its own (`U`, same leading dimension): PanelArgs::aug_delta / TileItem::half bit 1.
 //   * Its zero structure is used: row block a of I is zero left of column block a, so its panel workgroup joins the chain at
-//     step a and its tiles skip the panels left of strip a (plan_segment).  The caller has written the identity.
+//     step a and its tiles skip the panels left of strip a (plan_segment).  The caller has written the identity (its tiles on and
+//     right of the diagonal and the one left of each diagonal tile: the others are never read).
 //   * The caller transposes U into the lower-triangular V that every consumer reads (transpose_upper_launch below).
 // V differs from the recursive inverse by rounding (another summation order; the same in every schedule that takes this path:
 // single, batched).  L is the factor of the other schedules bit for bit.
@@ -1407,14 +1408,8 @@ bool potrf_stacked_usable(const gpry_ctx* ctx, int64_t Np) {
     return ctx->opt_chol == 0 && ctx->opt_chol_overlap && Np <= ctx->opt_chol_stacked && Np <= LARGE_TAIL && Np >= 128;
 }
 
-// U <- I (the appended matrix before potrf_stacked), and V <- U^T afterwards: V lower triangular with zeros above, as the
-// recursive inverse leaves it.  64 x 64 tiles through LDS; thetas of a batched launch in z.
-__global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ U_, int64_t ld, int64_t bstride) {
-    double* __restrict__ U = bset(U_, (int)blockIdx.z, bstride);
-    const int64_t i = blockIdx.x;
-    for (int64_t j2 = threadIdx.x; j2 < ld / 2; j2 += 256)
-        *reinterpret_cast<double2*>(U + i * ld + 2 * j2) = make_double2(2 * j2 == i ? 1.0 : 0.0, 2 * j2 + 1 == i ? 1.0 : 0.0);
-}
+// V <- U^T behind potrf_stacked: V lower triangular with zeros above, as the recursive inverse leaves it.  64 x 64 tiles
+// through LDS; thetas of a batched launch in z.  (U starts as the identity: written by the covariance build, kernel_build.hip.)
 __global__ __launch_bounds__(256) void transpose_upper_kernel(const double* __restrict__ U_, double* __restrict__ V_, int64_t ld, int64_t bstride) {
     __shared__ double tile[64][65];
     const double* __restrict__ U = bset(U_, (int)blockIdx.z, bstride);
@@ -1441,11 +1436,6 @@ __global__ __launch_bounds__(256) void transpose_upper_kernel(const double* __re
         if (bi == bj) { if (2 * j2 > i) a = 0.0; if (2 * j2 + 1 > i) b = 0.0; }
         *reinterpret_cast<double2*>(V + ((int64_t)bi * 64 + i) * ld + (int64_t)bj * 64 + 2 * j2) = make_double2(a, b);
     }
-}
-int set_identity_launch(gpry_ctx* ctx, double* U, int64_t Np) {
-    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)Np, 1, (unsigned)ctx->bn), dim3(256), 0, ctx->stream, U, Np, ctx->bstride);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
 }
 int transpose_upper_launch(gpry_ctx* ctx, const double* U, double* V, int64_t Np) {
     const unsigned nb = (unsigned)(Np / 64);

@@ -286,7 +286,7 @@ int sweep_gemm_dma_sp_launch(gpry_ctx* ctx, const GemmArgs& g);  // sweep_gemm.h
 // ---- kernel_build.hip --------------------------------------------------------------
 int upload_params(gpry_ctx* ctx, const double* theta);
 int launch_scale_train(gpry_ctx* ctx);                         // dXs from dX and theta
-int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise); // full symmetric K
+int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise, double* U = nullptr); // full symmetric K; U (nullable): the identity's tiles on and right of the diagonal (potrf_stacked)
 int launch_kernel_rows(gpry_ctx* ctx, int64_t row0, int k, int64_t ldk, double* Bk, double* Cb);   // border rows of K
 int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
                        int64_t ldk, double* Kst, double* mean_part, int raw_affine,
@@ -315,7 +315,6 @@ int potrf_lower_fused(gpry_ctx* ctx, double* A, int64_t Np);       // panel step
 int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np);
 int potrf_stacked(gpry_ctx* ctx, double* A, double* U, int64_t Np);      // A <- L, U <- L^-T (U: the identity on entry)
 bool potrf_stacked_usable(const gpry_ctx* ctx, int64_t Np);
-int set_identity_launch(gpry_ctx* ctx, double* U, int64_t Np);
 int transpose_upper_launch(gpry_ctx* ctx, const double* U, double* V, int64_t Np);     // panel step + earlier trailing tiles in ONE launch; above Np = 3584 segment by segment (default)
 int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np);
 // V = L^-1 queued phase by phase underneath potrf (chol.hip); begin returns 1 when the size is not cut

@@ -83,7 +83,7 @@ __device__ __forceinline__ void nt_store2(double2* p, double a, double b) {
 template <int KID>
 __global__ __launch_bounds__(256, 6) void kernel_train_q_kernel(
     const double* __restrict__ Xs_, const double* __restrict__ noise, double* __restrict__ K_,
-    int64_t ld, KernParams kp, int add_noise, const double* __restrict__ bpar, int64_t bstride) {
+    int64_t ld, KernParams kp, int add_noise, const double* __restrict__ bpar, int64_t bstride, double* __restrict__ U_, int u_full) {
     constexpr int TS = 64, WPR = TS / 32, NT = WPR * WPR * 64;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     // batched launch (gpry_ctx::bn): theta blockIdx.z builds its own K from its own scaled coordinates and constant
@@ -101,6 +101,21 @@ __global__ __launch_bounds__(256, 6) void kernel_train_q_kernel(
     double* Xj = sm + TS * ldx;   // [TS][ldx]
     int bi, bj; tri_decode(blockIdx.x, &bi, &bj);
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, lx = lane & 7, ly = lane >> 3;
+    if (U_ != nullptr) {
+        // (potrf_stacked, chol_panel.hip: the matrix that is appended to K starts as the identity -- tile (bj, bi) of it goes out
+        // with tile (bi, bj) of K, first, so that the stores are under way while the coordinates are staged; further left of
+        // its diagonal than one tile nothing is ever read)
+        double* __restrict__ U = bset(U_, (int)blockIdx.z, bstride);
+        for (int e = t; e < TS * (TS / 2); e += NT) {
+            const int i = e >> 5, j2 = (e & 31) * 2;
+            const double one = bi == bj ? 1.0 : 0.0;
+            nt_store2(reinterpret_cast<double2*>(U + ((int64_t)bj * TS + i) * ld + (int64_t)bi * TS + j2), j2 == i ? one : 0.0, j2 + 1 == i ? one : 0.0);
+            // (the tile left of a diagonal tile is read as well: row block a enters the chain at step a with the left-looking
+            // update of the strip before it, and a panel of two strips may start one strip left of a; the comparator without
+            // the zero structure reads everything)
+            if ((u_full && bi != bj) || bi == bj + 1) nt_store2(reinterpret_cast<double2*>(U + ((int64_t)bi * TS + i) * ld + (int64_t)bj * TS + j2), 0.0, 0.0);
+        }
+    }
     for (int e = t; e < TS * dp2; e += NT) {
         const int row = e / dp2, k2 = (e - row * dp2) * 2;
         *reinterpret_cast<double2*>(Xi + row * ldx + k2) = *reinterpret_cast<const double2*>(Xs + ((int64_t)bi * TS + row) * dp + k2);
@@ -167,13 +182,13 @@ __global__ __launch_bounds__(256, 6) void kernel_train_q_kernel(
     }
 }
 
-int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise) {
+int launch_kernel_train(gpry_ctx* ctx, double* K, int add_noise, double* U) {
     KernParams kp = make_kp(ctx);
     const int64_t nbq = ctx->Np / 64, ntq = nbq * (nbq + 1) / 2;
     const size_t smq = sizeof(double) * (size_t)(2 * 64 * (ctx->dpad + 2));
     const dim3 gq((unsigned)ntq, 1, (unsigned)ctx->bn);
 #define KQ(KID) hipLaunchKernelGGL((kernel_train_q_kernel<KID>), gq, dim3(256), smq, ctx->stream, ctx->dXs, ctx->dnoise, K, ctx->Np, kp, \
-                                   add_noise, ctx->bpar, ctx->bstride)
+                                   add_noise, ctx->bpar, ctx->bstride, U, ctx->opt_chol_stacked_dense)
     DISPATCH_KID(ctx->kernel_id, KQ)
 #undef KQ
     HIP_TRY(ctx, hipGetLastError());
