@@ -96,6 +96,7 @@ SIGNATURES = {
     "gpry_group_lml_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "gpry_timing_reset": (C.c_int, [_vp]),
     "gpry_timing_get": (C.c_int, [_vp, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
+    "gpry_sweep_info": (C.c_int, [_vp, _P(C.c_int), _vp]),
     "gpry_microbench": (C.c_int, [_vp, C.c_int, C.c_int64, _P(C.c_double)]),
     "gpry_debug_gemm": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 9),
     "gpry_debug_logexp": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.c_double, _vp]),
@@ -439,6 +440,17 @@ class Device:
         self.sweep_epoch = getattr(self, "sweep_epoch", 0) + 1    # the resident arrays changed
         self._sweep_M = M
         return out
+
+    PANEL_FORMS = {0: "none", 1: "mfma", 2: "difference", 3: "small"}
+
+    def sweep_info(self):
+        """How the cross-kernel panel of the last sweep / panel predict was built (``gpry_sweep_info``) and the error
+        estimates of the model that decided it."""
+        form = C.c_int(0)
+        est = np.zeros(4)
+        self._check(self._lib.gpry_sweep_info(self._h, C.byref(form), _ptr(est)), "gpry_sweep_info")
+        return {"panel_form": self.PANEL_FORMS.get(form.value, str(form.value)), "panel_error_estimate": float(est[0]),
+                "panel_error_mean_worst_case": float(est[1]), "panel_error_variance": float(est[2]), "panel_gate": float(est[3])}
 
     def sweep_fetch(self, want=("y", "sigma")):
         """Arrays of the last sweep that are still resident on the device."""

@@ -174,6 +174,7 @@ static int append_chunk(gpry_ctx* ctx, const double* Xn, const double* yn, const
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dy + N0, yn, sizeof(double) * k, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dnoise + N0, an, sizeof(double) * k, hipMemcpyHostToDevice, st));
     ctx->N = N0 + k;
+    for (int a = 0; a < k; a++) if (an[a] < ctx->noise_min) ctx->noise_min = an[a];
     // centre of the MFMA panel build: the running sums continue in row order, so that a context that grew by border rows
     // holds the centre -- to the bit -- of one that received the whole set at once (members of a device group do)
     for (int a = 0; a < k; a++)

@@ -250,6 +250,7 @@ static int trtri_plan_get(gpry_ctx* ctx, int64_t Np, TrtriPlan** out) {
 static int trtri_level_nsplit(gpry_ctx* ctx, const TrtriPlan* pl, size_t lev) {
     // the top levels are a handful of long tiles: split their K range so that the launch fills
     // the GPU (512 resident workgroups) and its critical path shrinks accordingly
+    if (ctx->tp) return 1;              // throughput schedule: whole tiles only (the thetas of the call fill the GPU)
     const int tm = (pl->maxM[lev] + 127) / 128, tn = (pl->maxN[lev] + 127) / 128;
     const int64_t tiles = (int64_t)tm * tn * pl->count[lev];
     int nsplit = 1;
@@ -264,7 +265,7 @@ static int trtri_level_products(gpry_ctx* ctx, const double* L, double* V, doubl
                                 const GemmBatchItem* d_t, int n_t, int mM_t, int mN_t,
                                 const GemmBatchItem* d_v, int n_v, int mM_v, int mN_v, hipStream_t st,
                                 const GemmPartsPlan* sk_t = nullptr, const GemmPartsPlan* sk_v = nullptr) {
-    if (sk_t && sk_v && Np <= ctx->opt_gemm_streamk) {       // stream-K launches (gemm_dma.hip)
+    if (sk_t && sk_v && Np <= ctx->opt_gemm_streamk && !ctx->tp) {       // stream-K launches (gemm_dma.hip)
         if (n_t > 0) {
             GemmArgs g = {};
             g.A = L; g.lda = Np; g.B = V; g.ldb = Np; g.C = T; g.ldc = Np;
@@ -469,7 +470,7 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
     // tiles) and 2830 -> 3000 us at 8192 (2080), where one workgroup per tile already fills the GPU for several
     // rounds and the longest-first tile order keeps the tail short (tools/ab_factor_pipeline.py; giving every XCD a
     // contiguous run of segments instead of every eighth changes nothing).  The plan lives with the V = L^-1 plan.
-    if (Np >= 512 && Np <= ctx->opt_gemm_streamk) {
+    if (Np >= 512 && Np <= ctx->opt_gemm_streamk && !ctx->tp) {
         TrtriPlan* pl = nullptr;
         GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
         GemmArgs g = {};
@@ -488,7 +489,7 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
     // Np = 8192 (2080 tiles) it costs 5 %.
     const int64_t tiles = (Np / 128) * (Np / 128 + 1) / 2;
     int nsplit = 1;
-    while (nsplit < 4 && tiles * nsplit * 2 <= 1100 && Np / (nsplit * 2) >= 256) nsplit *= 2;
+    while (!ctx->tp && nsplit < 4 && tiles * nsplit * 2 <= 1100 && Np / (nsplit * 2) >= 256) nsplit *= 2;
     if (nsplit > 1) {
         double* sbuf = nullptr;
         GPRY_TRY(gemm_split_scratch(ctx, nsplit, Np * Np, &sbuf));
@@ -501,6 +502,7 @@ int lauum_lower(gpry_ctx* ctx, const double* V, double* Kinv, int64_t Np) {
 // Split-K slices (of Np x Np doubles each) that V = L^-1 followed by K^-1 = V^T V ask of gemm_split_scratch at this size:
 // what a batched evaluation reserves per theta before the first launch (its arena is never re-allocated under way).
 int factor_chain_slices(gpry_ctx* ctx, int64_t Np, int* slices) {
+    if (ctx->tp) { *slices = 0; return 0; }     // throughput schedule: no partial slices anywhere
     TrtriPlan* pl = nullptr;
     GPRY_TRY(trtri_plan_get(ctx, Np, &pl));
     int m = 1;
@@ -647,6 +649,7 @@ __global__ __launch_bounds__(1024) void logdet_quad_kernel(const double* __restr
         if (host_res) {
             host_res[0] = r0[0]; host_res[1] = r1[0];
             host_res[info_at] = (double)info[0]; host_res[info_at + 1] = (double)info[1];
+                host_res[info_at + 2] = (double)info[3];       // (0x5A..: a bounded wait of the panel step ran out -- not a verdict on the matrix)
         }
     }
 }

@@ -619,6 +619,8 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
     __syncthreads();
     PANEL_STAMP(5);
     PANEL_PROGRESS(41);
+    if ((pa.flags & 64) && is_diag && t == 0) *s_abort = 0x7E;      // test hook ("panel_debug" = 64): as if a bounded wait had run out
+    if (pa.flags & 64) __syncthreads();
     if (*s_abort != 0) {            // a bounded wait ran out (never seen; kept so that a protocol error cannot hang the GPU)
         if (t == 0) { atomicCAS(info, 0, (int)(pa.col0 + j0 + 1 <= n_real ? pa.col0 + j0 + 1 : n_real)); info[3] = 0x5A00 + *s_abort; }
         return;
@@ -653,9 +655,9 @@ __device__ __forceinline__ void panel_step_body(const PanelArgs& pa, double* sme
 // One 64 x 64 tile of a trailing update, C -= A_r P^T with the 128 columns of one panel: both operand
 // images (64 rows x 128 k, row stride 130 doubles: conflict-free fragment reads) sit in LDS at once; the eight waves
 // (round 5; four until then, a 32 x 32 quadrant each) own a 16 x 32 piece each (1 x 2 MFMA tiles, 32 k-steps): two waves to
-// a SIMD, one's fragment reads under the other's MFMAs.  Per element the same MFMA sequence from a
-// zero accumulator and the same single rounding of C - acc as the 128 x 128 SYRK tile of the separate
-// trailing launches: bit-identical.  Small on purpose: shorter than a panel step, so that tiles
+// a SIMD, one's fragment reads under the other's MFMAs.  Per element the continuation of ONE MFMA chain that
+// starts at the covariance entry, k ascending -- as in the SYRK launches of the GEMM engines (EPI_SUB) and the
+// left-looking update of the panel step: every schedule of the factorisation gives the same bits.  Small on purpose: shorter than a panel step, so that tiles
 // riding in a panel launch never set its length (a lone 128 x 128 x 128 tile takes 32-36 us).
 #define S64 130
 // n consecutive panels (128 columns apart) in one visit, then (half != 0) the 64 columns at ha_off / hb_off: the first
@@ -675,14 +677,16 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
     const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
     // C/D fragment: row = g + 4q, col = r.  The 8 old values of this lane stay in registers over the visit.
     double* cbase = Ar + it.c_off + (int64_t)(wr * 16 + g) * ld + wc * 32 + r;
-    double val[2][4];
+    // ONE MFMA chain per element over all panels it ever receives, k ascending, started at the covariance entry (round 6): the
+    // accumulators take -C, the products of this visit's panels are added, -acc goes back -- the continuation of the chain the
+    // earlier visits left, whatever launch they rode in (see gemm_dma_body.h: EPI_SUB).
+    v4d acc[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) val[ni][q] = cbase[(int64_t)(4 * q) * ld + ni * 16];
+        for (int q = 0; q < 4; q++) acc[ni][q] = -cbase[(int64_t)(4 * q) * ld + ni * 16];
     if (diag) sB = sA;
-    // A lagging tile takes several pending panels in one visit: each one accumulated from zero and subtracted
-    // with one rounding, in order -- the values a store / reload between them would give.
+    // A lagging tile takes several pending panels in one visit, in order.
     const int nvisit = (int)it.n + (with_half ? 1 : 0);
 #pragma unroll 1
     for (int u = 0; u < nvisit; u++) {
@@ -709,9 +713,6 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        v4d acc[2];
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++) acc[ni] = (v4d){0.0, 0.0, 0.0, 0.0};
         const double* pa = sA + (wr * 16 + r) * S64 + g;
         const double* pb = sB + (wc * 32 + r) * S64 + g;
 #pragma unroll 1
@@ -724,15 +725,11 @@ __device__ __forceinline__ void syrk64_tile_body(double* __restrict__ A, int64_t
                 acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) val[ni][q] = val[ni][q] - acc[ni][q];
     }
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) cbase[(int64_t)(4 * q) * ld + ni * 16] = val[ni][q];
+        for (int q = 0; q < 4; q++) cbase[(int64_t)(4 * q) * ld + ni * 16] = -acc[ni][q];
 }
 
 // Loads of the COMPACT panel step (512 threads, below).  D and P_t (what the factor waits for) go to LDS through all eight
@@ -947,6 +944,8 @@ __device__ __forceinline__ void panel_step_compact(const PanelArgs& pa, double* 
     __syncthreads();
     PANEL_STAMP(5);
     PANEL_PROGRESS(41);
+    if ((pa.flags & 64) && is_diag && t == 0) *s_abort = 0x7E;      // test hook ("panel_debug" = 64): as if a bounded wait had run out
+    if (pa.flags & 64) __syncthreads();
     if (*s_abort != 0) {            // a bounded wait ran out (never seen; kept so that a protocol error cannot hang the GPU)
         if (t == 0) { atomicCAS(info, 0, (int)(pa.col0 + j0 + 1 <= n_real ? pa.col0 + j0 + 1 : n_real)); info[3] = 0x5A00 + *s_abort; }
         return;
@@ -982,8 +981,7 @@ __device__ __forceinline__ void panel_step_compact(const PanelArgs& pa, double* 
 // (64 rows x 64 k each, row stride 66 doubles: conflict-free fragment reads) take 68 KB of LDS, so TWO tile workgroups share a
 // CU and one's LDS-DMA runs under the other's MFMAs (until round 4 both operands of all 128 k sat in LDS at once, 133 KB: one
 // workgroup per CU, which waited for its own DMA).  The eight waves own a 16 x 32 piece each (1 x 2 MFMA tiles).  Per element
-// the same MFMA sequence from a zero accumulator (k ascending over both halves) and the same single rounding of C - acc as the
-// 128 x 128 SYRK tile of the separate trailing launches: bit-identical.
+// the continuation of the element's one MFMA chain (k ascending), as in syrk64_tile_body: bit-identical.
 #define S64C 66
 __device__ __forceinline__ void syrk64_tile_compact(double* __restrict__ A, int64_t ld, const TileItem it, double* smem,
                                                  const int* info, const int64_t aug_delta) {
@@ -999,16 +997,15 @@ __device__ __forceinline__ void syrk64_tile_compact(double* __restrict__ A, int6
     const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
     // C/D fragment: row = g + 4q, col = r.  The 8 old values of this lane stay in registers over the visit.
     double* cbase = Ar + it.c_off + (int64_t)(wr * 16 + g) * ld + wc * 32 + r;
-    double val[2][4];
+    v4d acc[2];         // the element's one MFMA chain, resumed at -C (see syrk64_tile_body)
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) val[ni][q] = cbase[(int64_t)(4 * q) * ld + ni * 16];
+        for (int q = 0; q < 4; q++) acc[ni][q] = -cbase[(int64_t)(4 * q) * ld + ni * 16];
     if (diag) sB = sA;
     const double* pa = sA + (wr * 16 + r) * S64C + g;
     const double* pb = sB + (wc * 32 + r) * S64C + g;
-    // A lagging tile takes several pending panels in one visit: each one accumulated from zero and subtracted
-    // with one rounding, in order -- the values a store / reload between them would give.
+    // A lagging tile takes several pending panels in one visit, in order.
     const int nvisit = (int)it.n + (with_half ? 1 : 0);
     bool first = true;
 #pragma unroll 1
@@ -1017,9 +1014,6 @@ __device__ __forceinline__ void syrk64_tile_compact(double* __restrict__ A, int6
         const double* Ag = half ? Ar + it.ha_off : Ar + it.a_off + (int64_t)u * 128;
         const double* Bg = half ? A + it.hb_off : A + it.b_off + (int64_t)u * 128;
         const int kd = half ? 64 : 128;
-        v4d acc[2];
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++) acc[ni] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
         for (int kc = 0; kc < kd; kc += 64) {       // k ascending, 64 at a time
             if (!first) __syncthreads();        // everybody has read the previous images
@@ -1049,15 +1043,11 @@ __device__ __forceinline__ void syrk64_tile_compact(double* __restrict__ A, int6
                 acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) val[ni][q] = val[ni][q] - acc[ni][q];
     }
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) cbase[(int64_t)(4 * q) * ld + ni * 16] = val[ni][q];
+        for (int q = 0; q < 4; q++) cbase[(int64_t)(4 * q) * ld + ni * 16] = -acc[ni][q];
 }
 
 // Fused step: the first P workgroups are the panel step, the others each take one 64 x 64 tile of an
@@ -1130,7 +1120,8 @@ static int panel_launch(gpry_ctx* ctx, ChainState& cs, double* A, int64_t ld, in
     const int n_top = (int)((n - j0) / 64);
     const int P = n_top + n_aug;
     cs.arrivals += P;
-    static const int panel_flags = getenv("GPRY_PANEL_FLAGS") ? atoi(getenv("GPRY_PANEL_FLAGS")) : 0;
+    static const int env_flags = getenv("GPRY_PANEL_FLAGS") ? atoi(getenv("GPRY_PANEL_FLAGS")) : 0;
+    const int panel_flags = env_flags | ctx->opt_panel_debug;
     PanelArgs pa = {A, ld, j0, Kfrom, ctx->N, col0, ctx->dinfo, ctx->dinfo + 2, cs.arrivals, ctx->bstride, panel_flags,
                     n_aug > 0 ? n_top : (1 << 30), aug_delta};
     // Two forms of the step, the same operations on every tile in the same order (bit-identical factors; every theta of a
@@ -1152,13 +1143,17 @@ static const int64_t LARGE_TAIL = 3584, HEAD_BLOCK = 768;       // grid of both 
 struct Segment { int64_t K0; int nrows, ncols; int first_launch; int naug = 0; bool aug_dense = false; };     // strips of 64; first_launch: index into the plan's per-launch lists;
                                                                                        // naug: row blocks of the appended matrix (potrf_stacked);
                                                                                        // aug_dense: without use of their zero structure (the comparator)
-static std::vector<Segment> segments_of(int64_t Np) {
+// (tail / block: LARGE_TAIL / HEAD_BLOCK for a single evaluation -- the latency optimum --, "tp_tail" / "tp_block" for the
+// throughput schedule of gpry_lml_batch, where the thetas of a call fill the GPU and what counts is that the multiply-adds run
+// in 128 x 128 tiles of the SYRK engine rather than in riding 64 x 64 tiles, which are bound by the L2.  Since every element is
+// ONE chain of MFMAs whatever launch its pieces ride in -- syrk64_tile_body, gemm_dma_body.h -- the cut changes no bit.)
+static std::vector<Segment> segments_of(int64_t Np, int64_t tail = LARGE_TAIL, int64_t block = HEAD_BLOCK) {
     std::vector<Segment> seg;
     int64_t K0 = 0;
     int launches = 0;
-    if (Np > LARGE_TAIL) {
-        // the fewest outer blocks of at most HEAD_BLOCK columns that leave at most LARGE_TAIL, all of the same width
-        const int64_t head = Np - LARGE_TAIL, nblk = (head + HEAD_BLOCK - 1) / HEAD_BLOCK;
+    if (Np > tail) {
+        // the fewest outer blocks of at most `block` columns that leave at most `tail`, all of the same width
+        const int64_t head = Np - tail, nblk = (head + block - 1) / block;
         const int64_t ob = round_up((head + nblk - 1) / nblk, 128);
         for (int64_t b = 0; b < nblk; b++, K0 += ob) {
             seg.push_back({K0, (int)((Np - K0) / 64), (int)(ob / 64), launches});
@@ -1231,12 +1226,13 @@ struct OverlapPlan {
     std::vector<int> first, count;      // per launch: slice of d_items
 };
 // plans per context: [0] the factorisation alone, [1] with the inverse factor as appended rows (potrf_stacked), [2] the same
-// without use of the zero structure of the appended rows (its comparator)
-struct OverlapPlans { OverlapPlan p[3]; };
+// without use of the zero structure of the appended rows (its comparator), [3] the factorisation alone in the column blocks
+// of the throughput schedule
+struct OverlapPlans { OverlapPlan p[4]; };
 void overlap_plan_free(gpry_ctx* ctx) {
     OverlapPlans* pl = static_cast<OverlapPlans*>(ctx->chol_plan);
     if (!pl) return;
-    for (int i = 0; i < 3; i++) if (pl->p[i].d_items) (void)hipFree(pl->p[i].d_items);
+    for (int i = 0; i < 4; i++) if (pl->p[i].d_items) (void)hipFree(pl->p[i].d_items);
     delete pl;
     ctx->chol_plan = nullptr;
 }
@@ -1338,7 +1334,7 @@ static bool plan_segment(const Segment& sg, int64_t ld, int ncu, std::vector<Til
     return true;
 }
 // returns 1 if no valid plan exists (the caller takes the schedule with separate trailing launches)
-static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out, int stacked = 0) {       // stacked: 0 no, 1 yes, 2 yes with dense appended rows
+static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out, int stacked = 0) {       // stacked: 0 no, 1 yes, 2 yes with dense appended rows, 3: no, throughput schedule
     if (!ctx->chol_plan) ctx->chol_plan = new OverlapPlans();
     OverlapPlan& pl = static_cast<OverlapPlans*>(ctx->chol_plan)->p[stacked];
     if (pl.Np == Np) { *out = &pl; return 0; }
@@ -1347,8 +1343,8 @@ static int overlap_plan_get(gpry_ctx* ctx, int64_t Np, OverlapPlan** out, int st
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
     std::vector<TileItem> items;
-    pl.seg = segments_of(Np);
-    if (stacked) {
+    pl.seg = stacked == 3 ? segments_of(Np, ctx->opt_tp_tail, ctx->opt_tp_block) : segments_of(Np);
+    if (stacked == 1 || stacked == 2) {
         if (pl.seg.size() != 1) { pl = OverlapPlan(); return 1; }      // (one segment: Np <= LARGE_TAIL)
         pl.seg[0].naug = pl.seg[0].nrows;
         pl.seg[0].aug_dense = stacked == 2;
@@ -1405,7 +1401,9 @@ int potrf_stacked(gpry_ctx* ctx, double* A, double* U, int64_t Np) {
     return 0;
 }
 bool potrf_stacked_usable(const gpry_ctx* ctx, int64_t Np) {
-    return ctx->opt_chol == 0 && ctx->opt_chol_overlap && Np <= ctx->opt_chol_stacked && Np <= LARGE_TAIL && Np >= 128;
+    // (the throughput schedule of gpry_lml_batch takes the recursive inverse: in a batch its products are plain GEMM launches that
+    // fill the GPU, while the appended rows double the panel workgroups of every step -- profiles/r06_batch.md)
+    return ctx->opt_chol == 0 && ctx->opt_chol_overlap && Np <= ctx->opt_chol_stacked && Np <= LARGE_TAIL && Np >= 128 && !ctx->tp;
 }
 
 // V <- U^T behind potrf_stacked: V lower triangular with zeros above, as the recursive inverse leaves it.  64 x 64 tiles
@@ -1446,7 +1444,7 @@ int transpose_upper_launch(gpry_ctx* ctx, const double* U, double* V, int64_t Np
 
 int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
     OverlapPlan* pl = nullptr;
-    const int prc = overlap_plan_get(ctx, Np, &pl);
+    const int prc = overlap_plan_get(ctx, Np, &pl, ctx->tp || ctx->opt_chol_tp_segments ? 3 : 0);
     if (prc == 1) return potrf_lower_fused(ctx, A, Np);
     if (prc) return prc;
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));

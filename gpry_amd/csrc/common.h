@@ -68,6 +68,22 @@ struct gpry_ctx {
                                        // against the thread farm of three contexts: full fits 2.2x faster at N = 1024, 1.4x at 2048,
                                        // 1.1x at 4096, 0.9x at 8192 (tools/r04/time_fit_crossover.py, bench.py --workload farm)
     int64_t opt_lml_batch_mb = 49152;  // upper limit of the arena (MiB of the 288 GB): longer batches go through in chunks
+    // Schedule of gpry_lml_batch (option "lml_schedule"): 0 = latency -- every theta gets the launches, and the bits, of a single
+    // gpry_lml (stream-K / split-K partial sums, the inverse factor out of the Cholesky launches up to "chol_stacked"); 1 =
+    // throughput -- the chain for MANY thetas at once: whole-tile products only (no partial slices to write and add), the
+    // Cholesky in column blocks with one MFMA SYRK launch behind each, the thetas dealt over "lml_streams" streams so that one
+    // group's panel chain runs underneath the other groups' products.  Its per-theta result does not depend on how many thetas
+    // share the call (B = 1 included) and differs from the latency schedule's by rounding (another summation order).
+    int opt_lml_schedule = 0;
+    int opt_lml_streams = 2;           // throughput schedule: stream groups per call (1: one chain for all thetas)
+    int64_t opt_tp_block = 512;        // throughput schedule: width of the column blocks of the Cholesky (multiple of 128)
+    int64_t opt_tp_tail = 1024;        // ... and the size of the last block, factored with riding tiles only
+    int64_t batch_shrinks = 0;         // times a batched evaluation halved its chunk after an out-of-memory answer (diagnostic, gpry_timing_get "lml_batch_shrinks")
+    int opt_chol_tp_segments = 0;      // 1: every factorisation of the context takes the column blocks of the throughput schedule (comparator: same bits)
+    int opt_panel_debug = 0;           // ORed into GPRY_PANEL_FLAGS (chol_panel.hip); 64: the diagonal workgroup of every panel step reports a timed-out wait (test hook)
+    bool tp = false;                   // a throughput-schedule chain is being queued (set by lml_batch_general only)
+    std::vector<hipStream_t> tp_streams;   // the extra streams of the groups (created on first use)
+    std::vector<hipEvent_t> tp_events;
 
     double* dX = nullptr;      // N x d raw transformed training rows (row-major, ld = d)
     double* dXs = nullptr;     // Np x dpad rows scaled by 1/l (pad rows = 0)
@@ -109,6 +125,10 @@ struct gpry_ctx {
     double xlo[GPRY_MAX_DIM] = {0}, xhi[GPRY_MAX_DIM] = {0};     // smallest / largest training coordinate per dimension (error estimate of the MFMA panel)
     int opt_cross_mfma = 1;    // 1 (default): the sweep's cross-kernel panel takes its distances from the matrix pipe
     double alpha_l2 = -1.0;    // ||alpha_||_2 of the prediction factor (fetched when the panel form is chosen; < 0: not yet)
+    double alpha_l1 = 0.0;     // ||alpha_||_1, fetched with it
+    double noise_min = 0.0;    // smallest entry of the noise vector `alpha` of the training rows (set_train, append_rows): lambda_min(K) >= it
+    int panel_form = 0;        // cross-kernel panel of the last sweep / panel predict: 0 none yet, 1 matrix pipe, 2 difference form, 3 small-batch kernel
+    double panel_est[4] = {0, 0, 0, 2.5e-7};   // its error estimates: mean (l2, gated), mean (l1, worst case), variance / C (gated), the gate
     double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
     int64_t kst_cap = 0;       // doubles allocated
     double* dG = nullptr;      // Np x dpad: d k(x, X_j)/dx of the last gpry_predict_grad
@@ -182,7 +202,7 @@ int gpry_fail(gpry_ctx* ctx, int code, const char* fmt, ...);
 
 // scoped device timing of one stage on ctx->stream
 struct StageScope {
-    gpry_ctx* ctx; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr;
+    gpry_ctx* ctx; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr; bool marked = false;
     StageScope(gpry_ctx* c, const char* n, hipStream_t stream = nullptr);
     ~StageScope();
 };

@@ -2,6 +2,7 @@
 #include "common.h"
 #include <string>
 #include <stdarg.h>
+#include <dlfcn.h>
 
 // per thread: concurrent optimiser restarts drive distinct contexts from distinct host threads
 thread_local char g_last_error[1024] = {0};
@@ -37,13 +38,44 @@ int dev_free(gpry_ctx* ctx, void* p) {
     return 0;
 }
 
+// roctx ranges around the stages (the reference's Timer / TimerCounter, gpry/progress.py:243-284, as marker ranges that
+// rocprofv3 --marker-trace shows next to the kernels): off unless GPRY_HIP_ROCTX=1; libroctx64.so is looked up at run time,
+// the library has no link-time dependency on it.  A range covers the host-side queueing of a stage's launches.
+namespace {
+struct Roctx {
+    bool tried = false, on = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+} g_roctx;
+bool roctx_on() {
+    if (!g_roctx.tried) {
+        g_roctx.tried = true;
+        const char* e = getenv("GPRY_HIP_ROCTX");
+        if (e && atoi(e) != 0) {
+            void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (lib) {
+                g_roctx.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+                g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
+                g_roctx.on = g_roctx.push && g_roctx.pop;
+            }
+            if (!g_roctx.on) fprintf(stderr, "gpry: GPRY_HIP_ROCTX=1 but libroctx64.so could not be loaded: no marker ranges\n");
+        }
+    }
+    return g_roctx.on;
+}
+}  // namespace
+
 StageScope::StageScope(gpry_ctx* c, const char* n, hipStream_t stream) : ctx(c), name(n) {
     st = stream ? stream : ctx->stream;
+    if (roctx_on()) { g_roctx.push(name); marked = true; }
     if (!ctx->opt_timing) return;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
     (void)hipEventRecord(e0, st);
 }
 StageScope::~StageScope() {
+    if (marked) g_roctx.pop();
     if (!e0) return;
     (void)hipEventRecord(e1, st);
     auto& tm = ctx->timers[name];
@@ -116,9 +148,11 @@ int ensure_capacity(gpry_ctx* ctx, int64_t N, int d) {
         if (ctx->dU) { GPRY_TRY(dev_free(ctx, ctx->dU)); ctx->dU = nullptr; }
         if (ctx->dXkb) { GPRY_TRY(dev_free(ctx, ctx->dXkb)); ctx->dXkb = nullptr; }
     }
-    // the scratch arena of the batched objective is sized for the padded size it was last used with: a smaller model gives
-    // the memory back (the next gpry_lml_batch allocates what it needs)
-    if (ctx->barena && Np < ctx->Np) {
+    // the scratch arena of the batched objective is sized for the padded size it was last used with: a model of less than
+    // half that footprint gives the memory back (the next gpry_lml_batch allocates what it needs).  A model whose size
+    // moves back and forth across a padding boundary keeps its arena: freeing and allocating tens of GB per fit cost more
+    // than the memory is worth.
+    if (ctx->barena && 2 * Np * Np < ctx->Np * ctx->Np) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(ctx->barena);
         ctx->barena = nullptr; ctx->barena_cap = 0;
@@ -214,6 +248,8 @@ int gpry_ctx_destroy(gpry_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
+    for (hipStream_t st : ctx->tp_streams) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : ctx->tp_events) (void)hipEventDestroy(ev);
     delete ctx;
     return 0;
 }
@@ -254,6 +290,12 @@ const OptionSpec OPTIONS[] = {
     OPT_INT("lml_cache", opt_lml_cache, 0, 1, c->lml_cache = false),
     OPT_INT("lml_batch", opt_lml_batch, 0, BIG, (void)0),
     OPT_INT("lml_batch_mb", opt_lml_batch_mb, 1, BIG, (void)0),
+    OPT_INT("lml_schedule", opt_lml_schedule, 0, 1, (void)0),
+    OPT_INT("lml_streams", opt_lml_streams, 1, 8, (void)0),
+    OPT_INT("chol_tp_segments", opt_chol_tp_segments, 0, 1, c->lml_cache = false),
+    OPT_INT("panel_debug", opt_panel_debug, 0, 255, c->lml_cache = false),
+    OPT_INT("tp_block", opt_tp_block, 128, BIG, c->opt_tp_block = round_up(c->opt_tp_block, 128); overlap_plan_free(c)),
+    OPT_INT("tp_tail", opt_tp_tail, 128, BIG, c->opt_tp_tail = round_up(c->opt_tp_tail, 128); overlap_plan_free(c)),
     OPT_INT("predict_small", opt_predict_small, 0, BIG, (void)0),
     OPT_INT("predict_split", opt_predict_split, 0, 1, (void)0),
     OPT_INT("sweep_upload", opt_sweep_upload, 0, 1, (void)0),
@@ -309,6 +351,11 @@ int gpry_set_train(gpry_ctx* ctx, const double* X_, const double* y_, const doub
         ctx->xsum[k] = s;
         ctx->xcenter[k] = s / (double)N;
         ctx->xlo[k] = lo; ctx->xhi[k] = hi;
+    }
+    {
+        double nm = alpha[0];
+        for (int64_t i = 1; i < N; i++) nm = alpha[i] < nm ? alpha[i] : nm;
+        ctx->noise_min = nm;
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dX, X_, sizeof(double) * N * d, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dy, 0, sizeof(double) * ctx->Np, st));

@@ -164,11 +164,27 @@ __device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* sm
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 15, gq = lane >> 4;
 
+    // EPI_SUB (the trailing updates of the Cholesky): C - sum_k a b as ONE chain that starts at C -- the accumulators take -C,
+    // the products are added, the result is stored negated (round-to-nearest is symmetric in sign: the bits of C - a b - ...).
+    // A chain cut at a multiple of 4 k and resumed from the stored tile is the same chain, so every schedule of the
+    // factorisation -- riding 64 x 64 tiles, column blocks with one launch behind each, left-looking panel steps -- gives the
+    // same factor bit for bit (chol_panel.hip).  The old values go out first: loads return in order, so the wait for the
+    // first slab of the DMA below covers them.
+    double* const cbase = C + (int64_t)(row0 + wr * 64 + gq) * g.ldc + col0 + wc * 64 + r;
     v4d acc[4][4];
+    if (EPI == EPI_SUB && !partial) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[i][j][q] = -cbase[(int64_t)(i * 16 + 4 * q) * g.ldc + j * 16];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
 
     if (nslab > 0) {
     // per-lane source addresses of this wave's 4 + 4 DMA pieces of a slab
@@ -268,34 +284,15 @@ __device__ __forceinline__ void gemm_dma_tile_body(const GemmArgs& g, double* sm
     }  // nslab > 0
 
     // ---- epilogue.  f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4*reg.
-    // The read-modify-write epilogue fetches the 32 old values of two 16-row blocks first and stores
-    // afterwards: written element by element the compiler (which cannot exclude aliasing) waits for
-    // every load before the next store, 64 memory round trips per tile.
-    double* const cbase = C + (int64_t)(row0 + wr * 64 + gq) * g.ldc + col0 + wc * 64 + r;
 #pragma unroll
-    for (int mh = 0; mh < 4; mh += 2) {
-        double old[2][4][4];
-        if (EPI == EPI_SUB && !partial) {
+    for (int mi = 0; mi < 4; mi++)
 #pragma unroll
-            for (int m2 = 0; m2 < 2; m2++)
+        for (int ni = 0; ni < 4; ni++)
 #pragma unroll
-                for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        old[m2][ni][q] = cbase[(int64_t)((mh + m2) * 16 + 4 * q) * g.ldc + ni * 16];
-        }
-#pragma unroll
-        for (int m2 = 0; m2 < 2; m2++)
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    double* p = cbase + (int64_t)((mh + m2) * 16 + 4 * q) * g.ldc + ni * 16;
-                    const double v = acc[mh + m2][ni][q];
-                    if (EPI == EPI_STORE || partial) *p = v;
-                    else if (EPI == EPI_STORE_NEG) *p = -v;
-                    else *p = old[m2][ni][q] - v;
-                }
-    }
+            for (int q = 0; q < 4; q++) {
+                double* p = cbase + (int64_t)(mi * 16 + 4 * q) * g.ldc + ni * 16;
+                const double v = acc[mi][ni][q];
+                if (EPI == EPI_STORE || partial) *p = v;
+                else *p = -v;           // EPI_STORE_NEG; EPI_SUB: the chain ran on -C
+            }
 }
-

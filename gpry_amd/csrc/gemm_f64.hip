@@ -133,11 +133,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 15, gq = lane >> 4;
 
+    // EPI_SUB: one chain that starts at -C (see gemm_dma_body.h)
     v4d acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < 4; j++) {
+            acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (EPI == EPI_SUB && g.nsplit <= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = row0 + wr * 64 + i * 16 + gq + 4 * q, col = col0 + wc * 64 + j * 16 + r;
+                    if (row < M && col < N) acc[i][j][q] = -C[(int64_t)row * g.ldc + col];
+                }
+            }
+        }
 
     double ra[8], rb[8];
     auto load_slab = [&](int s) {
@@ -211,21 +221,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
         return;
     }
-    // read-modify-write: the 16 old values of a 16-row block are fetched before the first store (the
-    // compiler cannot exclude aliasing and would otherwise wait for every load in turn)
 #pragma unroll
-    for (int mi = 0; mi < 4; mi++) {
-        double old[4][4];
-        if (EPI == EPI_SUB && g.nsplit <= 1) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    int row = row0 + wr * 64 + mi * 16 + gq + 4 * q;
-                    int col = col0 + wc * 64 + ni * 16 + r;
-                    old[ni][q] = (row < M && col < N) ? C[(int64_t)row * g.ldc + col] : 0.0;
-                }
-        }
+    for (int mi = 0; mi < 4; mi++)
 #pragma unroll
         for (int ni = 0; ni < 4; ni++)
 #pragma unroll
@@ -236,11 +233,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     double* p = C + (int64_t)row * g.ldc + col;
                     double v = acc[mi][ni][q];
                     if (EPI == EPI_STORE || g.nsplit > 1) *p = v;
-                    else if (EPI == EPI_STORE_NEG) *p = -v;
-                    else *p = old[ni][q] - v;
+                    else *p = -v;       // EPI_STORE_NEG; EPI_SUB: the chain ran on -C
                 }
             }
-    }
 }
 
 // C = sign * sum over the split-K slices, same tile map / batch / lower_only logic as the product

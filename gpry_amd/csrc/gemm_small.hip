@@ -6,7 +6,7 @@
 // MFMA tiles) owns a 64 x 64 tile, so the same product is spread over four times as many CUs; k advances in slabs of
 // 32 (global -> registers -> LDS, double buffered), which halves the number of exposed load latencies of these
 // short k-ranges.  Same operation order per output element as the 128-tile engines (k ascending in MFMA steps of 4
-// from a zero accumulator; the extra leading / trailing steps a coarser tile origin brings in multiply structural
+// from a zero accumulator -- EPI_SUB: from -C --; the extra leading / trailing steps a coarser tile origin brings in multiply structural
 // zeros of the triangular operand), hence the same bits.  Requires every M, N a multiple of 64 and K of 32
 // (GemmArgs.small64, set by the callers that guarantee it).
 #include "common.h"
@@ -72,11 +72,19 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 15, gq = lane >> 4;
+    // EPI_SUB: one chain that starts at -C (see gemm_dma_body.h)
     v4d acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < 2; j++) {
+            acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (EPI == EPI_SUB) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    acc[i][j][q] = -C[(int64_t)(row0 + wr * 32 + i * 16 + gq + 4 * q) * g.ldc + col0 + wc * 32 + j * 16 + r];
+            }
+        }
 
     double ra[8], rb[8];
     auto load_slab = [&](int s) {
@@ -116,16 +124,6 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
         __syncthreads();
     }
     // epilogue.  f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-    double old[2][2][4];
-    if (EPI == EPI_SUB) {
-#pragma unroll
-        for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    old[mi][ni][q] = C[(int64_t)(row0 + wr * 32 + mi * 16 + gq + 4 * q) * g.ldc + col0 + wc * 32 + ni * 16 + r];
-    }
 #pragma unroll
     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
@@ -135,8 +133,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
                 double* p = C + (int64_t)(row0 + wr * 32 + mi * 16 + gq + 4 * q) * g.ldc + col0 + wc * 32 + ni * 16 + r;
                 const double v = acc[mi][ni][q];
                 if (EPI == EPI_STORE) *p = v;
-                else if (EPI == EPI_STORE_NEG) *p = -v;
-                else *p = old[mi][ni][q] - v;
+                else *p = -v;           // EPI_STORE_NEG; EPI_SUB: the chain ran on -C
             }
 }
 

@@ -795,6 +795,7 @@ __global__ __launch_bounds__(256) void reduce_traces_kernel(const double* __rest
             if (k == 0) {
                 host_res[0] = lq[0]; host_res[1] = lq[1];
                 host_res[info_at] = (double)info[0]; host_res[info_at + 1] = (double)info[1];
+                host_res[info_at + 2] = (double)info[3];       // (0x5A..: a bounded wait of the panel step ran out -- not a verdict on the matrix)
             }
         }
     }

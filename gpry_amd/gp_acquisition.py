@@ -497,6 +497,20 @@ class NORA(GenericGPAcquisition):
         self.stats["sweep_s"] = time() - t0
         self.stats["sweep_M"] = M
         self.stats["sweep_contexts"] = getattr(dev, "size", 1) if grouped else 1
+        # which form of the cross-kernel panel the model's error estimates allowed (gpry_sweep_info): a fitted model that
+        # drops from the matrix-pipe form to the difference form sweeps ~1 % slower -- say so once instead of silently
+        info_dev = dev.member(0) if grouped and hasattr(dev, "member") else dev
+        if hasattr(info_dev, "sweep_info"):
+            info = info_dev.sweep_info()
+            self.stats.update(info)
+            # (estimates of 0: the gate was never evaluated -- Matern-1/2 always takes the difference form, option "cross_mfma" = 0)
+            if info["panel_form"] == "difference" and info["panel_error_estimate"] > 0 and \
+                    not getattr(NORA, "_warned_panel_form", False):
+                NORA._warned_panel_form = True
+                warnings.warn("gpry_amd: the cross-kernel panel of the sweep is built in the difference form for this model "
+                              f"(error estimates of the matrix-pipe form: mean {info['panel_error_estimate']:.2g}, variance "
+                              f"{info['panel_error_variance']:.2g} against a gate of {info['panel_gate']:.2g}); "
+                              "see acq.stats['panel_form']", RuntimeWarning)
         return y, s
 
     def _shortlist(self, gpr, K, exclude_global):

@@ -98,6 +98,16 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *     "lml_batch"             largest padded size at which gpry_lml_batch runs all its thetas through ONE chain of launches
  *                             (default 4096: beyond it the host's thread farm of three contexts is faster; 0 = one after another)
  *     "lml_batch_mb"          upper limit of the scratch arena of such a batch in MiB (default 49152; longer batches go in chunks)
+ *     "lml_schedule" 0/1      schedule of gpry_lml_batch above 128 rows.  0 (default) latency: every theta gets the launches -- and the
+ *                             bits -- of a single gpry_lml.  1 throughput: the chain for many thetas at once (whole-tile products only,
+ *                             the recursive inverse at every size, the Cholesky in column blocks with one SYRK launch behind each, the
+ *                             thetas dealt over "lml_streams" streams); a theta's result does not depend on how many thetas share the
+ *                             call (B = 1 included) and differs from the latency schedule's by rounding.  The host mirror sets it for
+ *                             the multi-restart fits (gpry/gpr.py:968-984)
+ *     "lml_streams" 1..8      throughput schedule: stream groups per call (default 2)
+ *     "tp_block", "tp_tail"   throughput schedule: width of the column blocks of the Cholesky (default 512) and size of the last
+ *                             block, factored with riding tiles only (default 1024); multiples of 128.  No bit depends on them
+ *     "chol_tp_segments" 0/1  1: every factorisation of the context takes those column blocks (comparator: the same factor bit for bit)
  *   predict / sweep (gpry/gpr.py:1022-1273, gpry/gp_acquisition.py:971-1108)
  *     "sweep_chunk"           candidates per sweep chunk, rounded up to a multiple of 1024 (default 0 = 32768 from 4096 padded
  *                             training rows on and proportionally more below: the K* panel of a chunk stays 1 GiB)
@@ -249,6 +259,14 @@ int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* 
                       double zeta, double baseline, double sigma_n,
                       double* y_all, double* sigma_all, double* acq_all,
                       int64_t* n_nan);
+/* How the cross-kernel panel K(X*, X_train) (gpry/gpr.py:1179) of the context's last sweep / panel predict was built, and the
+ * error estimates of the model that decided it.  *panel_form: 0 none yet, 1 distances from the matrix pipe (expanded form
+ * |x|^2 + |y|^2 - 2 x.y on centred coordinates), 2 difference form (as scipy's cdist), 3 the small-batch kernel (difference
+ * form).  est[0]: estimated error of the posterior mean in units of the normalised targets (entry error x ||alpha_||_2);
+ * est[1]: its worst case (x ||alpha_||_1); est[2]: estimated error of the posterior variance relative to the prior
+ * variance C (2 x entry error x the bound sqrt(C) / sigma_n,min of ||K^-1 k*||_2); est[3]: the gate both est[0] and est[2]
+ * must stay below for form 1 (2.5e-7, a quarter of the 1e-6 the posterior is specified to).  Either pointer may be NULL. */
+int gpry_sweep_info(gpry_ctx* ctx, int* panel_form, double* est);
 /* Host copies of the arrays of the last gpry_sweep_logexp that are still resident on the device
  * (any pointer may be NULL; M must be the size of that sweep).  Lets a caller skip the copies in
  * gpry_sweep_logexp and fetch them only if somebody asks (NORA.last_MC_sample). */
