@@ -285,6 +285,8 @@ static int lml_batch_general(gpry_ctx* ctx, const double* thetas, int64_t B, int
             hres[b * GPRY_BRES_STRIDE + RES_INFO] = -1.0; hres[b * GPRY_BRES_STRIDE + RES_INFO + 1] = -1.0;     // "not written"
         }
         for (int k = 0; k < w; k++) ctx->theta[k] = thetas[b0 * w + k];      // (the launchers read the sizes, not these, in a batch)
+        // test hook ("panel_debug" bit 7): every scratch set starts as NaNs -- a result that depended on what a set held before shows
+        if (ctx->opt_panel_debug & 128) HIP_TRY(ctx, hipMemsetAsync(a0, 0xFF, sizeof(double) * (size_t)(nb * L.stride), main_stream));
         HIP_TRY(ctx, hipMemcpy2DAsync(a0 + L.par, sizeof(double) * L.stride, hpar, sizeof(double) * (1 + GPRY_MAX_DIM),
                                       sizeof(double) * (1 + GPRY_MAX_DIM), (size_t)nb, hipMemcpyHostToDevice, main_stream));
         // Stream groups (throughput schedule): the panel chain of the Cholesky is one workgroup's latency per step whatever the
@@ -773,6 +775,7 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
         ctx->panel_est[1] = e * ctx->alpha_l1;
         ctx->panel_est[2] = ctx->noise_min > 0.0 ? 2.0 * e / (sqrt(ctx->noise_min) * sqrt(C)) : INFINITY;
         if (!(ctx->panel_est[0] <= ctx->panel_est[3]) || !(ctx->panel_est[2] <= ctx->panel_est[3])) fast_panel = false;
+        if (ctx->opt_panel_debug & 32) fast_panel = true;       // test hook: the matrix-pipe form whatever the estimates say
         if (fast_panel) ctx->panel_form = 1;
         if (getenv("GPRY_HIP_DEBUG_PANEL")) {
             fprintf(stderr, "gpry: panel form: C %.3g R2 %.3g |alpha|_2 %.3g |alpha|_1 %.3g min noise %.3g -> mean %.3g (l1 %.3g) var %.3g: %s; l =", C, R2,

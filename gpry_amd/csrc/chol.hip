@@ -325,7 +325,13 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
     // the 128 x 128 diagonal stage clear the blocks to the right of their own (a memset is one more dependent dispatch, 5 us
     // of an evaluation that takes 200 at N = 256); above, one memset of the matrix is cheaper than their row strips.
     const bool clear_in_diag = !single_wave && Np <= 1024;
-    if (!clear_in_diag && ctx->bn > 1) {
+    // The throughput schedule of gpry_lml_batch works on scratch sets nobody reads as matrices: what the products (128 x 128 or
+    // 64 x 64 tiles with 64-aligned origins and triangular k-ranges), K^-1 = V^T V and the alpha kernels touch above the
+    // diagonal is the 64 x 64 block right of every diagonal block and nothing else.  The diagonal stage writes those zeros
+    // itself (128-row leaves: the whole leaf block) -- no pass over the matrix (0.4 ms of 22 for 16 thetas at N = 4096).
+    const bool tp_min_clear = ctx->tp && !single_wave;
+    if (tp_min_clear) {
+    } else if (!clear_in_diag && ctx->bn > 1) {
         const int64_t n2 = Np * Np / 2;
         int64_t nb = (n2 + 2047) / 2048;          // 8 double2 per thread
         if (nb > 4096) nb = 4096;
@@ -340,9 +346,9 @@ int trtri_lower(gpry_ctx* ctx, const double* L, double* V, double* T, int64_t Np
         hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)(Np / 64)), dim3(64), 0, st, L, V, Np, ctx->dinfo);
         HIP_TRY(ctx, hipGetLastError());
     } else if (pl->leaf == 2) {         // (128 < Np <= 1024: exactly the sizes that clear in the diagonal stage)
-        GPRY_TRY(launch_trtri_diag128(ctx, L, V, Np, st, true));
+        GPRY_TRY(launch_trtri_diag128(ctx, L, V, Np, st, !tp_min_clear));
     } else {
-        GPRY_TRY(launch_trtri_diag(ctx, L, V, Np, st));
+        GPRY_TRY(launch_trtri_diag(ctx, L, V, Np, st, tp_min_clear));
     }
     for (size_t lev = 0; lev < pl->count.size(); lev++)
         GPRY_TRY(trtri_level_products(ctx, L, V, T, Np, trtri_level_nsplit(ctx, pl, lev), pl->aligned[lev],

@@ -233,8 +233,10 @@ __device__ __forceinline__ void tile_store_t(double* T, v4d v, int lane) {      
 #pragma unroll
     for (int q = 0; q < 4; q++) T[r * PLD + g + 4 * q] = v[q];
 }
+// zero_right: the block right of the diagonal block is cleared as well (its last columns for the last block excepted) -- all that the
+// tile-walking products of the chain ever read above the diagonal (see trtri_lower)
 __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restrict__ L_, double* __restrict__ V_,
-                                                           int64_t ld, const int* info, int64_t bstride) {
+                                                           int64_t ld, const int* info, int64_t bstride, int zero_right) {
     __shared__ __attribute__((aligned(16))) double sL[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sV[64 * PLD];
     __shared__ __attribute__((aligned(16))) double sVt[64 * PLD];
@@ -297,10 +299,16 @@ __global__ __launch_bounds__(256) void trtri_diag64_kernel(const double* __restr
         const int i = e >> 6, j = e & 63;
         V[(b0 + i) * ld + b0 + j] = sV[i * PLD + j];
     }
+    if (zero_right && b0 + 128 <= ld) {
+        for (int e = t; e < 64 * 64; e += 256) {
+            const int i = e >> 6, j = e & 63;
+            V[(b0 + i) * ld + b0 + 64 + j] = 0.0;
+        }
+    }
 }
-int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st) {
+int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool zero_right) {
     hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)(Np / 64), 1, (unsigned)ctx->bn), dim3(256), 0, st, L, V, Np, ctx->dinfo,
-                       ctx->bstride);
+                       ctx->bstride, zero_right ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -308,7 +316,7 @@ int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hip
 int launch_trtri_diag_range(gpry_ctx* ctx, const double* L, double* V, int64_t Np, int blk0, int nblk, hipStream_t st) {
     const int64_t off = (int64_t)blk0 * 64 * (Np + 1);
     hipLaunchKernelGGL(trtri_diag64_kernel, dim3((unsigned)nblk, 1, (unsigned)ctx->bn), dim3(256), 0, st, L + off, V + off, Np, ctx->dinfo,
-                       ctx->bstride);
+                       ctx->bstride, 0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -266,6 +266,29 @@ __device__ __forceinline__ void gemm_block_z(const GemmArgs& g, int z, int* tb, 
     if (g.bn > 1) { *tb = z / g.bz_div; *item = z - *tb * g.bz_div; }
     else { *tb = 0; *item = z; }
 }
+// The same for the launches of a batched evaluation (bn > 1), with the dispatch order taken apart again: workgroups start in
+// the order of their linear index (x fastest, then z), and with the thetas in z the LONGEST tiles of the last theta -- the
+// enumerations put long k-ranges first -- came behind all tiles of the thetas before it: a launch of K^-1 = V^T V for 16
+// thetas at N = 4096 ended with a tail of up to 32 of its 187 slab units per workgroup slot.  Here the theta is the fastest
+// index, then the batch item, then the tile: long tiles of ALL thetas first, the tail is made of the shortest ones; with a
+// multiple of eight thetas all tiles of a theta also land on one XCD (round-robin dispatch) and share its L2.  Which
+// workgroup computes a tile changes no bit.
+// (The thetas are counted in eights -- gemm_grid_z below launches round_up(bn, 8) of them, the surplus returns at once --, so
+// that theta t sits on XCD t mod 8 whatever bn is: returns false for a surplus workgroup.)
+__device__ __forceinline__ bool gemm_block_order(const GemmArgs& g, int* bx, int* tb, int* item) {
+    if (g.bn > 1) {
+        const int bnp = (g.bn + 7) & ~7;
+        const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.z;
+        const int rest = lin / bnp;
+        *tb = lin - rest * bnp;
+        *bx = rest / g.bz_div;
+        *item = rest - *bx * g.bz_div;
+        return *tb < g.bn;
+    }
+    *bx = (int)blockIdx.x; *tb = 0; *item = (int)blockIdx.z;
+    return true;
+}
+static inline unsigned gemm_grid_z(const GemmArgs& g) { return (unsigned)(g.bz_div * (g.bn > 1 ? ((g.bn + 7) & ~7) : g.bn)); }
 static inline void gemm_fill_batch(const gpry_ctx* ctx, GemmArgs* g) {
     g->bn = ctx->bn; g->bstride = ctx->bstride; g->bz_div = g->batch ? g->n_batch : 1;
 }
@@ -292,7 +315,7 @@ int gemm_f64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans
 int gemm64_launch(gpry_ctx* ctx, const GemmArgs& g, bool a_trans, bool b_trans, int epi);
 int gemm_split_scratch(gpry_ctx* ctx, int nsplit, int64_t slice, double** buf);
 // gemm_dma.hip: LDS-DMA staged, software-pipelined variant for 128-aligned products (NN, NT, TN)
-int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st);   // chol_panel.hip
+int launch_trtri_diag(gpry_ctx* ctx, const double* L, double* V, int64_t Np, hipStream_t st, bool zero_right = false);   // chol_panel.hip
 // re-scales the training coordinates for the prediction factor if the last LML evaluation left its own in dXs
 int ensure_pred_xs(gpry_ctx* ctx);   // kernel_build.hip
 int launch_point_full(gpry_ctx* ctx, const double* x, int want_kinv, double* kstar, double* G, double* u, double* part,

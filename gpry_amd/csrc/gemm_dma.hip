@@ -25,9 +25,9 @@ template <bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs g) {
     constexpr int A_SZ = !AT ? KC_DOUBLES : MC_DOUBLES, B_SZ = BT ? KC_DOUBLES : MC_DOUBLES;
     __shared__ __attribute__((aligned(16))) double smem[2 * (A_SZ + B_SZ)];
-    int tb, bz;
-    gemm_block_z(g, (int)blockIdx.z, &tb, &bz);
-    gemm_dma_tile_body<AT, BT, EPI>(g, smem, (int)blockIdx.x, (int)blockIdx.y, bz, nullptr, tb);
+    int bx, tb, bz;
+    if (!gemm_block_order(g, &bx, &tb, &bz)) return;
+    gemm_dma_tile_body<AT, BT, EPI>(g, smem, bx, (int)blockIdx.y, bz, nullptr, tb);
 }
 
 // can this product go through the DMA kernel?  (host side; batch items are checked by the caller
@@ -57,7 +57,7 @@ static int gd_launch_epi(gpry_ctx* ctx, const GemmArgs& g, int epi, dim3 grid) {
 int gemm_dma_launch_product(gpry_ctx* ctx, const GemmArgs& g0, bool a_trans, bool b_trans, int epi, dim3 grid) {
     GemmArgs g = g0;
     gemm_fill_batch(ctx, &g);
-    grid.z = (unsigned)(g.bz_div * g.bn);
+    grid.z = gemm_grid_z(g);
     if ((g.tile_map & 15) == TM_ROWMAJOR) {
         g.tile_map = TM_BALANCED;
         const int tm = g.M / BM, tn = g.N / BN;      // batched launches: the largest item

@@ -47,8 +47,8 @@ __device__ __forceinline__ void s64_store_mc(double* lds, const double (&r)[8]) 
 template <bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double smem[4 * OP_DOUBLES];
-    int tb, bz;
-    gemm_block_z(g, (int)blockIdx.z, &tb, &bz);
+    int bx, tb, bz;
+    if (!gemm_block_order(g, &bx, &tb, &bz)) return;
     if (g.info != nullptr && *bset(g.info, tb, g.bstride) != 0) return;
     const double* A = bset(g.A, tb, g.bstride); const double* B = bset(g.B, tb, g.bstride); double* C = bset(g.C, tb, g.bstride);
     int M = g.M, N = g.N, K = g.K;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs g) {
         M = it.M; N = it.N; K = it.K;
     }
     const int tiles_n = N / SB_T;
-    const int ti = blockIdx.x / tiles_n, tj = blockIdx.x - ti * tiles_n;
+    const int ti = bx / tiles_n, tj = bx - ti * tiles_n;
     if (ti >= M / SB_T || (g.lower_only && tj > ti)) return;
     const int row0 = ti * SB_T, col0 = tj * SB_T;
     int kbeg = 0, kend = K;
@@ -157,7 +157,7 @@ int gemm64_launch(gpry_ctx* ctx, const GemmArgs& g0, bool a_trans, bool b_trans,
     if (g.M % SB_T || g.N % SB_T || (g.batch == nullptr && g.K % SB_K))
         return gpry_fail(ctx, -1, "gemm64: M, N must be multiples of 64 and K of 32");
     if (a_trans && b_trans) return gpry_fail(ctx, -1, "gemm64: A^T B^T is not built");
-    const dim3 grid((unsigned)((g.M / SB_T) * (g.N / SB_T)), 1, (unsigned)(g.bz_div * g.bn));
+    const dim3 grid((unsigned)((g.M / SB_T) * (g.N / SB_T)), 1, gemm_grid_z(g));
     if (!a_trans && !b_trans) return launch64<false, false>(ctx, g, epi, grid);
     if (!a_trans && b_trans) return launch64<false, true>(ctx, g, epi, grid);
     return launch64<true, false>(ctx, g, epi, grid);

@@ -40,10 +40,13 @@ except Exception:  # pragma: no cover
 # own parallel mode is mpi4py under mpirun / srun (gpry/mpi.py:18-28, gpry/run.py:1254-1275), which set these instead.
 # A world size alone does not make a process a rank: inside an `sbatch --ntasks=8` allocation a plain `python run.py`
 # (no srun) sees SLURM_NTASKS=8 as well and must keep all its GPUs -- the launcher's rank variable has to be there too.
+# Slurm: the task count of the STEP (SLURM_STEP_NUM_TASKS, set by srun for its own tasks), not of the allocation -- a single
+# `python run.py` inside an interactive step (`salloc` with use_interactive_step, `srun --pty bash`) has SLURM_STEP_ID and
+# SLURM_NTASKS=8 as well, but a step of ONE task, and keeps every GPU.
 _LAUNCHERS = (("WORLD_SIZE", ("RANK", "LOCAL_RANK")),
               ("OMPI_COMM_WORLD_SIZE", ("OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_LOCAL_RANK")),
               ("PMI_SIZE", ("PMI_RANK", "MPI_LOCALRANKID")),
-              ("SLURM_NTASKS", ("SLURM_STEP_ID", "SLURM_STEPID")))      # set inside an srun step only, not in the batch script
+              ("SLURM_STEP_NUM_TASKS", ("SLURM_PROCID",)))
 _WORLD_SIZE_VARS = tuple(v for v, _ in _LAUNCHERS)
 _LOCAL_RANK_VARS = ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID")
 _LAUNCH_NOTE = {"said": False}
@@ -79,7 +82,8 @@ def multi_process_launch():
 # (thread farm, side-by-side groups) take the values of the model's own context, so that every context evaluates alike
 # whatever the caller has set ("same bits as the sequential loop")
 _FIT_CONTEXT_OPTIONS = ("chol", "chol_overlap", "chol_stacked", "factor_pipeline", "factor_pipeline_min", "gemm_dma", "gemm_streamk",
-                        "gemm_small", "lml_small", "lml_cache", "lml_batch", "lml_batch_mb")
+                        "gemm_small", "lml_small", "lml_cache", "lml_batch", "lml_batch_mb", "lml_schedule", "lml_streams",
+                        "tp_block", "tp_tail")
 
 
 def copy_fit_options(src, dst):
@@ -146,6 +150,31 @@ def batch_contexts(n_train=None):
     return 1 if n_train <= 300 else 3
 
 
+def fit_schedule(n_train, n_runs):
+    """Schedule of the batched objective for a side-by-side fit of ``n_runs`` optimiser runs on ``n_train`` points:
+    ``(name, groups)`` with name "latency" (every theta gets the launches and the bits of a single evaluation; the runs dealt
+    over ``batch_contexts`` independent groups) or "throughput" (``gpry_hip.h``: option "lml_schedule" = 1 -- whole-tile
+    products, the Cholesky in column blocks, stream groups inside a call; a theta's value does not depend on how many thetas
+    share the call, and differs from the latency schedule's by rounding).  ``GPRY_HIP_FIT_SCHEDULE`` = latency / throughput
+    forces one; by default the throughput schedule is taken where whole fits were measured ahead (one MI355X, tools/r06/time_fit.py,
+    profiles/r06_tp.md): 42 restarts at N = 4096, d = 16 in 2.4 s against 3.2 s; equal at N = 2048 (0.39 s), behind at N = 1024
+    (110 against 100 ms) -- per call it is ahead from 4 thetas at N = 4096, 10 at 2048 and 24 at 1024, and a fit's rounds thin
+    out as its runs converge.  So: from 2560 padded rows on, with at least six runs.  ``GPRY_HIP_FIT_TP_GROUPS`` (default 1): groups of a throughput fit -- its calls overlap their
+    own stream groups, so all runs share one context and every round is as wide as the fit allows."""
+    env = os.environ.get("GPRY_HIP_FIT_SCHEDULE", "auto").lower()
+    try:
+        tp_groups = max(1, int(os.environ.get("GPRY_HIP_FIT_TP_GROUPS", "1")))
+    except ValueError:
+        tp_groups = 1
+    if env == "latency":
+        return "latency", None
+    if env != "throughput":
+        npad = -(-int(n_train) // 128) * 128
+        if npad < 2560 or n_runs < 6:
+            return "latency", None
+    return "throughput", tp_groups
+
+
 def fit_context_devices(own, n_restarts, spec=None):
     """Device index of every context that shares the optimiser restarts of one fit in THIS process; entry 0
     is the model's own context.
@@ -153,7 +182,7 @@ def fit_context_devices(own, n_restarts, spec=None):
     ``spec`` (``GaussianProcessRegressor.fit_devices``): explicit list, one entry per context, repeats
     allowed.  ``None``: ``GPRY_HIP_DEVICES`` (a list of GPUs, or ``all`` / ``none``), else every visible GPU
     unless this process is one rank of a multi-process launch (``multi_process_launch``: torchrun's ``WORLD_SIZE``, or
-    ``OMPI_COMM_WORLD_SIZE`` / ``PMI_SIZE`` / ``SLURM_NTASKS`` of the reference's mpirun / srun mode -- one process per
+    ``OMPI_COMM_WORLD_SIZE`` / ``PMI_SIZE`` / ``SLURM_STEP_NUM_TASKS`` of the reference's mpirun / srun mode -- one process per
     GPU, the ranks farm the restarts among themselves, ``gpry_amd.parallel`` / ``gpry/run.py:1254-1275``); ``fit_contexts()`` contexts per GPU,
     dealt out round-robin so that the first restarts land on distinct GPUs.  An unmodified single-process
     ``gpry.Runner`` on an 8-GPU node (``gpry/run.py:315-325``: without mpi4py there is one rank) thereby
@@ -784,6 +813,18 @@ class GaussianProcessRegressor(_RM, _BE):
         return False
 
     def _restarts_side_by_side(self, starts, bounds):
+        try:
+            return self._restarts_side_by_side_impl(starts, bounds)
+        finally:
+            # the model's own context goes back to the schedule of the single evaluations, whatever happened
+            if getattr(self, "_fit_sched", "latency") == "throughput" and hasattr(self.device, "set_option"):
+                try:
+                    self.device.set_option("lml_schedule", 0)
+                except Exception:
+                    pass
+            self._fit_sched = "latency"
+
+    def _restarts_side_by_side_impl(self, starts, bounds):
         """The runs of a multi-restart fit stepped together (``gpry_amd.lockstep``: scipy's own L-BFGS-B routine, one
         reverse-communication call per run and round), the objective of a round evaluated for all runs in one
         ``gpry_lml_batch``.  Every run sees the values -- to the bit -- and takes the steps it would take alone, so
@@ -800,11 +841,21 @@ class GaussianProcessRegressor(_RM, _BE):
         n_runs = len(starts)
         devs = [dev]
         k = 1
-        if hasattr(dev, "set_train") and batch_contexts(self.n) > 1:
+        # which schedule of the batched objective (fit_schedule): set on the model's own context here, copied to the others below
+        sched, tp_groups = ("latency", None)
+        if hasattr(dev, "set_option") and 128 < self.n <= int(getattr(dev, "lml_batch_max", 128)):
+            sched, tp_groups = fit_schedule(self.n, n_runs)
+            try:
+                dev.set_option("lml_schedule", 1 if sched == "throughput" else 0)
+            except Exception:       # a build without the option
+                sched = "latency"
+        self._fit_sched = sched
+        n_groups = batch_contexts(self.n) if sched == "latency" else tp_groups
+        if hasattr(dev, "set_train") and n_groups > 1:
             # one GPU: batch_contexts() groups on it; several GPUs in the process: the groups go where fit_context_devices
             # deals the contexts of a fit (round-robin over the GPUs, its first entries on distinct ones)
             ctx_devs = fit_context_devices(getattr(dev, "device", 0), n_runs, getattr(self, "fit_devices", None))
-            k_max = len(ctx_devs) if len(set(ctx_devs)) > 1 else batch_contexts(self.n)
+            k_max = len(ctx_devs) if len(set(ctx_devs)) > 1 else n_groups
             k = min(k_max, max(1, n_runs // _BATCH_GROUP_MIN_RUNS))
         if k > 1:
             want = [ctx_devs[i] if i < len(ctx_devs) else ctx_devs[0] for i in range(1, k)]
@@ -888,7 +939,7 @@ class GaussianProcessRegressor(_RM, _BE):
             X[members[g]], F[members[g]], nfev[members[g]] = out[g]
         self.n_eval_loglike += sum(counts)
         self.fit_stats = {"contexts": k, "devices": [getattr(dv, "device", 0) for dv in devs], "side_by_side": True,
-                          "evals_per_run": [int(v) for v in nfev], "evals_per_context": list(counts)}
+                          "evals_per_run": [int(v) for v in nfev], "evals_per_context": list(counts), "schedule": sched}
         return [(X[i], F[i]) for i in range(n_runs)]
 
     def _concurrent_restarts(self, starts, bounds, ctx_devs):

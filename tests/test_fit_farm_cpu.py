@@ -165,7 +165,7 @@ def test_fit_contexts_are_dealt_out_over_the_devices_of_the_process(monkeypatch)
     assert G.fit_context_devices(3, 32) == [3, 3]
     monkeypatch.delenv("GPRY_HIP_DEVICES")
     for var in ("RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_STEP_ID", "SLURM_STEPID", "MPI_LOCALRANKID",
-                "OMPI_COMM_WORLD_LOCAL_RANK"):
+                "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_PROCID", "SLURM_STEP_NUM_TASKS", "SLURM_NTASKS"):
         monkeypatch.delenv(var, raising=False)
     monkeypatch.setenv("WORLD_SIZE", "8")                 # one process per GPU: the ranks farm among themselves
     monkeypatch.setenv("RANK", "6")
@@ -175,7 +175,7 @@ def test_fit_contexts_are_dealt_out_over_the_devices_of_the_process(monkeypatch)
     # the reference's own parallel mode is mpi4py under mpirun / srun: no WORLD_SIZE there; a world size
     # WITHOUT the launcher's rank variable is a single process inside a multi-task allocation (`sbatch --ntasks=8` and no
     # srun): it keeps every GPU
-    for var, rank_var in (("OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_RANK"), ("PMI_SIZE", "PMI_RANK"), ("SLURM_NTASKS", "SLURM_STEP_ID")):
+    for var, rank_var in (("OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_RANK"), ("PMI_SIZE", "PMI_RANK"), ("SLURM_STEP_NUM_TASKS", "SLURM_PROCID")):
         monkeypatch.setenv(var, "8")
         assert not G.multi_process_launch()
         assert G.fit_context_devices(6, 32)[:3] == [6, 0, 1]
@@ -184,6 +184,15 @@ def test_fit_contexts_are_dealt_out_over_the_devices_of_the_process(monkeypatch)
         assert G.fit_context_devices(6, 32) == [6, 6]
         monkeypatch.delenv(var)
         monkeypatch.delenv(rank_var)
+    # ONE `python run.py` inside an interactive Slurm step of an 8-task allocation (salloc with
+    # use_interactive_step, `srun --pty bash`) has a step id, a rank and the allocation's task count -- but a step of one
+    # task: it is not a rank of many and keeps every GPU
+    for k, v in (("SLURM_NTASKS", "8"), ("SLURM_STEP_ID", "0"), ("SLURM_PROCID", "0"), ("SLURM_STEP_NUM_TASKS", "1"), ("SLURM_LOCALID", "0")):
+        monkeypatch.setenv(k, v)
+    assert not G.multi_process_launch()
+    assert G.fit_context_devices(6, 32)[:3] == [6, 0, 1]
+    for k in ("SLURM_NTASKS", "SLURM_STEP_ID", "SLURM_PROCID", "SLURM_STEP_NUM_TASKS", "SLURM_LOCALID"):
+        monkeypatch.delenv(k)
     monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "5")
     assert G.default_device_index() == 5
     monkeypatch.delenv("OMPI_COMM_WORLD_LOCAL_RANK")

@@ -998,6 +998,15 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
             assert np.array_equal(L0, L1) and np.array_equal(V0, V1) and np.array_equal(a0, a1)
         lml1 = dev.lml(theta, True)
         assert lml0[0] == lml1[0] and np.array_equal(lml0[1], lml1[1])
+        # Round 6: every element of the factor is ONE chain of MFMAs over the columns left of it, started at the covariance
+        # entry, whatever launch its pieces ride in -- so the column blocks of the throughput schedule (any widths, one SYRK
+        # launch behind each; "chol_tp_segments") give this very factor too, bit for bit, and the same failing minor below
+        for blk, tail in ((512, 1024), (128, 128), (256, 640)):
+            dev.set_option("tp_block", blk); dev.set_option("tp_tail", tail); dev.set_option("chol_tp_segments", 1)
+            assert dev.factorize() == 0
+            L2, V2, a2 = dev.get_factor()
+            assert np.array_equal(L0, L2) and np.array_equal(V0, V2) and np.array_equal(a0, a2), (blk, tail)
+        dev.set_option("chol_tp_segments", 0)
         K = dev.kernel_train(add_alpha=True)
         assert relmax(L1 @ L1.T, K) < 1e-13
         # not positive definite: a duplicated row with zero noise far down the matrix
@@ -1007,12 +1016,14 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
             alpha = np.full(N, 1e-5)
             alpha[N - 7] = alpha[N // 3] = -1e-3
             infos = []
-            for ov in (0, 1):
-                dev.set_option("chol_overlap", ov)
+            for ov in (0, 1, 2):
+                dev.set_option("chol_overlap", min(ov, 1))
+                dev.set_option("chol_tp_segments", 1 if ov == 2 else 0)
                 dev.set_train(Xb, y, alpha)
                 dev.set_theta(3, theta)
                 infos.append(dev.factorize())
-            assert infos[0] == infos[1] and infos[0] > 0
+            dev.set_option("chol_tp_segments", 0)
+            assert infos[0] == infos[1] == infos[2] and infos[0] > 0
         # ... and inside an outer block of the large schedule (its column counts from the start of the whole matrix)
         if N >= 5000:
             Xb = X.copy()
@@ -1029,6 +1040,42 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
     finally:
         dev.set_option("chol_overlap", 1)
         dev.set_option("chol_stacked", 2048)
+        dev.set_option("chol_tp_segments", 0)
+        dev.set_option("tp_block", 512); dev.set_option("tp_tail", 1024)
+
+
+def test_a_panel_step_that_timed_out_is_an_error_not_a_verdict_on_the_matrix(dev):
+    """the bounded waits of the panel step report a timeout through the status word of a not-positive-definite
+    matrix plus a marker in the fourth word.  The host reads the marker: the caller gets an error (-2, "timed out"), never the
+    -inf of sklearn's non-PD convention (sklearn:_gpr.py:586-589), which would let an optimiser go on with a wrong
+    objective.  The marker is forced with the test hook "panel_debug" = 64."""
+    from gpry_amd import _lib
+    rng = np.random.default_rng(3)
+    N, d = 300, 3
+    X = rng.uniform(size=(N, d)); y = rng.standard_normal(N)
+    dev.set_affine()
+    dev.set_train(X, y, np.full(N, 1e-4))
+    theta = np.log(np.array([2.0, 0.5, 0.5, 0.5]))
+    dev.set_theta(3, theta)
+    ok = dev.lml(theta, True)
+    assert np.isfinite(ok[0])
+    try:
+        dev.set_option("panel_debug", 64)
+        with pytest.raises(_lib.GpryHipError, match="timed out"):
+            dev.lml(theta, True)
+        with pytest.raises(_lib.GpryHipError, match="timed out"):
+            dev.lml_batch(np.array([theta, theta + 0.1]), True)
+        with pytest.raises(_lib.GpryHipError, match="timed out"):
+            dev.factorize()
+        for sched in (1,):
+            dev.set_option("lml_schedule", sched)
+            with pytest.raises(_lib.GpryHipError, match="timed out"):
+                dev.lml_batch(np.array([theta, theta + 0.1, theta - 0.1]), True)
+    finally:
+        dev.set_option("panel_debug", 0)
+        dev.set_option("lml_schedule", 0)
+    again = dev.lml(theta, True)
+    assert again[0] == ok[0] and np.array_equal(again[1], ok[1])
 
 
 @pytest.mark.parametrize("N", [130, 200, 500, 1000, 1100, 2048, 2100, 3100, 3584])
@@ -1379,3 +1426,82 @@ def test_panel_form_follows_the_error_estimate_of_the_model(dev):
     assert not np.array_equal(out[1], out[0])               # matrix pipe: same numbers to 1e-9, not the same bits
     assert np.max(np.abs(out[1] - out[0])) <= 1e-9 * max(1.0, np.max(np.abs(rm)))
     assert np.max(np.abs(out[1] - rm)) <= 1e-8 * max(1.0, np.max(np.abs(rm)))
+
+
+@pytest.mark.timeout(900)
+def test_the_fitted_model_of_the_bench_against_the_oracle_and_its_panel_form():
+    """the headline cycle sweeps with the model it FITTED -- bench.synthetic(4080, 16), ``fit_gpr='simple'`` from a
+    random start, 16 proposals appended, another simple refit: N = 4096 with several length scales at their lower bound --, not
+    with the hand-set theta = log[4, 0.3 ...] of the full-size test above.  Here that model, built exactly as bench.py builds
+    it, against gpry/gpr.py:1179-1231 and gpry/gp_acquisition.py:1049-1054 through the oracle: which panel form the model's
+    error estimates allowed is asserted from ``acq.stats`` (gpry_sweep_info: the variance term of round 6 sends this model
+    to the difference form), mean / variance / acquisition of 2048 random candidates plus 200 rows on and within l / 5 of
+    training points at the suite's tolerances (1e-8 rel, 1e-9 C), the 16 proposals for identity, and the same sweep with the
+    OTHER panel form forced within the north star's 1e-6 (the estimates are upper bounds, never reached on random candidates)."""
+    import bench
+    from gpry_amd.gp_acquisition import NORA
+    n_base, d, M, npts = 4080, 16, 200_000, 16
+    bounds, X, y, Xc, truth = bench.synthetic(n_base, d, M)
+    gpr = bench.make_gpr(bounds)
+    gpr.verbose = 0
+    gpr.append_to_data(X, y, fit_gpr="simple")
+    acq = NORA(bounds, sampler="uniform", mc_every=1, verbose=0, devices=[0])
+    pool = {"X": Xc}
+    acq.do_MC_sample = lambda gpr, bounds=None, rng=None, sampler=None: (pool["X"], None, None, None)
+    rng = np.random.default_rng(2)
+    X_new, _, _ = acq.multi_add(gpr, n_points=npts, rng=rng)
+    gpr.append_to_data(X_new, truth(X_new), fit_gpr="simple")            # a timed step of the bench: N = 4096
+    assert gpr.n == 4096
+    theta = np.array(gpr.kernel_.theta, dtype=float)
+    ls = np.exp(theta[1:])
+    assert (ls < 2e-3).any(), ls                                           # (the operating point: length scales at the lower bound)
+    # candidates on training points and a fifth of a length scale away from them, in front of the random pool
+    span = bounds[:, 1] - bounds[:, 0]
+    Xt = gpr.X_train[-100:].copy()
+    near = gpr.X_train[:100] + 0.2 * ls * span * np.random.default_rng(0).standard_normal((100, d)) / np.sqrt(d)
+    Xs = np.concatenate([Xt, np.clip(near, bounds[:, 0], bounds[:, 1]), Xc])
+    pool["X"] = Xs
+    Xp, yp, ap = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(3))
+    st = dict(acq.stats)
+    assert st["panel_form"] in ("mfma", "difference") and st["panel_gate"] == 2.5e-7
+    assert st["panel_error_estimate"] > 0 and st["panel_error_variance"] > 0
+    assert st["panel_error_mean_worst_case"] >= st["panel_error_estimate"]
+    # the gate is what decided: matrix pipe iff both estimates are inside it
+    assert (st["panel_form"] == "mfma") == (st["panel_error_estimate"] <= 2.5e-7 and st["panel_error_variance"] <= 2.5e-7), st
+    dev = gpr.device
+    out = dev.sweep_fetch(("y", "sigma", "acq"))
+    ref = orc.OracleGPR(bounds, kernel_id=orc.MATERN52)
+    ref.theta = theta
+    ref.fitted = True
+    ref.append_to_data(gpr.X_train, gpr.y_train, fit_gpr=False, fit_preprocessors=True)
+    sub = np.concatenate([np.arange(200), 200 + np.sort(np.random.default_rng(5).choice(M, 2048, replace=False))])
+    rm, rs = ref.predict(Xs[sub], return_std=True)
+    C = np.exp(theta[0]) * ref.pre_y.std_ ** 2
+    assert np.ptp(rs[:200]) > 0 and np.min(rs[:100]) < 0.5 * np.max(rs)   # (the kernel does reach the rows next to the data)
+    assert np.max(np.abs(out["y"][sub] - rm)) <= 1e-8 * np.max(np.abs(rm))
+    assert np.max(np.abs(out["sigma"][sub] ** 2 - rs ** 2)) <= 1e-9 * C
+    zeta = orc.auto_zeta(d)
+    racq = orc.logexp_f(rm, rs, ref.y_max, ref.noise_level, zeta)
+    a = out["acq"]
+    assert np.array_equal(np.isneginf(a[sub]), np.isneginf(racq))
+    fin = np.isfinite(racq)
+    np.testing.assert_allclose(a[sub][fin], racq[fin], rtol=1e-6, atol=1e-6)
+    # the proposals: the oracle's restatement of multi_add on the device shortlist united with 30 000 random rows
+    order = np.lexsort((-np.arange(len(a)), -a))
+    union = np.union1d(order[:max(256, st["shortlist"])], np.random.default_rng(6).choice(len(a), 30_000, replace=False))
+    Xr, yr, ar = orc.nora_multi_add(ref, Xs[union], npts)
+    np.testing.assert_array_equal(Xp, Xr)
+    np.testing.assert_allclose(ap, ar, rtol=1e-5, atol=1e-6)
+    # the other form of the panel on the same model and rows: what the gate protects against, measured
+    other = 0 if st["panel_form"] == "mfma" else 1
+    try:
+        dev.set_option("cross_mfma", other)
+        if other == 1:
+            dev.set_option("panel_debug", 32)      # (test hook: the matrix-pipe form whatever the estimates say)
+        o2 = dev.sweep_logexp(None, zeta, gpr.y_max, gpr.noise_level, M=len(Xs), want=("y", "sigma"))
+        assert dev.sweep_info()["panel_form"] == ("difference" if other == 0 else "mfma")
+    finally:
+        dev.set_option("cross_mfma", 1)
+        dev.set_option("panel_debug", 0)
+    assert np.max(np.abs(o2["y"][sub] - rm)) <= 1e-6 * max(ref.pre_y.std_, np.max(np.abs(rm)))
+    assert np.max(np.abs(o2["sigma"][sub] ** 2 - rs ** 2)) <= 1e-6 * C

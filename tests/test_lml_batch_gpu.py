@@ -208,3 +208,98 @@ def test_side_by_side_runs_in_independent_groups_on_one_gpu(monkeypatch):
     for k in ("3", "2"):
         np.testing.assert_array_equal(out[k][0], out["1"][0])
         assert out[k][1] == out["1"][1] and out[k][2] == out["1"][2]
+
+
+# ---- the throughput schedule (option "lml_schedule" = 1, round 6) ---------------------------------------------------------------
+@pytest.mark.parametrize("kid", [0, 3])
+@pytest.mark.parametrize("N,d,B", [(129, 3, 7), (300, 5, 12), (1000, 8, 9), (1100, 6, 10), (2048, 16, 6), (2600, 12, 5)])
+def test_throughput_schedule_is_independent_of_the_batch_and_agrees_with_the_oracle(N, d, B, kid):
+    """``lml_schedule`` = 1: the chain for many thetas at once -- whole-tile products only (no partial slices), the recursive
+    inverse at every size, the Cholesky in column blocks with a SYRK launch behind each, the thetas dealt over stream groups.
+    Bar (sklearn:_gpr.py:574-652 via gpry/gpr.py:876-881): a theta's value and gradient are the SAME BITS whatever shares the
+    call with it -- alone (B = 1), in a batch of three, in the full batch, with one / two / three stream groups, with other column
+    blocks, from scratch sets full of NaNs --, they agree with the latency schedule to rounding and with the oracle within
+    the tolerances of the other objective tests, and a not-positive-definite theta is reported on its own."""
+    from gpry_amd import _lib
+    rng, X, y, alpha = _problem(N, d, 11 * N + d + kid)
+    base = np.log(np.array([2.0] + [0.5] * d))
+    thetas = base + rng.uniform(-0.7, 0.7, (B, d + 1))
+    bad = 2
+    for j in range(0, 12, 2):
+        X[j + 1] = X[j]
+    alpha[:12] = 1e-2
+    thetas[bad, 0] = np.log(1e15)
+    dv = _lib.Device(0)
+    try:
+        dv.set_train(X, y, alpha)
+        dv.set_theta(kid, base)
+        lat = dv.lml_batch(thetas, True)
+        dv.set_option("lml_schedule", 1)
+        lml, grad, info = dv.lml_batch(thetas, True)
+        assert info[bad] > 0 and np.isneginf(lml[bad]) and not grad[bad].any()
+        good = [b for b in range(B) if b != bad]
+        assert all(info[b] == 0 for b in good)
+        # against the latency schedule (another summation order) and the oracle
+        for b in good:
+            assert abs(lml[b] - lat[0][b]) <= 1e-11 * max(1.0, abs(lat[0][b])), (b, lml[b], lat[0][b])
+            assert np.max(np.abs(grad[b] - lat[1][b])) <= 1e-8 * max(1.0, np.max(np.abs(lat[1][b])))
+        for b in ([0, 1] if N <= 1100 else [0]):
+            rl, rg = (orc.log_marginal_likelihood(X, y, alpha, thetas[b], kid, eval_gradient=True) if N <= 1100 else
+                      orc.log_marginal_likelihood_blocked(X, y, alpha, thetas[b], kid))
+            assert abs(lml[b] - rl) <= 1e-10 * max(1.0, abs(rl)), (lml[b], rl)
+            assert np.max(np.abs(grad[b] - rg)) <= 1e-7 * max(1.0, np.max(np.abs(rg))), (grad[b], rg)
+
+        def same(res, idx):
+            for k, b in enumerate(idx):
+                assert res[2][k] == info[b]
+                assert res[0][k] == lml[b] or (np.isneginf(res[0][k]) and np.isneginf(lml[b])), (b, res[0][k], lml[b])
+                np.testing.assert_array_equal(res[1][k], grad[b])
+
+        for b in (0, bad, B - 1):                       # alone
+            same(dv.lml_batch(thetas[b:b + 1], True), [b])
+        same(dv.lml_batch(thetas[1:4], True), [1, 2, 3])   # three of them, the failing one in the middle
+        for streams in (1, 3):                          # other stream groups
+            dv.set_option("lml_streams", streams)
+            same(dv.lml_batch(thetas, True), list(range(B)))
+        dv.set_option("lml_streams", 2)
+        dv.set_option("tp_block", 256); dv.set_option("tp_tail", 256)      # other column blocks: the factor is the same, bit for bit
+        same(dv.lml_batch(thetas, True), list(range(B)))
+        dv.set_option("tp_block", 512); dv.set_option("tp_tail", 1024)
+        dv.set_option("panel_debug", 128)               # scratch sets full of NaNs
+        same(dv.lml_batch(thetas, True), list(range(B)))
+        dv.set_option("panel_debug", 0)
+        lml0, info0 = dv.lml_batch(thetas, False)       # value only
+        for b in range(B):
+            assert info0[b] == info[b] and (lml0[b] == lml[b] or (np.isneginf(lml0[b]) and np.isneginf(lml[b])))
+        # the latency schedule is untouched by all this
+        dv.set_option("lml_schedule", 0)
+        again = dv.lml_batch(thetas, True)
+        np.testing.assert_array_equal(again[0], lat[0]); np.testing.assert_array_equal(again[1], lat[1])
+    finally:
+        dv.close()
+
+
+def test_throughput_schedule_at_the_headline_size():
+    """N = 4096, d = 16 (BASELINE configs[2]): column blocks of 512 with the SYRK engine behind each, whole-tile V = L^-1 and
+    K^-1 = V^T V; B-invariant, to rounding the latency schedule, the blocked oracle's value and gradient."""
+    from gpry_amd import _lib
+    rng, X, y, alpha = _problem(4096, 16, 4112)
+    base = np.log(np.array([2.0] + [0.5] * 16))
+    thetas = base + rng.uniform(-0.4, 0.4, (5, 17))
+    dv = _lib.Device(0)
+    try:
+        dv.set_train(X, y, alpha); dv.set_theta(3, base)
+        lat = dv.lml_batch(thetas, True)
+        dv.set_option("lml_schedule", 1)
+        lml, grad, info = dv.lml_batch(thetas, True)
+        assert not info.any()
+        one = dv.lml_batch(thetas[3:4], True)
+        assert one[0][0] == lml[3]
+        np.testing.assert_array_equal(one[1][0], grad[3])
+        assert np.max(np.abs(lml - lat[0]) / np.abs(lat[0])) <= 1e-11
+        assert np.max(np.abs(grad - lat[1]).max(1) / np.abs(lat[1]).max(1)) <= 1e-8
+        rl, rg = orc.log_marginal_likelihood_blocked(X, y, alpha, thetas[0], 3)
+        assert abs(lml[0] - rl) <= 1e-10 * max(1.0, abs(rl))
+        assert np.max(np.abs(grad[0] - rg)) <= 1e-7 * max(1.0, np.max(np.abs(rg)))
+    finally:
+        dv.close()

@@ -44,8 +44,10 @@ for i in (0, B // 2, B - 1):
         j = min(i, B - 3)
         lb, gb, _ = dv.lml_batch(th[j:j + 3], True)
         ok_inv &= (lb[i - j] == l1[i]) and np.array_equal(gb[i - j], g1[i])
-# the same call again: deterministic?
+# the same call again, from scratch sets full of NaNs: deterministic, and independent of what the sets held?
+dv.set_option("panel_debug", 128)
 l2, g2, _ = dv.lml_batch(th, True)
+dv.set_option("panel_debug", 0)
 ok_det = np.array_equal(l1, l2) and np.array_equal(g1, g2)
 # factor bits
 dv.set_option("lml_schedule", 0)
