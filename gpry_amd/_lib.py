@@ -441,7 +441,7 @@ class Device:
         self._sweep_M = M
         return out
 
-    PANEL_FORMS = {0: "none", 1: "mfma", 2: "difference", 3: "small"}
+    PANEL_FORMS = {0: "none", 1: "mfma", 2: "difference", 3: "small", 4: "hybrid"}
 
     def sweep_info(self):
         """How the cross-kernel panel of the last sweep / panel predict was built (``gpry_sweep_info``) and the error

@@ -733,6 +733,7 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
     // (not for Matern-1/2: exp(-r) has a cusp at r = 0, where the rounding noise e of the expanded r^2 becomes sqrt(e) in r --
     // 1e-7 in k for a candidate on a training point; the smoother kernels see e itself)
     bool fast_panel = ctx->opt_cross_mfma && !small_build && ctx->kernel_id != GPRY_MATERN12;
+    bool hybrid_panel = false;
     ctx->panel_form = small_build ? 3 : 2;
     ctx->panel_est[0] = ctx->panel_est[1] = ctx->panel_est[2] = 0.0; ctx->panel_est[3] = 2.5e-7;
     if (fast_panel) {
@@ -777,15 +778,22 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
         if (!(ctx->panel_est[0] <= ctx->panel_est[3]) || !(ctx->panel_est[2] <= ctx->panel_est[3])) fast_panel = false;
         if (ctx->opt_panel_debug & 32) fast_panel = true;       // test hook: the matrix-pipe form whatever the estimates say
         if (fast_panel) ctx->panel_form = 1;
+        // THE HYBRID FORM (round 6; cross_build_mfma_kernel<.., HYB>): distances from the matrix pipe, and every pair that comes
+        // out nearer than r^2 = 100 -- the only ones whose kernel value listens to r^2 at the 1e-15 level -- again from the
+        // coordinates, as the difference form does.  Its entries are as good as the difference form's; what decides between the
+        // two is cost: a model that failed the gate through R^2 (length scales far below the extent of the data: the bench's
+        // fitted model) has next to no near pairs and pays the matrix-pipe price; one that failed it through its weights at
+        // ordinary length scales has nothing else and takes the difference form.
+        else if (ctx->opt_cross_hybrid && R2 >= 1000.0) { hybrid_panel = true; ctx->panel_form = 4; }
         if (getenv("GPRY_HIP_DEBUG_PANEL")) {
             fprintf(stderr, "gpry: panel form: C %.3g R2 %.3g |alpha|_2 %.3g |alpha|_1 %.3g min noise %.3g -> mean %.3g (l1 %.3g) var %.3g: %s; l =", C, R2,
                     ctx->alpha_l2, ctx->alpha_l1, ctx->noise_min, ctx->panel_est[0], ctx->panel_est[1], ctx->panel_est[2],
-                    fast_panel ? "matrix pipe" : "difference form");
+                    fast_panel ? "matrix pipe" : hybrid_panel ? "hybrid" : "difference form");
             for (int k = 0; k < ctx->d; k++) fprintf(stderr, " %.3g (%.3g..%.3g)", exp(ctx->theta[1 + k]), ctx->xlo[k], ctx->xhi[k]);
             fprintf(stderr, "\n");
         }
     }
-    if (fast_panel) GPRY_TRY(launch_cross_prepare(ctx));
+    if (fast_panel || hybrid_panel) GPRY_TRY(launch_cross_prepare(ctx));
     // A fresh pool (gpry_sweep_logexp with a host array, option "sweep_upload"): the rows of chunk c go up on stream2 while
     // the main stream still works on chunk c - 1 -- 4.2 MB against 7.7 ms of kernels at N = 4096 -- and the main stream
     // waits for nothing but its own chunk (one event per chunk, never re-recorded within a call).  From pageable memory
@@ -819,9 +827,9 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
         if (small_build) {
             StageScope s(ctx, "cross_build");
             GPRY_TRY(launch_cross_build_small(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
-        } else if (fast_panel) {
+        } else if (fast_panel || hybrid_panel) {
             StageScope s(ctx, "cross_build");
-            GPRY_TRY(launch_cross_build_mfma(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
+            GPRY_TRY(launch_cross_build_mfma(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1, hybrid_panel ? 1 : 0));
         } else {
             StageScope s(ctx, "cross_build");
             GPRY_TRY(launch_cross_build(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));

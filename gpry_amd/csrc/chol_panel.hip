@@ -1452,7 +1452,9 @@ int transpose_upper_launch(gpry_ctx* ctx, const double* U, double* V, int64_t Np
 
 int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
     OverlapPlan* pl = nullptr;
-    const int prc = overlap_plan_get(ctx, Np, &pl, ctx->tp || ctx->opt_chol_tp_segments ? 3 : 0);
+    // (the column blocks pay from three thetas per chain on; one or two take the cut of the single evaluation -- the factor is
+    // the same, bit for bit, either way: profiles/r06_tp.md)
+    const int prc = overlap_plan_get(ctx, Np, &pl, (ctx->tp && ctx->bn >= 3) || ctx->opt_chol_tp_segments ? 3 : 0);
     if (prc == 1) return potrf_lower_fused(ctx, A, Np);
     if (prc) return prc;
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));

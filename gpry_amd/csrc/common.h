@@ -127,7 +127,8 @@ struct gpry_ctx {
     double alpha_l2 = -1.0;    // ||alpha_||_2 of the prediction factor (fetched when the panel form is chosen; < 0: not yet)
     double alpha_l1 = 0.0;     // ||alpha_||_1, fetched with it
     double noise_min = 0.0;    // smallest entry of the noise vector `alpha` of the training rows (set_train, append_rows): lambda_min(K) >= it
-    int panel_form = 0;        // cross-kernel panel of the last sweep / panel predict: 0 none yet, 1 matrix pipe, 2 difference form, 3 small-batch kernel
+    int panel_form = 0;        // cross-kernel panel of the last sweep / panel predict: 0 none yet, 1 matrix pipe, 2 difference form, 3 small-batch kernel, 4 hybrid (matrix pipe, near pairs from the coordinates)
+    int opt_cross_hybrid = 1;  // 1: a model that fails the gate of the matrix-pipe form because of SHORT length scales takes the hybrid form instead of the difference form
     double panel_est[4] = {0, 0, 0, 2.5e-7};   // its error estimates: mean (l2, gated), mean (l1, worst case), variance / C (gated), the gate
     double* dKst = nullptr;    // Np x chunk cross-kernel panel (k-major)
     int64_t kst_cap = 0;       // doubles allocated
@@ -273,22 +274,23 @@ __device__ __forceinline__ void gemm_block_z(const GemmArgs& g, int z, int* tb, 
 // index, then the batch item, then the tile: long tiles of ALL thetas first, the tail is made of the shortest ones; with a
 // multiple of eight thetas all tiles of a theta also land on one XCD (round-robin dispatch) and share its L2.  Which
 // workgroup computes a tile changes no bit.
-// (The thetas are counted in eights -- gemm_grid_z below launches round_up(bn, 8) of them, the surplus returns at once --, so
-// that theta t sits on XCD t mod 8 whatever bn is: returns false for a surplus workgroup.)
+// (With a multiple of eight thetas every theta sits on one XCD; any other count spreads them evenly.  Counting the thetas in
+// eights -- surplus workgroups returning at once -- pins theta t to XCD t mod 8 for EVERY count, and was measured and dropped:
+// two thetas then use two of the eight XCDs, nine load one XCD twice; a 42-restart fit at N = 4096, whose rounds run through
+// all widths, went from 2.45 to 3.2 s.)
 __device__ __forceinline__ bool gemm_block_order(const GemmArgs& g, int* bx, int* tb, int* item) {
     if (g.bn > 1) {
-        const int bnp = (g.bn + 7) & ~7;
         const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.z;
-        const int rest = lin / bnp;
-        *tb = lin - rest * bnp;
+        const int rest = lin / g.bn;
+        *tb = lin - rest * g.bn;
         *bx = rest / g.bz_div;
         *item = rest - *bx * g.bz_div;
-        return *tb < g.bn;
+        return true;
     }
     *bx = (int)blockIdx.x; *tb = 0; *item = (int)blockIdx.z;
     return true;
 }
-static inline unsigned gemm_grid_z(const GemmArgs& g) { return (unsigned)(g.bz_div * (g.bn > 1 ? ((g.bn + 7) & ~7) : g.bn)); }
+static inline unsigned gemm_grid_z(const GemmArgs& g) { return (unsigned)(g.bz_div * g.bn); }
 static inline void gemm_fill_batch(const gpry_ctx* ctx, GemmArgs* g) {
     g->bn = ctx->bn; g->bstride = ctx->bstride; g->bz_div = g->batch ? g->n_batch : 1;
 }
@@ -336,7 +338,7 @@ int launch_cross_build(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc,
                        hipStream_t st = nullptr);
 int launch_cross_prepare(gpry_ctx* ctx);               // centred scaled training rows for ...
 int launch_cross_build_mfma(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk, double* Kst, double* mean_part,
-                            int raw_affine);           // ... the panel with MFMA distances (sweep, large predict batches)
+                            int raw_affine, int hybrid = 0);           // ... the panel with MFMA distances (sweep, large predict batches); hybrid: near pairs from the coordinates
 int launch_cross_build_small(gpry_ctx* ctx, const double* Xc, int64_t m0, int64_t mc, int64_t ldk,
                              double* Kst, double* mean_part, int raw_affine);     // 4 x (Np/128) mean partials
 int launch_predict_mean_small(gpry_ctx* ctx, const double* Xc, int64_t M, int nsplit, double* part_out);

@@ -284,6 +284,7 @@ const OptionSpec OPTIONS[] = {
     OPT_INT("gemm_streamk", opt_gemm_streamk, 0, BIG, trtri_plan_free(c)),       // the plan holds the stream-K parts
     OPT_INT("gemm_small", opt_gemm_small, 0, BIG, c->lml_cache = false),
     OPT_INT("cross_mfma", opt_cross_mfma, 0, 1, (void)0),
+    OPT_INT("cross_hybrid", opt_cross_hybrid, 0, 1, (void)0),
     OPT_INT("sweep_chunk", opt_sweep_chunk, 0, BIG, c->opt_sweep_chunk = round_up(c->opt_sweep_chunk, 1024)),
     OPT_INT("topk_host", opt_topk_host, 0, BIG, (void)0),
     OPT_INT("lml_small", opt_lml_small, 0, 1, c->lml_cache = false),

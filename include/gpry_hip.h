@@ -113,7 +113,13 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *                             training rows on and proportionally more below: the K* panel of a chunk stays 1 GiB)
  *     "cross_mfma" 0/1        1 (default): the cross-kernel panel of sweeps and large predict batches takes its squared
  *                             distances from the matrix pipe (centred coordinates, |x|^2 + |y|^2 - 2 x.y); 0: the difference
- *                             form (comparator; gpry_kernel_cross, the small batches and Matern-1/2 always use it)
+ *                             form (comparator; gpry_kernel_cross, the small batches and Matern-1/2 always use it).  The form a sweep
+ *                             actually took, and the error estimates of the model that decided it: gpry_sweep_info
+ *     "cross_hybrid" 0/1      1 (default): a model whose error estimates rule the matrix-pipe form out because its length scales are
+ *                             far below the extent of its data takes the hybrid form (matrix-pipe distances, every pair nearer than
+ *                             r^2 = 100 again from the coordinates) instead of the difference form; 0: always the difference form
+ *     "panel_debug"           test hooks, ORed bits: 32 the matrix-pipe panel whatever the estimates say, 64 every Cholesky panel step
+ *                             reports a timed-out wait, 128 the scratch sets of a batched objective start as NaNs (default 0)
  *     "topk_host"             largest pool that gpry_sweep_topk selects on the host from one kernel's records
  *                             (default 16384; 0 = always the device radix select)
  *     "predict_small"         mean-only gpry_predict of at most this many points is one fused launch (default 2048)
@@ -262,7 +268,8 @@ int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* 
 /* How the cross-kernel panel K(X*, X_train) (gpry/gpr.py:1179) of the context's last sweep / panel predict was built, and the
  * error estimates of the model that decided it.  *panel_form: 0 none yet, 1 distances from the matrix pipe (expanded form
  * |x|^2 + |y|^2 - 2 x.y on centred coordinates), 2 difference form (as scipy's cdist), 3 the small-batch kernel (difference
- * form).  est[0]: estimated error of the posterior mean in units of the normalised targets (entry error x ||alpha_||_2);
+ * form), 4 hybrid: distances from the matrix pipe, every pair nearer than r^2 = 100 again from the coordinates (taken by a model
+ * that fails the gate of form 1 through length scales far below the extent of its data; option "cross_hybrid").  est[0]: estimated error of the posterior mean in units of the normalised targets (entry error x ||alpha_||_2);
  * est[1]: its worst case (x ||alpha_||_1); est[2]: estimated error of the posterior variance relative to the prior
  * variance C (2 x entry error x the bound sqrt(C) / sigma_n,min of ||K^-1 k*||_2); est[3]: the gate both est[0] and est[2]
  * must stay below for form 1 (2.5e-7, a quarter of the 1e-6 the posterior is specified to).  Either pointer may be NULL. */

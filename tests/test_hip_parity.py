@@ -1396,9 +1396,11 @@ def test_panel_form_follows_the_error_estimate_of_the_model(dev):
     entry of K* (R: radius of the training set in units of the length scales), which the posterior mean multiplies by the
     weights alpha_.  The sweep estimates that product for the model at hand and takes the difference form by itself when
     it is not a factor of four inside the 1e-6 the mean is specified to: length scales at their lower bound in 16
-    dimensions (R^2 = 4e6) do that -- "cross_mfma" = 1 and 0 then give the same bits, candidates on and next to training
-    points included -- while the same data at l = 0.3 keep the matrix-pipe form (the two options differ in the last bits,
-    and agree to 1e-9)."""
+    dimensions (R^2 = 4e6) do that -- with "cross_hybrid" = 0, "cross_mfma" = 1 and 0 then give the same bits, candidates on
+    and next to training points included; with the default "cross_hybrid" = 1 such a model takes the HYBRID form (round 6:
+    distances from the matrix pipe, every pair nearer than r^2 = 100 again from the coordinates), which agrees with the
+    difference form to 1e-12 of the scale on exactly those candidates -- while the same data at l = 0.3 keep the matrix-pipe
+    form (the two options differ in the last bits, and agree to 1e-9)."""
     N, d, M = 400, 16, 3000
     bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M, seed=5)
     Xc[:50] = X[:50]                                        # candidates on training points ...
@@ -1410,19 +1412,32 @@ def test_panel_form_follows_the_error_estimate_of_the_model(dev):
         m.fitted = True
         m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
         _load_model(dev, m)
-        out = {}
+        out, forms = {}, {}
         try:
+            dev.set_option("cross_hybrid", 0)
             for mf in (1, 0):
                 dev.set_option("cross_mfma", mf)
                 out[mf] = dev.sweep_logexp(Xc, 0.1, 0.0, 1e-2, want=("y", "sigma"))["y"].copy()
+                forms[mf] = dev.sweep_info()["panel_form"]
+            dev.set_option("cross_hybrid", 1); dev.set_option("cross_mfma", 1)
+            hy = dev.sweep_logexp(Xc, 0.1, 0.0, 1e-2, want=("y", "sigma"))
+            out["hybrid"], out["hybrid_sigma"] = hy["y"].copy(), hy["sigma"].copy()
+            forms["hybrid"] = dev.sweep_info()["panel_form"]
+            dev.set_option("cross_mfma", 0)
+            out["diff_sigma"] = dev.sweep_logexp(Xc, 0.1, 0.0, 1e-2, want=("y", "sigma"))["sigma"].copy()
         finally:
-            dev.set_option("cross_mfma", 1)
-        res[name] = (out, m.predict(Xc))
-    out, rm = res["short"]
+            dev.set_option("cross_mfma", 1); dev.set_option("cross_hybrid", 1)
+        res[name] = (out, m.predict(Xc), forms)
+    out, rm, forms = res["short"]
+    assert forms == {1: "difference", 0: "difference", "hybrid": "hybrid"}, forms
     assert np.ptp(out[0][:100]) > 0.1                       # (the kernel does reach those candidates)
     np.testing.assert_array_equal(out[1], out[0])          # the estimate chose the difference form
     assert np.max(np.abs(out[1] - rm)) <= 1e-8 * max(1.0, np.max(np.abs(rm)))
-    out, rm = res["regular"]
+    # the hybrid form: the near pairs come from the coordinates -- to rounding the difference form, on and next to training points too
+    assert np.max(np.abs(out["hybrid"] - out[0])) <= 1e-12 * max(1.0, np.max(np.abs(rm)))
+    assert np.max(np.abs(out["hybrid_sigma"] ** 2 - out["diff_sigma"] ** 2)) <= 1e-12 * np.max(out["diff_sigma"]) ** 2
+    out, rm, forms = res["regular"]
+    assert forms == {1: "mfma", 0: "difference", "hybrid": "mfma"}, forms
     assert not np.array_equal(out[1], out[0])               # matrix pipe: same numbers to 1e-9, not the same bits
     assert np.max(np.abs(out[1] - out[0])) <= 1e-9 * max(1.0, np.max(np.abs(rm)))
     assert np.max(np.abs(out[1] - rm)) <= 1e-8 * max(1.0, np.max(np.abs(rm)))
@@ -1434,8 +1449,8 @@ def test_the_fitted_model_of_the_bench_against_the_oracle_and_its_panel_form():
     random start, 16 proposals appended, another simple refit: N = 4096 with several length scales at their lower bound --, not
     with the hand-set theta = log[4, 0.3 ...] of the full-size test above.  Here that model, built exactly as bench.py builds
     it, against gpry/gpr.py:1179-1231 and gpry/gp_acquisition.py:1049-1054 through the oracle: which panel form the model's
-    error estimates allowed is asserted from ``acq.stats`` (gpry_sweep_info: the variance term of round 6 sends this model
-    to the difference form), mean / variance / acquisition of 2048 random candidates plus 200 rows on and within l / 5 of
+    error estimates allowed is asserted from ``acq.stats`` (gpry_sweep_info: the variance term of round 6 rules the bare
+    matrix-pipe form out for this model; its short length scales send it to the hybrid form), mean / variance / acquisition of 2048 random candidates plus 200 rows on and within l / 5 of
     training points at the suite's tolerances (1e-8 rel, 1e-9 C), the 16 proposals for identity, and the same sweep with the
     OTHER panel form forced within the north star's 1e-6 (the estimates are upper bounds, never reached on random candidates)."""
     import bench
@@ -1463,7 +1478,7 @@ def test_the_fitted_model_of_the_bench_against_the_oracle_and_its_panel_form():
     pool["X"] = Xs
     Xp, yp, ap = acq.multi_add(gpr, n_points=npts, rng=np.random.default_rng(3))
     st = dict(acq.stats)
-    assert st["panel_form"] in ("mfma", "difference") and st["panel_gate"] == 2.5e-7
+    assert st["panel_form"] in ("mfma", "difference", "hybrid") and st["panel_gate"] == 2.5e-7
     assert st["panel_error_estimate"] > 0 and st["panel_error_variance"] > 0
     assert st["panel_error_mean_worst_case"] >= st["panel_error_estimate"]
     # the gate is what decided: matrix pipe iff both estimates are inside it
@@ -1492,16 +1507,18 @@ def test_the_fitted_model_of_the_bench_against_the_oracle_and_its_panel_form():
     Xr, yr, ar = orc.nora_multi_add(ref, Xs[union], npts)
     np.testing.assert_array_equal(Xp, Xr)
     np.testing.assert_allclose(ap, ar, rtol=1e-5, atol=1e-6)
-    # the other form of the panel on the same model and rows: what the gate protects against, measured
-    other = 0 if st["panel_form"] == "mfma" else 1
+    # the other forms of the panel on the same model and rows: the difference form (and the hybrid one, whichever was not the
+    # default) at the suite's tolerances; the bare matrix-pipe form, forced -- what the gate protects against, measured -- within
+    # the north star's 1e-6
     try:
-        dev.set_option("cross_mfma", other)
-        if other == 1:
-            dev.set_option("panel_debug", 32)      # (test hook: the matrix-pipe form whatever the estimates say)
-        o2 = dev.sweep_logexp(None, zeta, gpr.y_max, gpr.noise_level, M=len(Xs), want=("y", "sigma"))
-        assert dev.sweep_info()["panel_form"] == ("difference" if other == 0 else "mfma")
+        for hybrid, mfma, forced, want_form, tol_m, tol_v in ((0, 0, 0, "difference", 1e-8, 1e-9), (1, 1, 0, None, 1e-8, 1e-9),
+                                                              (1, 1, 32, "mfma", 1e-6, 1e-6)):
+            dev.set_option("cross_hybrid", hybrid); dev.set_option("cross_mfma", mfma); dev.set_option("panel_debug", forced)
+            o2 = dev.sweep_logexp(None, zeta, gpr.y_max, gpr.noise_level, M=len(Xs), want=("y", "sigma"))
+            form = dev.sweep_info()["panel_form"]
+            assert want_form is None or form == want_form, (form, want_form)
+            assert np.max(np.abs(o2["y"][sub] - rm)) <= tol_m * max(ref.pre_y.std_, np.max(np.abs(rm))), form
+            assert np.max(np.abs(o2["sigma"][sub] ** 2 - rs ** 2)) <= tol_v * C, form
     finally:
-        dev.set_option("cross_mfma", 1)
+        dev.set_option("cross_mfma", 1); dev.set_option("cross_hybrid", 1)
         dev.set_option("panel_debug", 0)
-    assert np.max(np.abs(o2["y"][sub] - rm)) <= 1e-6 * max(ref.pre_y.std_, np.max(np.abs(rm)))
-    assert np.max(np.abs(o2["sigma"][sub] ** 2 - rs ** 2)) <= 1e-6 * C

@@ -30,6 +30,10 @@ for rep in range(reps):
     if best is None or dt < best:
         best, share = dt, dict(acc)
 fs = gpr.fit_stats
+ev = np.array(fs["evals_per_run"])
+widths = [int((ev > r).sum()) for r in range(ev.max())]        # thetas in flight per round (all groups together)
+hist = np.bincount(np.minimum(widths, 48))
+print("rounds by width (all groups together):", {int(w): int(c) for w, c in enumerate(hist) if c}, flush=True)
 print(f"N={N} d={d} schedule={os.environ.get('GPRY_HIP_FIT_SCHEDULE', 'auto')}->{fs.get('schedule')} groups={fs.get('contexts')} "
       f"streams={os.environ.get('GPRY_TP_STREAMS', 'default')}: {best * 1e3:.0f} ms; evaluations {gpr.n_eval_loglike}, rounds {max(fs['evals_per_run'])}; "
       f"lml {gpr.log_marginal_likelihood_value_:.6f}; in gpry_lml_batch {share['t'] * 1e3:.0f} ms over {share['calls']} calls "
