@@ -712,18 +712,23 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
     int64_t chunk = ctx->opt_sweep_chunk;
     if (chunk <= 0) chunk = Np < 4096 ? round_up(32768 * 4096 / Np, 1024) : 32768;
     if (chunk > round_up(M, 128)) chunk = round_up(M, 128);
-    if (Np * chunk > ctx->kst_cap) {
+    // "sweep_overlap" = 1 (round 6): the cross-kernel panel of chunk c + 1 is built on the side stream while the main stream
+    // contracts chunk c -- two panels and two sets of partial sums, one event per hand-over.  Same kernels on the same data:
+    // same bits.  Only for sweeps of several chunks with the one-pass contraction.
+    const bool overlap = ctx->opt_sweep_overlap && ctx->stream2 != nullptr && !allow_split && want_std && M > chunk;
+    const int nbuf = overlap ? 2 : 1;
+    if (nbuf * Np * chunk > ctx->kst_cap) {
         if (ctx->dKst) GPRY_TRY(dev_free(ctx, ctx->dKst));
         ctx->dKst = nullptr; ctx->kst_cap = 0;
-        GPRY_TRY(dev_alloc(ctx, &ctx->dKst, Np * chunk));
-        ctx->kst_cap = Np * chunk;
+        GPRY_TRY(dev_alloc(ctx, &ctx->dKst, nbuf * Np * chunk));
+        ctx->kst_cap = nbuf * Np * chunk;
     }
     // gpry_predict with a few hundred points: the panel comes from the small-batch kernel, which leaves
     // four mean partials per 128 training rows (kernel_build.hip: cross_build_small_kernel)
     const bool small_build = allow_split && M <= 512;
     const int nt_mean = small_build ? 4 * nt : nt;
     const int64_t part_stride = (int64_t)(nt_mean + nt) * chunk;
-    GPRY_TRY(ensure_part(ctx, part_stride));
+    GPRY_TRY(ensure_part(ctx, nbuf * part_stride));
     FinishParams fp;
     fp.C = exp(ctx->theta[0]); fp.y_mean = ctx->tf.y_mean; fp.y_std = ctx->tf.y_std;
     fp.clip_hi = ctx->tf.clip_hi; fp.zeta = zeta; fp.baseline = baseline; fp.sigma_n = sigma_n;
@@ -799,40 +804,78 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
     // waits for nothing but its own chunk (one event per chunk, never re-recorded within a call).  From pageable memory
     // hipMemcpyAsync returns when the rows are staged, so the host is one chunk ahead of the GPU, which is all it takes.
     const double* up_X = ctx->up_X;
-    if (up_X) {
-        const size_t nchunk = (size_t)((M + chunk - 1) / chunk);
-        while (ctx->ev_pool.size() < nchunk) {
+    const size_t nchunk = (size_t)((M + chunk - 1) / chunk);
+    if (up_X || overlap) {
+        while (ctx->ev_pool.size() < 3 * nchunk + 1) {
             hipEvent_t ev;
             HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             ctx->ev_pool.push_back(ev);
         }
     }
+    const hipStream_t main_stream = ctx->stream, side = ctx->stream2;
+    // the launchers queue on ctx->stream: for the work of the side stream it is swapped for the duration of the call
+    struct StreamSwap {
+        gpry_ctx* c; hipStream_t keep;
+        StreamSwap(gpry_ctx* ctx, hipStream_t st) : c(ctx), keep(ctx->stream) { c->stream = st; }
+        ~StreamSwap() { c->stream = keep; }
+    };
+    // upload (and gates) of chunk ci on the side stream; `ev_up` = ev_pool[ci]
+    auto upload_chunk = [&](size_t ci, bool gates_on_side) -> int {
+        const int64_t m0 = (int64_t)ci * chunk, mc = (M - m0 < chunk) ? M - m0 : chunk;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dXc + m0 * ctx->d, up_X + m0 * ctx->d, sizeof(double) * mc * ctx->d,
+                                    hipMemcpyHostToDevice, side));
+        if (gates_on_side && ctx->up_gates) {
+            StreamSwap sw(ctx, side);
+            StageScope s(ctx, "gates");
+            GPRY_TRY(launch_gates(ctx, ctx->dXc + m0 * ctx->d, mc, ctx->dmask + m0));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[ci], side));
+        return 0;
+    };
+    auto build_panel = [&](size_t ci, double* Kst, double* mean_part) -> int {
+        const int64_t m0 = (int64_t)ci * chunk, mc = (M - m0 < chunk) ? M - m0 : chunk, mcp = round_up(mc, 128);
+        StageScope s(ctx, "cross_build");
+        if (small_build) return launch_cross_build_small(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1);
+        if (fast_panel || hybrid_panel) return launch_cross_build_mfma(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1, hybrid_panel ? 1 : 0);
+        return launch_cross_build(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1);
+    };
+    if (overlap) {
+        // the side stream starts behind what the main stream has queued so far (the scaled / centred training rows, the mask)
+        hipEvent_t ev0 = ctx->ev_pool[3 * nchunk];
+        HIP_TRY(ctx, hipEventRecord(ev0, main_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(side, ev0, 0));
+        if (up_X) GPRY_TRY(upload_chunk(0, true));
+        { StreamSwap sw(ctx, side); GPRY_TRY(build_panel(0, ctx->dKst, ctx->dpart)); }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[nchunk], side));
+    }
     for (int64_t m0 = 0; m0 < M; m0 += chunk) {
         int64_t mc = (M - m0 < chunk) ? M - m0 : chunk;
         int64_t mcp = round_up(mc, 128);
-        if (up_X) {
-            hipEvent_t ev = ctx->ev_pool[(size_t)(m0 / chunk)];
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->dXc + m0 * ctx->d, up_X + m0 * ctx->d, sizeof(double) * mc * ctx->d,
-                                        hipMemcpyHostToDevice, ctx->stream2));
-            HIP_TRY(ctx, hipEventRecord(ev, ctx->stream2));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
-            if (ctx->up_gates) {        // the SVM / trust-region verdicts of this chunk, on top of the caller's bits
-                StageScope s(ctx, "gates");
-                GPRY_TRY(launch_gates(ctx, ctx->dXc + m0 * ctx->d, mc, ctx->dmask + m0));
-            }
-        }
-        double* Kst = ctx->dKst;
-        double* mean_part = ctx->dpart;
+        const size_t ci = (size_t)(m0 / chunk);
+        const int buf = overlap ? (int)(ci & 1) : 0;
+        double* Kst = ctx->dKst + (int64_t)buf * Np * chunk;
+        double* mean_part = ctx->dpart + (int64_t)buf * part_stride;
         double* ss_part = mean_part + (int64_t)nt_mean * chunk;
-        if (small_build) {
-            StageScope s(ctx, "cross_build");
-            GPRY_TRY(launch_cross_build_small(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
-        } else if (fast_panel || hybrid_panel) {
-            StageScope s(ctx, "cross_build");
-            GPRY_TRY(launch_cross_build_mfma(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1, hybrid_panel ? 1 : 0));
+        if (overlap) {
+            // side stream: upload and panel of the NEXT chunk, into the buffers chunk ci - 1 has finished with
+            if (ci + 1 < nchunk) {
+                if (up_X) GPRY_TRY(upload_chunk(ci + 1, true));
+                if (ci >= 1) HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_pool[2 * nchunk + ci - 1], 0));
+                const int nb = (int)((ci + 1) & 1);
+                { StreamSwap sw(ctx, side); GPRY_TRY(build_panel(ci + 1, ctx->dKst + (int64_t)nb * Np * chunk, ctx->dpart + (int64_t)nb * part_stride)); }
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[nchunk + ci + 1], side));
+            }
+            HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pool[nchunk + ci], 0));
         } else {
-            StageScope s(ctx, "cross_build");
-            GPRY_TRY(launch_cross_build(ctx, ctx->dXc, m0, mcp, mcp, Kst, mean_part, 1));
+            if (up_X) {
+                GPRY_TRY(upload_chunk(ci, false));
+                HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pool[ci], 0));
+                if (ctx->up_gates) {        // the SVM / trust-region verdicts of this chunk, on top of the caller's bits
+                    StageScope s(ctx, "gates");
+                    GPRY_TRY(launch_gates(ctx, ctx->dXc + m0 * ctx->d, mc, ctx->dmask + m0));
+                }
+            }
+            GPRY_TRY(build_panel(ci, Kst, mean_part));
         }
         // A batch of a few hundred to a few thousand points has fewer tiles than the GPU has workgroup
         // slots, and its longest tile walks all Np/16 slabs alone (1 ms at Np = 4096): split every
@@ -881,6 +924,7 @@ static int run_sweep(gpry_ctx* ctx, int64_t M, bool have_mask, bool want_std, bo
                                ctx->dy_all, ctx->dsig_all, ctx->dacq_all, fp);
             HIP_TRY(ctx, hipGetLastError());
         }
+        if (overlap) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * nchunk + ci], main_stream));
     }
     return 0;
 }
@@ -1351,8 +1395,13 @@ int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* 
         have_mask = true;
     }
     struct UploadScope {        // (cleared on every way out: a later sweep of the resident pool must not upload again)
-        gpry_ctx* c;
-        ~UploadScope() { c->up_X = nullptr; c->up_gates = 0; }
+        gpry_ctx* c; bool done = false;
+        ~UploadScope() {
+            c->up_X = nullptr; c->up_gates = 0;
+            // a sweep that did not complete leaves no resident pool behind: with the chunked upload part of dXc would be
+            // stale, and a later call with X == NULL must not pass the size check; the side stream is drained as well
+            if (!done) { c->sw_M = 0; if (c->stream2) (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream); }
+        }
     } upload_scope{ctx};
     if (piped) { ctx->up_X = X; ctx->up_gates = ctx->gates_on ? 1 : 0; }
     GPRY_TRY(run_sweep(ctx, M, have_mask, true, true, zeta, baseline, sigma_n));
@@ -1365,6 +1414,7 @@ int gpry_sweep_logexp(gpry_ctx* ctx, const double* X, int64_t M, const uint8_t* 
     if (sigma_all) HIP_TRY(ctx, hipMemcpyAsync(sigma_all, ctx->dsig_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
     if (acq_all) HIP_TRY(ctx, hipMemcpyAsync(acq_all, ctx->dacq_all, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    upload_scope.done = true;
     if (n_nan) *n_nan = (int64_t)nn;
     return 0;
 }

@@ -172,6 +172,7 @@ struct gpry_ctx {
     int64_t opt_serve_idle_us = 2000;  // the kernel leaves after this long without a request
     int64_t opt_chol_stacked = 2048;   // up to this Np the inverse factor comes out of the Cholesky launches themselves (potrf_stacked, chol_panel.hip); 0: never
     int opt_chol_stacked_dense = 0;    // 1: potrf_stacked without use of the zero structure of the appended rows (comparator)
+    int opt_sweep_overlap = 0;         // 1: the cross-kernel panel of chunk c + 1 is built on the side stream underneath the contraction of chunk c (two panels)
     int opt_sweep_upload = 1;          // 1: a fresh candidate pool is uploaded chunk by chunk on stream2, chunk c + 1 underneath the kernels of chunk c
     const double* up_X = nullptr;      // host pool of the sweep in flight whose chunks are still to be uploaded (run_sweep)
     int up_gates = 0;                  // ... and the device gates are evaluated chunk by chunk behind each upload

@@ -300,6 +300,7 @@ const OptionSpec OPTIONS[] = {
     OPT_INT("predict_small", opt_predict_small, 0, BIG, (void)0),
     OPT_INT("predict_split", opt_predict_split, 0, 1, (void)0),
     OPT_INT("sweep_upload", opt_sweep_upload, 0, 1, (void)0),
+    OPT_INT("sweep_overlap", opt_sweep_overlap, 0, 1, (void)0),
     OPT_INT("chol_stacked", opt_chol_stacked, 0, BIG, c->lml_cache = false),
     OPT_INT("chol_stacked_dense", opt_chol_stacked_dense, 0, 1, c->lml_cache = false),
     OPT_INT("predict_gates", opt_predict_gates, 0, 1, (void)0),
