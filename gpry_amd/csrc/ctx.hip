@@ -39,8 +39,8 @@ int dev_free(gpry_ctx* ctx, void* p) {
 }
 
 // roctx ranges around the stages (the reference's Timer / TimerCounter, gpry/progress.py:243-284, as marker ranges that
-// rocprofv3 --marker-trace shows next to the kernels): off unless GPRY_HIP_ROCTX=1; libroctx64.so is looked up at run time,
-// the library has no link-time dependency on it.  A range covers the host-side queueing of a stage's launches.
+// rocprofv3 --marker-trace shows next to the kernels): off unless GPRY_HIP_ROCTX=1; the roctx library is looked up at run time
+// (dlopen), the library has no link-time dependency on it.  A range covers the host-side queueing of a stage's launches.
 namespace {
 struct Roctx {
     bool tried = false, on = false;
@@ -52,15 +52,20 @@ bool roctx_on() {
         g_roctx.tried = true;
         const char* e = getenv("GPRY_HIP_ROCTX");
         if (e && atoi(e) != 0) {
-            void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
-            if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
-            if (!lib) lib = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            // rocprofv3 (rocprofiler-sdk) records the ranges of ITS roctx library; the roctracer one (libroctx64) is the fallback
+            // for the older tools -- same entry points
+            void* lib = nullptr;
+            for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                                     "libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (lib) break;
+            }
             if (lib) {
                 g_roctx.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
                 g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
                 g_roctx.on = g_roctx.push && g_roctx.pop;
             }
-            if (!g_roctx.on) fprintf(stderr, "gpry: GPRY_HIP_ROCTX=1 but libroctx64.so could not be loaded: no marker ranges\n");
+            if (!g_roctx.on) fprintf(stderr, "gpry: GPRY_HIP_ROCTX=1 but neither librocprofiler-sdk-roctx.so nor libroctx64.so could be loaded: no marker ranges\n");
         }
     }
     return g_roctx.on;

@@ -106,6 +106,25 @@ def _one_case(case, rng, dev, worst):
             # (the diagonal ratio underestimates cond(K): two-dimensional RBF / Matern cases reach 2e-8)
             if e > max(1e-7, 1e-15 * cond) or eg > max(1e-6, 1e-12 * cond):
                 print(f"case {case}: lml err {e:.2e} grad err {eg:.2e} (N={N} d={d} kid={kid})"); bad += 1
+        # round 6: the throughput schedule of the batched objective (above 128 rows): a theta's bits do not depend on what shares
+        # the call, and it agrees with the single evaluation to the conditioning of K
+        if N > 128 and np.isfinite(rl) and hasattr(dev, "set_option"):
+            try:
+                dev.set_option("lml_schedule", 1)
+                ths = np.array([th, m.theta, th + rng.normal(0, 0.05, d + 1)])
+                bl, bg, bi = dev.lml_batch(ths, True)
+                one = dev.lml_batch(ths[:1], True)
+                two = dev.lml_batch(ths[::-1].copy(), True)
+            finally:
+                dev.set_option("lml_schedule", 0)
+            same = (one[0][0] == bl[0] and np.array_equal(one[1][0], bg[0]) and two[0][2] == bl[0] and np.array_equal(two[1][2], bg[0])
+                    and two[0][0] == bl[2] and np.array_equal(two[1][0], bg[2]))
+            et = abs(bl[0] - lml) / max(1.0, abs(lml)) if info == 0 and bi[0] == 0 else 0.0
+            etg = np.max(np.abs(bg[0] - grad)) / max(1.0, np.max(np.abs(grad))) if info == 0 and bi[0] == 0 else 0.0
+            worst["tp_lml"] = max(worst.get("tp_lml", 0.0), et)
+            worst["tp_grad"] = max(worst.get("tp_grad", 0.0), etg)
+            if not same or bi[0] != info or et > max(1e-9, 1e-15 * cond) or etg > max(1e-7, 1e-12 * cond):
+                print(f"case {case}: throughput schedule: B-invariant {same}, info {bi[0]} / {info}, lml {et:.2e} grad {etg:.2e} (N={N} d={d} kid={kid})"); bad += 1
         x0 = Xc[0]
         mg, kg, G = dev.predict_grad(x0, want_kinv=True, want_kgrad=True)
         Gr = orc.kernel_gradient_x(m.pre_X.transform(x0[None, :])[0], m.X_train_, m.theta, kid)
