@@ -196,16 +196,16 @@ def cpu_baseline(N, d, M, lml_evals, cache_models):
 
 def measured_traffic(which, Np, M_launch_total):
     """HBM-side bytes per launch of the sweep contraction, from the PMC counters of THIS round's build
-    (profiles/r05_traffic.json, written from tools/r05/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    (profiles/r06_traffic.json, written from tools/r06/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns (bytes or None, note): the figure is
     a measurement of the profiled run of that workload shape, not of this process; it is carried only when the shape of
     this run (padded training size, candidates per launch) is the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r05_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r06_traffic.json")
     if not os.path.exists(path):
-        return None, "no PMC measurement of this round's build (profiles/r05_traffic.json)"
+        return None, "no PMC measurement of this round's build (profiles/r06_traffic.json)"
     rec = json.load(open(path)).get(which)
     if not rec:
-        return None, f"profiles/r05_traffic.json has no entry {which!r}"
+        return None, f"profiles/r06_traffic.json has no entry {which!r}"
     if int(rec.get("Np", -1)) != int(Np):
         return None, f"measured at Np={rec.get('Np')}, this run has Np={Np}"
     note = (f"{rec['hbm_bytes_per_launch'] / 1e9:.2f} GB per launch of {rec['candidates_per_launch']} candidates = "
