@@ -702,6 +702,14 @@ class GaussianProcessRegressor(_RM, _BE):
         dev = self._dev if self._dev is not None else self.device
         if dev.N != len(self.y_train_):
             raise RuntimeError("device training set out of sync")
+        if eval_gradient and getattr(self, "_seq_fit_tp", False):
+            # a sequential fit under the throughput schedule (the comparator of the side-by-side fit, fit_gpr_hyperparameters):
+            # the chain of the many for ONE theta -- the bits a theta has in any batch of that schedule
+            lb, gb, _ = dev.lml_batch(np.asarray(theta_full, dtype=float)[None, :], True)
+            lml, grad_full = float(lb[0]), gb[0]
+            if not np.isfinite(lml):
+                return -np.inf, np.zeros_like(theta)
+            return lml, (kernel.grad_from_full_fast(grad_full, self.d) if fast else kernel.grad_from_full(grad_full, self.d))
         if eval_gradient:
             lml, grad_full, _ = dev.lml(theta_full, True)
             if not np.isfinite(lml):
@@ -767,14 +775,29 @@ class GaussianProcessRegressor(_RM, _BE):
             optima = (self._restarts_side_by_side(starts, hyperparameter_bounds) if side_by_side
                       else self._concurrent_restarts(starts, hyperparameter_bounds, ctx_devs))
         else:
+            # The sequential loop evaluates with single gpry_lml calls (the latency schedule).  ``GPRY_HIP_FIT_SCHEDULE=throughput``
+            # makes it the comparator of a throughput-schedule fit instead: every evaluation through the chain of the many with
+            # one theta -- the side-by-side fit under that schedule then equals this loop bit for bit
+            seq_tp = (n_restarts > 1 and os.environ.get("GPRY_HIP_FIT_SCHEDULE", "").lower() == "throughput"
+                      and hasattr(self.device, "set_option") and 128 < self.n <= int(getattr(self.device, "lml_batch_max", 128)))
             optima = []
-            for iteration in range(n_restarts):
-                if iteration == 0 and start_from_current:
-                    theta0 = self.kernel_.theta
-                else:
-                    theta0 = self._rng.uniform(hyperparameter_bounds[:, 0], hyperparameter_bounds[:, 1])
-                optima.append(self._constrained_optimization(obj_func, theta0, hyperparameter_bounds))
-            self.fit_stats = {"contexts": 1, "devices": [getattr(self.device, "device", 0)], "evals_per_context": None}
+            try:
+                if seq_tp:
+                    self._upload_train()
+                    self.device.set_option("lml_schedule", 1)
+                    self._seq_fit_tp = True
+                for iteration in range(n_restarts):
+                    if iteration == 0 and start_from_current:
+                        theta0 = self.kernel_.theta
+                    else:
+                        theta0 = self._rng.uniform(hyperparameter_bounds[:, 0], hyperparameter_bounds[:, 1])
+                    optima.append(self._constrained_optimization(obj_func, theta0, hyperparameter_bounds))
+            finally:
+                if seq_tp:
+                    self._seq_fit_tp = False
+                    self.device.set_option("lml_schedule", 0)
+            self.fit_stats = {"contexts": 1, "devices": [getattr(self.device, "device", 0)], "evals_per_context": None,
+                              "schedule": "throughput" if seq_tp else "latency"}
         # how the restarts ran, for whoever wonders why a fit was slow: side by side (one batched objective per round) or
         # one after another / farmed over contexts, and -- when scipy's private routine was the obstacle -- why
         self.fit_stats = dict(getattr(self, "fit_stats", None) or {})

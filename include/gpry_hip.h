@@ -127,6 +127,8 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *     "sweep_upload" 0/1      gpry_sweep_logexp with a host pool: 1 (default) uploads it chunk by chunk on a copy stream, chunk
  *                             c + 1 underneath the kernels of chunk c (gpry/gp_acquisition.py:1023-1031 draws a fresh pool every
  *                             mc_every-th call); 0: one copy in front of the sweep (the comparator; same bits)
+ *     "sweep_overlap" 0/1     1: the cross-kernel panel of chunk c + 1 is built on the side stream underneath the contraction of
+ *                             chunk c (two panels; same bits).  Default 0: measured slower (profiles/r06_sweep.md), kept as the comparator
  *     "chol_stacked"          up to this padded training-set size (default 2048; at most 3584) the inverse factor V = L^-1 comes
  *                             out of the launches of the Cholesky factorisation itself (the identity appended to the matrix as
  *                             extra rows); 0: always the recursive inverse behind the factorisation.  Same L; V, and what is

@@ -581,3 +581,38 @@ def test_restarts_stepped_side_by_side_on_the_device_select_the_sequential_optim
     np.testing.assert_array_equal(b[0], a[0])
     assert b[1] == a[1] and b[2] == a[2]
     np.testing.assert_array_equal(b[3], a[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_side_by_side_fit_under_the_throughput_schedule_equals_its_sequential_loop(monkeypatch):
+    """Round 6: from 2560 padded rows on the side-by-side fit evaluates its rounds with the THROUGHPUT schedule of
+    ``gpry_lml_batch`` (whole-tile products, column-block Cholesky, stream groups) -- a theta's value there does not depend on
+    how many thetas share the call.  So the fit (gpry/gpr.py:968-984: the reference's restarts, its start points and RNG order)
+    still equals the sequential loop bit for bit -- the loop that evaluates through the same schedule with one theta per call
+    (``GPRY_HIP_FIT_SCHEDULE=throughput`` + ``GPRY_HIP_FIT_LOCKSTEP=0``) --, whatever the number of groups; and it agrees with
+    the latency-schedule fit (the bits of single evaluations) in its optimum to rounding.  N = 700 here, the schedule forced."""
+    bounds, X, y, Xc = orc.synthetic_like_goldens(700, 5, 300, seed=17)
+    out = {}
+    for mode, lock, sched, groups in (("sequential tp", "0", "throughput", "1"), ("side by side tp", "1", "throughput", "1"),
+                                      ("side by side tp, 2 groups", "1", "throughput", "2"), ("side by side latency", "1", "latency", "1")):
+        monkeypatch.setenv("GPRY_HIP_FIT_CONTEXTS", "1")
+        monkeypatch.setenv("GPRY_HIP_FIT_LOCKSTEP", lock)
+        monkeypatch.setenv("GPRY_HIP_FIT_SCHEDULE", sched)
+        monkeypatch.setenv("GPRY_HIP_FIT_TP_GROUPS", groups)
+        gpr = make_gpr(bounds, 3, n_restarts_optimizer=7, random_state=5)
+        gpr.append_to_data(X, y, fit_gpr=True)
+        st = gpr.fit_stats
+        assert st.get("schedule") == sched, st
+        assert bool(st.get("side_by_side")) == (lock == "1")
+        assert gpr.device.get_option("lml_schedule") == 0          # the model's own context is back on the latency schedule
+        out[mode] = (gpr.kernel_.theta.copy(), gpr.log_marginal_likelihood_value_, gpr.n_eval_loglike, gpr.predict(Xc))
+    a = out["sequential tp"]
+    for mode in ("side by side tp", "side by side tp, 2 groups"):
+        b = out[mode]
+        np.testing.assert_array_equal(b[0], a[0])
+        assert b[1] == a[1] and b[2] == a[2], (mode, b[1], a[1], b[2], a[2])
+        np.testing.assert_array_equal(b[3], a[3])
+    c = out["side by side latency"]
+    assert abs(c[1] - a[1]) <= 1e-6 * max(1.0, abs(a[1]))
+    assert np.max(np.abs(c[3] - a[3])) <= 1e-5 * max(1.0, np.max(np.abs(a[3])))

@@ -21,6 +21,8 @@ dv.set_train(X, y, np.full(N, 1e-4))
 base = np.log(np.array([2.0] + [0.5] * d)); dv.set_theta(kid, base)
 th = base + rng.uniform(-0.3, 0.3, (B, d + 1))
 dv.set_option("lml_streams", streams); dv.set_option("tp_block", blk); dv.set_option("tp_tail", tail)
+if N > 4096:
+    dv.set_option("lml_batch", 8192)        # (the default stops at 4096, where the host's thread farm takes over)
 
 def best(f, reps=3):
     f(); ts = []

@@ -13,7 +13,8 @@ import json, re
 rows = [l.rstrip("\n").split("\t") for l in open("gpurun_out/r06/pmc_traffic.txt") if l.count("\t") >= 4]
 val = {}
 for tag, c, k, n, v in rows:
-    val[(tag, c, "sweep" if "sweep" in k else "cross")] = (int(n.split()[1]), float(v.split()[2]))
+    key = "sweep" if "sweep_gemm" in k else "cross" if "cross_build" in k else None      # (not sweep_finish_kernel)
+    if key: val[(tag, c, key)] = (int(n.split()[1]), float(v.split()[2]))
 out = {"_comment": "HBM-side (L2 memory-side: Infinity-Cache hits included) traffic of the sweep contraction of the ROUND-6 build: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, program directly behind `--` (tools/r06/pmc_traffic.sh -> profiles/r06_pmc_traffic_raw.tsv).  FETCH_SIZE (KB) is doubled as MI355X_MICROARCH.md (HBM) prescribes for 16-B/lane streaming reads on gfx950; WRITE_SIZE as reported.  bench.py reads this file (measured_traffic)."}
 for tag, Np, d, cand in (("config2", 4096, 16, 32768), ("config1", 1024, 8, 100000)):
     f, w = val.get((tag, "FETCH_SIZE", "sweep")), val.get((tag, "WRITE_SIZE", "sweep"))
