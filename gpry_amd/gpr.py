@@ -963,6 +963,10 @@ class GaussianProcessRegressor(_RM, _BE):
         self.n_eval_loglike += sum(counts)
         self.fit_stats = {"contexts": k, "devices": [getattr(dv, "device", 0) for dv in devs], "side_by_side": True,
                           "evals_per_run": [int(v) for v in nfev], "evals_per_context": list(counts), "schedule": sched}
+        try:        # a fit that ran short of device memory halves its batches (and is slower for it): say so
+            self.fit_stats["batch_shrinks"] = int(sum(dv.timing("lml_batch_shrinks")[1] for dv in devs if hasattr(dv, "timing")))
+        except Exception:
+            pass
         return [(X[i], F[i]) for i in range(n_runs)]
 
     def _concurrent_restarts(self, starts, bounds, ctx_devs):

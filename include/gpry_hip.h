@@ -368,7 +368,8 @@ int gpry_group_lml_batch(gpry_group* group, const double* thetas, int n_theta, i
 /* Device-side timing of the last call's stages in milliseconds (HIP events on the
  * ctx stream).  Known names: "kernel_build", "potrf", "trtri", "lauum", "lml_traces",
  * "cross_build", "sweep_gemm", "sweep_finish", "topk".  Returns <0 if unknown.
- * *count = launches accumulated since gpry_timing_reset. */
+ * *count = launches accumulated since gpry_timing_reset.  "lml_batch_shrinks" is a counter, not a timer: *count = the times a
+ * batched objective of this context halved its chunk after an out-of-memory answer (any other failure is returned to the caller). */
 int gpry_timing_reset(gpry_ctx* ctx);
 int gpry_timing_get(gpry_ctx* ctx, const char* name, double* total_ms, int64_t* count);
 /* Raw micro-benchmarks used by bench.py to quote measured peaks beside the spec:
