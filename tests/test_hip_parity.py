@@ -1522,3 +1522,35 @@ def test_the_fitted_model_of_the_bench_against_the_oracle_and_its_panel_form():
     finally:
         dev.set_option("cross_mfma", 1); dev.set_option("cross_hybrid", 1)
         dev.set_option("panel_debug", 0)
+
+
+@pytest.mark.parametrize("N,d,M,chunk", [(700, 5, 9000, 2048), (1500, 9, 20000, 4096)])
+def test_panel_built_underneath_the_contraction_gives_the_same_sweep(dev, N, d, M, chunk):
+    """Option "sweep_overlap" (round 6, measured slower and off by default: profiles/r06_sweep.md): the cross-kernel panel of
+    chunk c + 1 is built on the side stream while the main stream contracts chunk c -- two panels, two sets of partial sums, one
+    event per hand-over.  Same kernels on the same data: mean, sigma and acquisition (gpry/gpr.py:1179-1231,
+    gpry/acquisition_functions.py:1068-1074) of every candidate are the bits of the schedule with one stream, for a resident
+    pool and for one that is uploaded chunk by chunk, ragged last chunk included."""
+    bounds, X, y, Xc = orc.synthetic_like_goldens(N, d, M - 37, seed=N)
+    m = orc.OracleGPR(bounds, kernel_id=3)
+    m.theta = np.log(np.array([3.0] + [0.4] * d))
+    m.fitted = True
+    m.append_to_data(X, y, fit_gpr=False, fit_preprocessors=True)
+    _load_model(dev, m)
+    try:
+        dev.set_option("sweep_chunk", chunk)
+        out = {}
+        for ov in (0, 1):
+            dev.set_option("sweep_overlap", ov)
+            fresh = dev.sweep_logexp(Xc, 0.1, m.y_max, 1e-2, want=("y", "sigma", "acq"))
+            resident = dev.sweep_logexp(None, 0.1, m.y_max, 1e-2, M=len(Xc), want=("y", "sigma", "acq"))
+            for k in ("y", "sigma", "acq"):
+                np.testing.assert_array_equal(fresh[k], resident[k])
+            out[ov] = fresh
+        for k in ("y", "sigma", "acq"):
+            np.testing.assert_array_equal(out[1][k], out[0][k])
+        rm, rs = m.predict(Xc[:1500], return_std=True)
+        assert np.max(np.abs(out[1]["y"][:1500] - rm)) <= 1e-8 * max(1.0, np.max(np.abs(rm)))
+    finally:
+        dev.set_option("sweep_overlap", 0)
+        dev.set_option("sweep_chunk", 0)
