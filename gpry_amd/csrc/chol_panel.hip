@@ -1117,7 +1117,8 @@ static int trailing_update(gpry_ctx* ctx, double* A, int64_t ld, int64_t n, int6
     g.B = A + c0 * ld + K0; g.ldb = ld;
     g.C = A + r0 * ld + c0; g.ldc = ld;
     g.M = (int)(n - r0); g.N = (int)nc; g.K = kdepth;
-    g.kmode = KM_FULL; g.lower_only = (r0 == c0 && nc == n - r0) ? 1 : 0; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
+    // (tiles above the diagonal of a block that starts on it are never read: skipped, for a block column as for the square)
+    g.kmode = KM_FULL; g.lower_only = (r0 == c0) ? 1 : 0; g.tile_map = TM_ROWMAJOR; g.info = ctx->dinfo;
     return gemm_f64_launch(ctx, g, false, true, EPI_SUB);
 }
 struct ChainState { int arrivals = 0; };
@@ -1460,16 +1461,23 @@ int potrf_lower_overlap(gpry_ctx* ctx, double* A, int64_t Np) {
     if (!ctx->info_cleared) HIP_TRY(ctx, hipMemsetAsync(ctx->dinfo, 0, 4 * sizeof(int), ctx->stream));
     ctx->info_cleared = false;
     ChainState cs;
+    // "tp_left" = 1 (comparator; measured 1.5 % behind at N = 4096, equal at 2048: profiles/r06_tp.md): the column blocks LEFT-looking
+    // -- in front of a block ONE launch brings its columns up to date with ALL columns left of it (k from 0: deep tiles, C read
+    // and written once) instead of one launch behind every block onto everything right of it (k = the block's width, C read and
+    // written once per block).  The element's chain is the same chain, k ascending from the covariance entry: same bits.
+    const bool left = ((ctx->tp && ctx->bn >= 3) || ctx->opt_chol_tp_segments) && ctx->opt_tp_left;
     for (const Segment& sg : pl->seg) {
         double* As = A + sg.K0 * Np + sg.K0;
         const int64_t n = (int64_t)sg.nrows * 64;
+        if (left && sg.K0 > 0)
+            GPRY_TRY(trailing_update(ctx, A, Np, Np, 0, sg.K0, sg.K0, sg.ncols == sg.nrows ? n : (int64_t)sg.ncols * 64, (int)sg.K0));
         for (int c = 0; c < sg.ncols; c++) {
             const int64_t j0 = (int64_t)c * 64;
             const int l = sg.first_launch + c;
             // every step applies the strip before its own (64 k, left-looking) itself
             GPRY_TRY(panel_launch(ctx, cs, As, Np, n, sg.K0, j0, j0 >= 64 ? j0 - 64 : 0, pl->d_items + pl->first[l], pl->count[l]));
         }
-        GPRY_TRY(block_update(ctx, As, Np, sg));
+        if (!left) GPRY_TRY(block_update(ctx, As, Np, sg));
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

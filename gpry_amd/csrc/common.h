@@ -77,6 +77,7 @@ struct gpry_ctx {
     int opt_lml_schedule = 0;
     int opt_lml_streams = 2;           // throughput schedule: stream groups per call (1: one chain for all thetas)
     int64_t opt_tp_block = 512;        // throughput schedule: width of the column blocks of the Cholesky (multiple of 128)
+    int opt_tp_left = 0;               // throughput schedule: 0 = the column blocks right-looking (one launch of the block's width behind each; default: measured ahead), 1 = left-looking (one deep launch in front of each); same bits
     int64_t opt_tp_tail = 1024;        // ... and the size of the last block, factored with riding tiles only
     int64_t batch_shrinks = 0;         // times a batched evaluation halved its chunk after an out-of-memory answer (diagnostic, gpry_timing_get "lml_batch_shrinks")
     int opt_chol_tp_segments = 0;      // 1: every factorisation of the context takes the column blocks of the throughput schedule (comparator: same bits)

@@ -300,6 +300,7 @@ const OptionSpec OPTIONS[] = {
     OPT_INT("lml_streams", opt_lml_streams, 1, 8, (void)0),
     OPT_INT("chol_tp_segments", opt_chol_tp_segments, 0, 1, c->lml_cache = false),
     OPT_INT("panel_debug", opt_panel_debug, 0, 255, c->lml_cache = false),
+    OPT_INT("tp_left", opt_tp_left, 0, 1, (void)0),
     OPT_INT("tp_block", opt_tp_block, 128, BIG, c->opt_tp_block = round_up(c->opt_tp_block, 128); overlap_plan_free(c)),
     OPT_INT("tp_tail", opt_tp_tail, 128, BIG, c->opt_tp_tail = round_up(c->opt_tp_tail, 128); overlap_plan_free(c)),
     OPT_INT("predict_small", opt_predict_small, 0, BIG, (void)0),

@@ -107,6 +107,9 @@ int gpry_ctx_sync(gpry_ctx* ctx);
  *     "lml_streams" 1..8      throughput schedule: stream groups per call (default 2)
  *     "tp_block", "tp_tail"   throughput schedule: width of the column blocks of the Cholesky (default 512) and size of the last
  *                             block, factored with riding tiles only (default 1024); multiples of 128.  No bit depends on them
+ *     "tp_left" 0/1           throughput schedule: 0 (default) the column blocks right-looking (one launch of the block's width behind
+ *                             every block), 1 left-looking (ONE deep launch in front of a block brings its columns up to date with
+ *                             all columns left of it; the comparator, measured 1.5 % behind at 4096 rows).  Same factor bit for bit
  *     "chol_tp_segments" 0/1  1: every factorisation of the context takes those column blocks (comparator: the same factor bit for bit)
  *   predict / sweep (gpry/gpr.py:1022-1273, gpry/gp_acquisition.py:971-1108)
  *     "sweep_chunk"           candidates per sweep chunk, rounded up to a multiple of 1024 (default 0 = 32768 from 4096 padded

@@ -1001,11 +1001,14 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
         # Round 6: every element of the factor is ONE chain of MFMAs over the columns left of it, started at the covariance
         # entry, whatever launch its pieces ride in -- so the column blocks of the throughput schedule (any widths, one SYRK
         # launch behind each; "chol_tp_segments") give this very factor too, bit for bit, and the same failing minor below
-        for blk, tail in ((512, 1024), (128, 128), (256, 640)):
-            dev.set_option("tp_block", blk); dev.set_option("tp_tail", tail); dev.set_option("chol_tp_segments", 1)
+        # ... left-looking (one deep launch in front of every block: "tp_left" = 1) as well as right-looking (one launch of the
+        # block's width behind every block)
+        for blk, tail, left in ((512, 1024, 1), (512, 1024, 0), (128, 128, 1), (256, 640, 0), (256, 640, 1)):
+            dev.set_option("tp_block", blk); dev.set_option("tp_tail", tail); dev.set_option("tp_left", left)
+            dev.set_option("chol_tp_segments", 1)
             assert dev.factorize() == 0
             L2, V2, a2 = dev.get_factor()
-            assert np.array_equal(L0, L2) and np.array_equal(V0, V2) and np.array_equal(a0, a2), (blk, tail)
+            assert np.array_equal(L0, L2) and np.array_equal(V0, V2) and np.array_equal(a0, a2), (blk, tail, left)
         dev.set_option("chol_tp_segments", 0)
         K = dev.kernel_train(add_alpha=True)
         assert relmax(L1 @ L1.T, K) < 1e-13
@@ -1041,7 +1044,7 @@ def test_cholesky_with_tiles_riding_in_the_panel_launches_is_bit_identical(dev, 
         dev.set_option("chol_overlap", 1)
         dev.set_option("chol_stacked", 2048)
         dev.set_option("chol_tp_segments", 0)
-        dev.set_option("tp_block", 512); dev.set_option("tp_tail", 1024)
+        dev.set_option("tp_block", 512); dev.set_option("tp_tail", 1024); dev.set_option("tp_left", 0)
 
 
 def test_a_panel_step_that_timed_out_is_an_error_not_a_verdict_on_the_matrix(dev):

@@ -13,6 +13,7 @@ N, d, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 streams = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 blk = int(sys.argv[5]) if len(sys.argv) > 5 else 512
 tail = int(sys.argv[6]) if len(sys.argv) > 6 else 1024
+left = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 kid = 3
 rng = np.random.default_rng(0)
 X = rng.uniform(size=(N, d)); y = np.sin(3 * X).sum(1); y = (y - y.mean()) / y.std()
@@ -20,7 +21,7 @@ dv = _lib.Device(0)
 dv.set_train(X, y, np.full(N, 1e-4))
 base = np.log(np.array([2.0] + [0.5] * d)); dv.set_theta(kid, base)
 th = base + rng.uniform(-0.3, 0.3, (B, d + 1))
-dv.set_option("lml_streams", streams); dv.set_option("tp_block", blk); dv.set_option("tp_tail", tail)
+dv.set_option("lml_streams", streams); dv.set_option("tp_block", blk); dv.set_option("tp_tail", tail); dv.set_option("tp_left", left)
 if N > 4096:
     dv.set_option("lml_batch", 8192)        # (the default stops at 4096, where the host's thread farm takes over)
 
@@ -59,7 +60,7 @@ if N <= 4096:
     dv.set_option("chol_tp_segments", 1); dv.set_theta(kid, th[0]); dv.factorize(); L1, V1, a1 = dv.get_factor()
     dv.set_option("chol_tp_segments", 0)
     ok_L = bool(np.array_equal(L0, L1))
-print(f"N={N} d={d} B={B} streams={streams} block={blk} tail={tail}: latency {t_lat * 1e3:.3f} ms | throughput {t_tp * 1e3:.3f} ms "
+print(f"N={N} d={d} B={B} streams={streams} block={blk} tail={tail} left={left}: latency {t_lat * 1e3:.3f} ms | throughput {t_tp * 1e3:.3f} ms "
       f"(x{t_lat / t_tp:.2f}); lml rel {rel_l:.2e} grad rel {rel_g:.2e}; B-invariant {ok_inv}; deterministic {ok_det}; "
       f"L(tp segments) == L(latency) {ok_L}; info {int(np.abs(i0).max())}/{int(np.abs(i1).max())}", flush=True)
 dv.close()
