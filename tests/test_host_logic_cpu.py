@@ -25,6 +25,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.gpry_version() >= 100
 
 
+def test_every_option_of_the_library_is_documented_in_the_header():
+    """ONE option table (csrc/ctx.hip) behind gpry_ctx_set_option / gpry_ctx_get_option; include/gpry_hip.h documents every key
+    (a maintainer binds against the header alone), and the options a fit copies to its extra contexts exist."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    keys = re.findall(r'OPT_INT\("([a-z0-9_]+)"', open(os.path.join(root, "gpry_amd", "csrc", "ctx.hip")).read())
+    header = open(os.path.join(root, "include", "gpry_hip.h")).read()
+    assert len(keys) == len(set(keys)) and len(keys) >= 30
+    missing = [k for k in keys if f'"{k}"' not in header]
+    assert not missing, f"options without a line in include/gpry_hip.h: {missing}"
+    from gpry_amd import gpr as G
+    assert set(G._FIT_CONTEXT_OPTIONS) <= set(keys)
+
+
 def test_product_fails_loudly_without_gpu():
     from gpry_amd import _lib
     if _lib.device_count() > 0:
