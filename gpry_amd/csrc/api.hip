@@ -169,11 +169,14 @@ static int batch_layout(gpry_ctx* ctx, BatchLayout* L) {
     L->stride = o + 32 * 9;                 // not a multiple of a large power of two: consecutive sets start on different channels
     return 0;
 }
+// returns 2 when the device has no room for the arena (the caller halves its chunk), < 0 on any other failure
 static int ensure_batch_buffers(gpry_ctx* ctx, int64_t arena_doubles, int64_t res_bytes) {
     if (arena_doubles > ctx->barena_cap) {
         if (ctx->barena) GPRY_TRY(dev_free(ctx, ctx->barena));
         ctx->barena = nullptr; ctx->barena_cap = 0;
-        GPRY_TRY(dev_alloc(ctx, &ctx->barena, arena_doubles));
+        const hipError_t e = hipMalloc((void**)&ctx->barena, sizeof(double) * (size_t)arena_doubles);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); ctx->barena = nullptr; return 2; }
+        if (e != hipSuccess) { ctx->barena = nullptr; return gpry_fail(ctx, -2, "lml_batch: hipMalloc of the scratch arena failed: %s", hipGetErrorString(e)); }
         ctx->barena_cap = arena_doubles;
     }
     if (res_bytes > ctx->hbres_cap) {
@@ -250,8 +253,7 @@ static int lml_batch_general(gpry_ctx* ctx, const double* thetas, int64_t B, int
     for (;;) {
         const int rc = ensure_batch_buffers(ctx, chunk * L.stride, (int64_t)sizeof(double) * chunk * (GPRY_BRES_STRIDE + 1 + GPRY_MAX_DIM));
         if (rc == 0) break;
-        (void)hipGetLastError();
-        if (!strstr(ctx->err, hipGetErrorString(hipErrorOutOfMemory))) return rc;      // any other failure is the caller's to see
+        if (rc != 2) return rc;             // anything but "out of memory" is the caller's to see
         ctx->batch_shrinks++;
         chunk /= 2;
         if (chunk < min_chunk) {
