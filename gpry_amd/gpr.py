@@ -157,9 +157,9 @@ def fit_schedule(n_train, n_runs):
     products, the Cholesky in column blocks, stream groups inside a call; a theta's value does not depend on how many thetas
     share the call, and differs from the latency schedule's by rounding).  ``GPRY_HIP_FIT_SCHEDULE`` = latency / throughput
     forces one; by default the throughput schedule is taken where whole fits were measured ahead (one MI355X, tools/r06/time_fit.py,
-    profiles/r06_tp.md): 42 restarts at N = 4096, d = 16 in 2.4 s against 3.2 s; equal at N = 2048 (0.39 s), behind at N = 1024
+    profiles/r06_tp.md): 42 restarts at N = 4096, d = 16 in 2.4 s against 3.2 s, 0.50 against 0.58 s at N = 2304; equal at N = 2048 (0.39 s), behind at N = 1024
     (110 against 100 ms) -- per call it is ahead from 4 thetas at N = 4096, 10 at 2048 and 24 at 1024, and a fit's rounds thin
-    out as its runs converge.  So: from 2560 padded rows on, with at least six runs.  ``GPRY_HIP_FIT_TP_GROUPS`` (default 1): groups of a throughput fit -- its calls overlap their
+    out as its runs converge.  So: from 2304 padded rows on, with at least six runs.  ``GPRY_HIP_FIT_TP_GROUPS`` (default 1): groups of a throughput fit -- its calls overlap their
     own stream groups, so all runs share one context and every round is as wide as the fit allows."""
     env = os.environ.get("GPRY_HIP_FIT_SCHEDULE", "auto").lower()
     try:
@@ -170,7 +170,7 @@ def fit_schedule(n_train, n_runs):
         return "latency", None
     if env != "throughput":
         npad = -(-int(n_train) // 128) * 128
-        if npad < 2560 or n_runs < 6:
+        if npad < 2304 or n_runs < 6:
             return "latency", None
     return "throughput", tp_groups
 

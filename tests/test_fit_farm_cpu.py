@@ -883,15 +883,16 @@ def test_predict_leaves_classifier_and_trust_box_to_a_device_that_applies_them()
 def test_schedule_of_a_side_by_side_fit(monkeypatch):
     """Round 6: the batched objective has two schedules (include/gpry_hip.h: "lml_schedule").  The host mirror takes the
     throughput one for the multi-restart fits (gpry/gpr.py:968-984, 10 + 2 d restarts by gpry/run.py:315-325) where whole fits
-    were measured ahead -- from 2560 padded rows on, with at least six runs, all runs in one group --, the latency one (the bits
+    were measured ahead -- from 2304 padded rows on, with at least six runs, all runs in one group --, the latency one (the bits
     of single evaluations) everywhere else; ``GPRY_HIP_FIT_SCHEDULE`` forces either."""
     from gpry_amd import gpr as G
     monkeypatch.delenv("GPRY_HIP_FIT_SCHEDULE", raising=False)
     monkeypatch.delenv("GPRY_HIP_FIT_TP_GROUPS", raising=False)
     assert G.fit_schedule(4096, 42) == ("throughput", 1)
-    assert G.fit_schedule(2561, 6) == ("throughput", 1)          # (pads to 2688)
-    assert G.fit_schedule(2560, 42) == ("throughput", 1)
-    assert G.fit_schedule(2432, 42) == ("latency", None)
+    assert G.fit_schedule(2305, 6) == ("throughput", 1)          # (pads to 2432)
+    assert G.fit_schedule(2304, 42) == ("throughput", 1)
+    assert G.fit_schedule(2177, 42) == ("throughput", 1)         # (pads to 2304)
+    assert G.fit_schedule(2176, 42) == ("latency", None)
     assert G.fit_schedule(1024, 26) == ("latency", None)
     assert G.fit_schedule(4096, 5) == ("latency", None)
     monkeypatch.setenv("GPRY_HIP_FIT_SCHEDULE", "latency")

@@ -586,7 +586,7 @@ def test_restarts_stepped_side_by_side_on_the_device_select_the_sequential_optim
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_side_by_side_fit_under_the_throughput_schedule_equals_its_sequential_loop(monkeypatch):
-    """Round 6: from 2560 padded rows on the side-by-side fit evaluates its rounds with the THROUGHPUT schedule of
+    """Round 6: from 2304 padded rows on the side-by-side fit evaluates its rounds with the THROUGHPUT schedule of
     ``gpry_lml_batch`` (whole-tile products, column-block Cholesky, stream groups) -- a theta's value there does not depend on
     how many thetas share the call.  So the fit (gpry/gpr.py:968-984: the reference's restarts, its start points and RNG order)
     still equals the sequential loop bit for bit -- the loop that evaluates through the same schedule with one theta per call
